@@ -1,0 +1,360 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference implementation on CPU.
+
+Dev-container only: imports the reference from /root/reference (read-only; bytecode
+writes disabled).  The reference never travels to the GPU box -- only the small .npz
+fixtures (inputs + expected outputs, fp32) committed under tests/golden/ do.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Fixture inventory:
+  g1_block      GlobalPoolBiasBlock(32,8,16): eval/train outputs + input/param grads
+  g2_model_tiny SEResNetParams(2,32,8,16,8,32,16,50): state_dict, outputs, grads (randn + board-like obs)
+  g2_model_mid  6x128 and 3x256 with closed-form weights (oracle.synth_state_dict): outputs + grad norms
+  g3_loss       masked log-softmax / clip / entropy / CE / MSE terms + gradients wrt logits
+  g4_gae        reference-test known answers, (128,64) random w/ dones, NaN override, padded
+  g5_update     one full KataGoPPOAlgorithm.update() on CPU with recorded randperm sequences
+  g6_adam       clip_grad_norm_ + Adam, 3 steps
+  g7_scalar     mlp / transformer tiny forward
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+REPO = Path(__file__).resolve().parent.parent
+REF = Path(os.environ.get("KEISEI_REFERENCE", "/root/reference"))
+sys.path.insert(0, str(REF))
+sys.path.insert(0, str(REPO))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from keisei.training import gae as ref_gae  # noqa: E402
+from keisei.training.katago_ppo import (  # noqa: E402
+    KataGoPPOAlgorithm, KataGoPPOParams, KataGoRolloutBuffer, ppo_clip_loss, wdl_cross_entropy_loss,
+)
+from keisei.training.model_registry import build_model  # noqa: E402
+from keisei.training.models.se_resnet import GlobalPoolBiasBlock, SEResNetModel, SEResNetParams, _global_pool  # noqa: E402
+from keisei.training.value_adapter import MultiHeadValueAdapter  # noqa: E402
+
+from oracle import keisei_oracle as orc  # noqa: E402
+
+OUT = REPO / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def npz(name: str, **arrays) -> None:
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    np.savez_compressed(OUT / f"{name}.npz", **conv)
+    size = (OUT / f"{name}.npz").stat().st_size
+    print(f"  wrote {name}.npz  ({size / 1024:.1f} KiB, {len(conv)} arrays)")
+
+
+def sd_arrays(prefix: str, sd) -> dict:
+    return {f"{prefix}{k}": v.detach().clone() for k, v in sd.items()}
+
+
+def g1_block() -> None:
+    torch.manual_seed(11)
+    blk = GlobalPoolBiasBlock(32, 8, 16)
+    with torch.no_grad():  # non-trivial BN affine / running stats
+        for bn in (blk.bn1, blk.bn2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+    x = torch.relu(torch.randn(4, 32, 9, 9))  # block inputs are post-ReLU in the model
+    x[1, 3] = 0.0          # dead channel: amax tie over all 81, sigma = 0
+    x[2, 5] = 0.75         # constant plane: sigma = 0 with non-zero mean
+    cot = torch.randn(4, 32, 9, 9)
+    arrays = sd_arrays("sd.", blk.state_dict())
+    arrays.update(x=x, cot=cot, pool=_global_pool(x))
+    blk.eval()
+    arrays["out_eval"] = blk(x)
+    blk.train()
+    for bn in (blk.bn1, blk.bn2):
+        bn.momentum = 0.0
+    xr = x.clone().requires_grad_(True)
+    out = blk(xr)
+    arrays["out_train"] = out
+    grads = torch.autograd.grad((out * cot).sum(), [xr] + list(blk.parameters()))
+    arrays["grad.x"] = grads[0]
+    for (n, _), g in zip(blk.named_parameters(), grads[1:]):
+        arrays["grad." + n] = g
+    npz("g1_block", **arrays)
+
+
+def _model_case(model, obs, prefix, arrays, cot_seed):
+    g = torch.Generator().manual_seed(cot_seed)
+    model.eval()
+    with torch.no_grad():
+        o = model(obs)
+    arrays[prefix + "eval.policy"] = o.policy_logits.contiguous()
+    arrays[prefix + "eval.value"] = o.value_logits
+    arrays[prefix + "eval.score"] = o.score_lead
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    o = model(obs)
+    arrays[prefix + "train.policy"] = o.policy_logits.contiguous()
+    arrays[prefix + "train.value"] = o.value_logits
+    arrays[prefix + "train.score"] = o.score_lead
+    cp = torch.randn(o.policy_logits.shape, generator=g)
+    cv = torch.randn(o.value_logits.shape, generator=g)
+    cs = torch.randn(o.score_lead.shape, generator=g)
+    arrays[prefix + "cot.policy"], arrays[prefix + "cot.value"], arrays[prefix + "cot.score"] = cp, cv, cs
+    loss = (o.policy_logits * cp).sum() / obs.shape[0] + (o.value_logits * cv).sum() + (o.score_lead * cs).sum()
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    return dict(zip([n for n, _ in model.named_parameters()], grads))
+
+
+def g2_model_tiny() -> None:
+    torch.manual_seed(22)
+    params = SEResNetParams(num_blocks=2, channels=32, se_reduction=8, global_pool_channels=16,
+                            policy_channels=8, value_fc_size=32, score_fc_size=16, obs_channels=50)
+    model = SEResNetModel(params)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.6, 1.4)
+    arrays = sd_arrays("sd.", model.state_dict())
+    obs_a = torch.randn(4, 50, 9, 9)
+    obs_b = orc.board_like_obs(4, seed=5)
+    arrays["randn.obs"], arrays["board.obs"] = obs_a, obs_b
+    for tag, obs, seed in (("randn.", obs_a, 1), ("board.", obs_b, 2)):
+        grads = _model_case(model, obs, tag, arrays, seed)
+        for n, gval in grads.items():
+            arrays[f"{tag}grad.{n}"] = gval
+    npz("g2_model_tiny", **arrays)
+
+
+def g2_model_mid() -> None:
+    arrays = {}
+    for tag, shape, batch in (
+        ("s6x128.", orc.NetShape(num_blocks=6, channels=128), 3),
+        ("s3x256.", orc.NetShape(num_blocks=3, channels=256), 2),
+    ):
+        model = SEResNetModel(SEResNetParams(**shape.__dict__))
+        model.load_state_dict(orc.synth_state_dict(shape), strict=True)
+        obs = torch.randn(batch, 50, 9, 9, generator=torch.Generator().manual_seed(77))
+        arrays[tag + "obs"] = obs
+        grads = _model_case(model, obs, tag, arrays, 3)
+        # grads are large: store norms for every tensor and full tensors for a few small ones
+        arrays[tag + "grad_names"] = np.array(list(grads.keys()))
+        arrays[tag + "grad_norms"] = np.array([float(g.double().norm()) for g in grads.values()])
+        for n in ("input_bn.weight", "blocks.0.bn1.bias", "blocks.1.se_fc1.weight",
+                  "policy_conv1.weight", "value_fc2.weight", "score_fc2.bias"):
+            arrays[f"{tag}grad.{n}"] = grads[n]
+        arrays[tag + "grad.blocks.0.conv1.weight[:4]"] = grads["blocks.0.conv1.weight"][:4]
+        arrays[tag + "grad.input_conv.weight[:4]"] = grads["input_conv.weight"][:4]
+    npz("g2_model_mid", **arrays)
+
+
+def g3_loss() -> None:
+    arrays = {}
+    for tag, legal_kind, all_ignored in (("third.", "third", False), ("ragged.", "ragged", True)):
+        mb = orc.synth_minibatch(4, seed=31 if tag == "third." else 32, legal_kind=legal_kind,
+                                 all_ignored=all_ignored)
+        g = torch.Generator().manual_seed(33)
+        logits = (2.0 * torch.randn(4, 9, 9, 139, generator=g)).requires_grad_(True)
+        vlog = torch.randn(4, 3, generator=g).requires_grad_(True)
+        score = torch.randn(4, 1, generator=g).requires_grad_(True)
+        # -- the reference's own statements, katago_ppo.py:858-924 (inline path, no adapter)
+        flat = logits.reshape(4, -1)
+        masked = flat.masked_fill(~mb["legal"], float("-inf"))
+        lp_all = torch.nn.functional.log_softmax(masked, dim=-1)
+        new_lp = lp_all.gather(1, mb["actions"].unsqueeze(1)).squeeze(1)
+        old_lp = (new_lp.detach() + 0.3 * torch.randn(4, generator=g))
+        pl = ppo_clip_loss(new_lp, old_lp, mb["advantages"], 0.2)
+        probs = lp_all.exp()
+        ent = -(probs * lp_all.masked_fill(~mb["legal"], 0.0)).sum(dim=-1).mean()
+        vl = wdl_cross_entropy_loss(vlog, mb["value_cats"])
+        sl = torch.nn.functional.mse_loss(score.squeeze(-1), mb["score_targets"])
+        total = 1.0 * pl + (1.5 * vl + 0.1 * sl) - 0.01 * ent
+        gl, gv, gs = torch.autograd.grad(total, [logits, vlog, score])
+        adapter = MultiHeadValueAdapter(1.5, 0.1, 0.1)
+        arrays.update({
+            tag + "logits": logits, tag + "value_logits": vlog, tag + "score": score,
+            tag + "legal": mb["legal"], tag + "actions": mb["actions"], tag + "old_log_probs": old_lp,
+            tag + "advantages": mb["advantages"], tag + "value_cats": mb["value_cats"],
+            tag + "score_targets": mb["score_targets"],
+            tag + "new_log_probs": new_lp, tag + "policy_loss": pl, tag + "entropy": ent,
+            tag + "value_loss": vl, tag + "score_loss": sl, tag + "total": total,
+            tag + "adapter_loss": adapter.compute_value_loss(vlog, None, mb["value_cats"], mb["score_targets"], score),
+            tag + "scalar_value": adapter.scalar_value_from_output(vlog),
+            tag + "scalar_blended": adapter.scalar_value_blended(vlog, score * 3),
+            tag + "grad.logits": gl, tag + "grad.value_logits": gv, tag + "grad.score": gs,
+        })
+    npz("g3_loss", **arrays)
+
+
+def g4_gae() -> None:
+    arrays = {}
+    g = torch.Generator().manual_seed(123)
+    T, N = 128, 64
+    rewards = 0.1 * torch.randn(T, N, generator=g)
+    values = torch.randn(T, N, generator=g)
+    term = torch.rand(T, N, generator=g) < 0.05
+    nv = torch.randn(N, generator=g)
+    arrays.update(rewards=rewards, values=values, terminated=term, next_value=nv)
+    arrays["adv_loop"] = ref_gae.compute_gae(rewards, values, term, nv, 0.99, 0.95)
+    arrays["adv_gpu"] = ref_gae.compute_gae_gpu(rewards, values, term.float(), nv, 0.99, 0.95)
+    ov = torch.full((T, N), float("nan"))
+    pick = torch.rand(T, N, generator=g) < 0.1
+    ov[pick] = torch.randn(int(pick.sum()), generator=g)
+    arrays["override"] = ov
+    arrays["adv_override"] = ref_gae.compute_gae(rewards, values, term, nv, 0.99, 0.95, next_value_override=ov)
+    arrays["adv_override_gpu"] = ref_gae.compute_gae_gpu(rewards, values, term.float(), nv, 0.99, 0.95,
+                                                         next_value_override=ov)
+    # alternating-perspective pattern (katago_ppo.py:320-362): override = -V[t+1] on non-terminal cells
+    alt = torch.full((T, N), float("nan"))
+    alt[:-1] = torch.where(term[:-1], torch.tensor(float("nan")), -values[1:])
+    arrays["override_alt"] = alt
+    arrays["adv_override_alt"] = ref_gae.compute_gae(rewards, values, term, nv, 0.99, 0.95, next_value_override=alt)
+    # padded: ragged lengths, padding terminated = 1
+    lengths = torch.randint(1, T + 1, (N,), generator=g)
+    lengths[0], lengths[1] = T, 1
+    term_p = term.float().clone()
+    for i in range(N):
+        term_p[int(lengths[i]):, i] = 1.0
+    arrays["lengths"] = lengths
+    arrays["terminated_padded"] = term_p
+    arrays["adv_padded"] = ref_gae.compute_gae_padded(rewards, values, term_p, nv, lengths, 0.99, 0.95)
+    arrays["adv_padded_gpu"] = ref_gae.compute_gae_padded_gpu(rewards, values, term_p, nv, lengths, 0.99, 0.95)
+    arrays["adv_padded_override"] = ref_gae.compute_gae_padded(rewards, values, term_p, nv, lengths, 0.99, 0.95,
+                                                               next_value_override=ov)
+    # 1-D trajectory, edge parameters
+    r1 = torch.tensor([1.0, 2.0, 3.0, -1.0, 0.5])
+    v1 = torch.tensor([0.5, 0.4, 0.3, 0.2, 0.1])
+    d1 = torch.tensor([False, False, True, False, False])
+    arrays.update(r1=r1, v1=v1, d1=d1)
+    for tag, (gm, lm) in {"a": (0.99, 0.95), "b": (1.0, 1.0), "c": (0.9, 0.0), "d": (0.0, 0.5)}.items():
+        arrays["adv1_" + tag] = ref_gae.compute_gae(r1, v1, d1, torch.tensor(0.3), gm, lm)
+    # float64 values -> float64 arithmetic (gae.py:49)
+    arrays["adv_f64"] = ref_gae.compute_gae(rewards[:16, :4], values[:16, :4].double(), term[:16, :4],
+                                            nv[:4].double(), 0.99, 0.95)
+    npz("g4_gae", **arrays)
+
+
+def _fill_buffer(buf, T, N, gen, with_override):
+    for t in range(T):
+        legal = torch.rand(N, 11259, generator=gen) < 0.02
+        acts = torch.randint(0, 11259, (N,), generator=gen)
+        legal[torch.arange(N), acts] = True
+        last = t == T - 1
+        dones = torch.full((N,), last)
+        cats = torch.randint(0, 3, (N,), generator=gen) if last else torch.full((N,), -1)
+        buf.add(obs=torch.randn(N, 50, 9, 9, generator=gen), actions=acts,
+                log_probs=-5.0 + 0.2 * torch.randn(N, generator=gen), values=0.3 * torch.randn(N, generator=gen),
+                rewards=0.1 * torch.randn(N, generator=gen), dones=dones, terminated=dones.clone(),
+                legal_masks=legal, value_categories=cats,
+                score_targets=torch.randn(N, generator=gen).clamp(-1.5, 1.5),
+                next_value_override=(torch.full((N,), float("nan")) if with_override else None))
+
+
+def g5_update() -> None:
+    torch.manual_seed(55)
+    mparams = dict(num_blocks=1, channels=32, se_reduction=8, global_pool_channels=16,
+                   policy_channels=8, value_fc_size=32, score_fc_size=16, obs_channels=50)
+    model = build_model("se_resnet", mparams)
+    arrays = sd_arrays("sd0.", model.state_dict())
+    T, N = 4, 4
+    pp = KataGoPPOParams(learning_rate=1e-3, epochs_per_batch=2, batch_size=8, lambda_score=0.1,
+                         score_blend_alpha=0.1)
+    algo = KataGoPPOAlgorithm(pp, model)
+    adapter = MultiHeadValueAdapter(pp.lambda_value, pp.lambda_score, pp.score_blend_alpha)
+    buf = KataGoRolloutBuffer(num_envs=N, obs_shape=(50, 9, 9), action_space=11259)
+    gen = torch.Generator().manual_seed(56)
+    _fill_buffer(buf, T, N, gen, with_override=True)
+    buf.fill_alternating_perspective_overrides()
+    flat = buf.flatten()
+    for k, v in flat.items():
+        arrays["buf." + k] = v.clone()
+    next_values = 0.3 * torch.randn(N, generator=gen)
+    arrays["next_values"] = next_values
+    perms = []
+    real_randperm = torch.randperm
+
+    def recording_randperm(n, *a, **kw):
+        p = real_randperm(n, *a, **kw)
+        perms.append(p.clone())
+        return p
+
+    torch.randperm = recording_randperm
+    try:
+        metrics = algo.update(buf, next_values, value_adapter=adapter)
+    finally:
+        torch.randperm = real_randperm
+    arrays["perms"] = torch.stack(perms)
+    for k, v in metrics.items():
+        arrays["metric." + k] = np.float64(v)
+    arrays.update(sd_arrays("sd1.", model.state_dict()))
+    opt = algo.optimizer.state_dict()["state"]
+    arrays["opt.step"] = np.float64(float(opt[0]["step"]))
+    arrays["opt.exp_avg.0"] = opt[0]["exp_avg"]
+    arrays["opt.exp_avg_sq.0"] = opt[0]["exp_avg_sq"]
+    arrays["hyper"] = np.array([pp.learning_rate, pp.gamma, pp.gae_lambda, pp.clip_epsilon, pp.lambda_policy,
+                                pp.lambda_value, pp.lambda_score, pp.lambda_entropy, pp.grad_clip,
+                                pp.epochs_per_batch, pp.batch_size, T, N])
+    npz("g5_update", **arrays)
+
+
+def g6_adam() -> None:
+    g = torch.Generator().manual_seed(66)
+    shapes = [(7,), (5, 3), (2, 3, 3, 3), (1,), (64, 9)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    opt = torch.optim.Adam(params, lr=2e-4)
+    arrays = {f"p0.{i}": p.detach().clone() for i, p in enumerate(params)}
+    for step in range(3):
+        scale = [3.0, 0.05, 1.0][step]  # step 0 clips hard, step 1 does not clip
+        for i, p in enumerate(params):
+            p.grad = scale * torch.randn(p.shape, generator=g)
+            arrays[f"g{step}.{i}"] = p.grad.clone()
+        norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        arrays[f"norm{step}"] = norm
+        opt.step()
+        for i, p in enumerate(params):
+            arrays[f"p{step + 1}.{i}"] = p.detach().clone()
+    st = opt.state_dict()["state"]
+    for i in range(len(params)):
+        arrays[f"m.{i}"] = st[i]["exp_avg"]
+        arrays[f"v.{i}"] = st[i]["exp_avg_sq"]
+    npz("g6_adam", **arrays)
+
+
+def g7_scalar() -> None:
+    """Scalar-contract models: weights from the closed-form generator (policy_fc alone is
+    MBs), so only obs + outputs are stored."""
+    arrays = {}
+    obs = torch.randn(3, 50, 9, 9, generator=torch.Generator().manual_seed(70))
+    arrays["obs"] = obs
+    for arch, p in (("mlp", {"hidden_sizes": [32, 16]}), ("transformer", {"d_model": 32, "nhead": 4, "num_layers": 2}),
+                    ("resnet", {"hidden_size": 16, "num_layers": 2})):
+        m = build_model(arch, p).eval()
+        m.load_state_dict(orc.closed_form_fill(m.state_dict()), strict=True)
+        with torch.no_grad():
+            pol, val = m(obs)
+        arrays[f"{arch}.policy"], arrays[f"{arch}.value"] = pol, val
+    npz("g7_scalar", **arrays)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    for fn in (g1_block, g2_model_tiny, g2_model_mid, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar):
+        if only and fn.__name__ not in only:
+            continue
+        print(fn.__name__)
+        fn()

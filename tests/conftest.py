@@ -1,0 +1,59 @@
+"""pytest config: registers the `gpu` marker; GPU tests are skipped when no GPU is visible."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    """Lazy view over one tests/golden/*.npz fixture returning torch tensors."""
+
+    def __init__(self, name: str):
+        self._z = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+
+    def __contains__(self, k):
+        return k in self._z.files
+
+    def keys(self):
+        return list(self._z.files)
+
+    def np(self, k):
+        return self._z[k]
+
+    def __getitem__(self, k) -> torch.Tensor:
+        return torch.from_numpy(np.array(self._z[k]))
+
+    def sub(self, prefix: str) -> dict:
+        return {k[len(prefix):]: self[k] for k in self._z.files if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return load

@@ -1,0 +1,209 @@
+"""Pins the CPU oracle (oracle/keisei_oracle.py) against (a) golden vectors produced by the real
+reference (oracle/make_golden.py) and (b) the known answers the reference's own tests hold
+(tests/test_gae.py, tests/test_se_resnet.py:206-219, tests/test_value_adapter.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import keisei_oracle as orc
+
+TOL = dict(rtol=1e-5, atol=1e-5)   # the reference's own alternate-backend bound (tests/test_torch_compile.py:340-347)
+
+
+def test_global_pool_known_answer():
+    # reference tests/test_se_resnet.py:206-219: 2x2 plane [1,2,3,4] -> mean 2.5, max 4, std sqrt(1.25)
+    x = torch.tensor([[[[1.0, 2.0], [3.0, 4.0]]]])
+    p = orc.global_pool(x)
+    assert torch.allclose(p, torch.tensor([[2.5, 4.0, math.sqrt(1.25)]]), atol=1e-6)
+    const = torch.full((2, 3, 9, 9), 0.7)
+    assert torch.all(orc.global_pool(const)[:, 6:] == 0)  # tests/test_se_resnet.py:176-196
+
+
+def test_block_matches_reference(golden):
+    g = golden("g1_block")
+    sd = {"b." + k: v for k, v in g.sub("sd.").items()}
+    x = g["x"]
+    assert torch.allclose(orc.global_pool(x), g["pool"], **TOL)
+    out = orc.block_forward(sd, "b.", x, train=False)
+    assert torch.allclose(out, g["out_eval"], **TOL)
+    names = [k for k in sd if sd[k].dtype.is_floating_point and "running" not in k]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    xr = x.clone().requires_grad_(True)
+    live = dict(sd); live.update(leaves)
+    out = orc.block_forward(live, "b.", xr, train=True, momentum=0.0)
+    assert torch.allclose(out, g["out_train"], **TOL)
+    grads = torch.autograd.grad((out * g["cot"]).sum(), [xr] + list(leaves.values()))
+    assert torch.allclose(grads[0], g["grad.x"], rtol=1e-4, atol=2e-5)
+    for n, gr in zip(names, grads[1:]):
+        ref = g["grad." + n[2:]]
+        assert torch.allclose(gr, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()) + 1e-6), n
+
+
+@pytest.mark.parametrize("tag", ["randn.", "board."])
+def test_tiny_model_matches_reference(golden, tag):
+    g = golden("g2_model_tiny")
+    sd = g.sub("sd.")
+    obs = g[tag + "obs"]
+    p, v, s = orc.seresnet_forward(dict(sd), obs, 2, train=False)
+    assert p.shape == (4, 9, 9, 139)
+    assert torch.allclose(p, g[tag + "eval.policy"], **TOL)
+    assert torch.allclose(v, g[tag + "eval.value"], **TOL)
+    assert torch.allclose(s, g[tag + "eval.score"], **TOL)
+    names = [k for k in sd if sd[k].dtype.is_floating_point and "running" not in k]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    live = dict(sd); live.update(leaves)
+    p, v, s = orc.seresnet_forward(live, obs, 2, train=True, momentum=0.0)
+    assert torch.allclose(p, g[tag + "train.policy"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(v, g[tag + "train.value"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(s, g[tag + "train.score"], rtol=1e-4, atol=2e-5)
+    loss = (p * g[tag + "cot.policy"]).sum() / 4 + (v * g[tag + "cot.value"]).sum() + (s * g[tag + "cot.score"]).sum()
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    for n, gr in zip(names, grads):
+        ref = g[f"{tag}grad.{n}"]
+        assert torch.allclose(gr, ref, rtol=1e-3, atol=1e-4 * float(ref.abs().max()) + 1e-6), n
+
+
+@pytest.mark.parametrize("tag,shape", [("s6x128.", orc.NetShape(6, 128)), ("s3x256.", orc.NetShape(3, 256))])
+def test_mid_models_closed_form_weights(golden, tag, shape):
+    g = golden("g2_model_mid")
+    sd = orc.synth_state_dict(shape)
+    obs = g[tag + "obs"]
+    p, v, s = orc.seresnet_forward(dict(sd), obs, shape.num_blocks, train=False)
+    assert torch.allclose(p, g[tag + "eval.policy"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(v, g[tag + "eval.value"], rtol=1e-4, atol=2e-5)
+    p, v, s = orc.seresnet_forward(dict(sd), obs, shape.num_blocks, train=True, momentum=0.0)
+    assert torch.allclose(p, g[tag + "train.policy"], rtol=1e-4, atol=5e-5)
+    assert torch.allclose(s, g[tag + "train.score"], rtol=1e-4, atol=5e-5)
+
+
+def test_state_dict_contract(golden):
+    g = golden("g2_model_tiny")
+    sd = g.sub("sd.")
+    spec = orc.state_dict_spec(orc.NetShape(2, 32, 8, 16, 8, 32, 16, 50))
+    assert list(spec.keys()) == list(sd.keys())
+    for k, shp in spec.items():
+        assert tuple(sd[k].shape) == shp, k
+
+
+@pytest.mark.parametrize("tag", ["third.", "ragged."])
+def test_losses_match_reference(golden, tag):
+    g = golden("g3_loss")
+    logits = g[tag + "logits"].requires_grad_(True)
+    vlog = g[tag + "value_logits"].requires_grad_(True)
+    score = g[tag + "score"].requires_grad_(True)
+    w = orc.LossWeights(1.0, 1.5, 0.1, 0.01, 0.2)
+    out = orc.ppo_losses(logits, vlog, score, g[tag + "legal"], g[tag + "actions"], g[tag + "old_log_probs"],
+                         g[tag + "advantages"], g[tag + "value_cats"], g[tag + "score_targets"], w)
+    for k in ("policy_loss", "entropy", "value_loss", "score_loss", "total"):
+        assert torch.allclose(out[k], g[tag + k], rtol=1e-5, atol=1e-6), k
+    assert torch.allclose(out["new_log_probs"], g[tag + "new_log_probs"], **TOL)
+    gl, gv, gs = torch.autograd.grad(out["total"], [logits, vlog, score])
+    assert torch.allclose(gl, g[tag + "grad.logits"], rtol=1e-5, atol=1e-8)
+    assert torch.allclose(gv, g[tag + "grad.value_logits"], rtol=1e-5, atol=1e-8)
+    assert torch.allclose(gs, g[tag + "grad.score"], rtol=1e-5, atol=1e-8)
+    assert torch.allclose(orc.scalar_value(vlog), g[tag + "scalar_value"], **TOL)
+    assert torch.allclose(orc.scalar_value_blended(vlog, score * 3, 0.1), g[tag + "scalar_blended"], **TOL)
+    assert torch.allclose(1.5 * out["value_loss"] + 0.1 * out["score_loss"], g[tag + "adapter_loss"], **TOL)
+
+
+def test_loss_guards():
+    mb = orc.synth_minibatch(2, legal_kind="third")
+    logits = torch.zeros(2, 9, 9, 139)
+    args = (torch.zeros(2, 3), torch.zeros(2, 1), mb["legal"], mb["actions"], mb["old_log_probs"],
+            mb["advantages"], mb["value_cats"], mb["score_targets"], orc.LossWeights())
+    bad = logits.clone(); bad[0, 0, 0, 0] = float("nan")
+    with pytest.raises(RuntimeError, match="NaN in raw policy logits"):
+        orc.ppo_losses(bad, *args)
+    legal = mb["legal"].clone(); legal[1] = False
+    with pytest.raises(RuntimeError, match="zero legal actions"):
+        orc.ppo_losses(logits, args[0], args[1], legal, *args[3:])
+
+
+def test_gae_known_answers():
+    # reference tests/test_gae.py:10-40
+    a = orc.gae_single(np.float32([1.0]), np.float32([0.5]), [False], np.float32(0.3), 0.99, 0.95)
+    assert abs(a[0] - 0.797) < 1e-3
+    a = orc.gae_single(np.float32([1, 2]), np.float32([0.5, 0.5]), [True, False], np.float32(0.3), 0.99, 0.95)
+    assert abs(a[0] - 0.5) < 1e-3
+    a = orc.gae_single(np.float32([1, 2, 3]), np.float32([0.5] * 3), [False] * 3, np.float32(0.0), 0.99, 0.95)
+    assert abs(a[2] - 2.5) < 1e-3 and abs(a[1] - 4.34625) < 1e-3 and abs(a[0] - 5.081) < 1e-2
+
+
+def test_gae_matches_reference_bitwise(golden):
+    g = golden("g4_gae")
+    r, v, t, nv = (g.np(k) for k in ("rewards", "values", "terminated", "next_value"))
+    adv = orc.gae_grid(r, v, t, nv, 0.99, 0.95)
+    assert np.array_equal(adv, g.np("adv_gpu"))          # same op order as compute_gae_gpu -> bit-exact
+    assert np.allclose(adv, g.np("adv_loop"), rtol=1e-5, atol=1e-5)
+    ov = g.np("override")
+    assert np.array_equal(orc.gae_grid(r, v, t, nv, 0.99, 0.95, ov), g.np("adv_override_gpu"))
+    assert np.allclose(orc.gae_grid(r, v, t, nv, 0.99, 0.95, ov), g.np("adv_override"), rtol=1e-5, atol=1e-5)
+    assert np.allclose(orc.gae_grid(r, v, t, nv, 0.99, 0.95, g.np("override_alt")), g.np("adv_override_alt"),
+                       rtol=1e-5, atol=1e-5)
+    tp, ln = g.np("terminated_padded"), g.np("lengths")
+    assert np.array_equal(orc.gae_grid(r, v, tp, nv, 0.99, 0.95, lengths=ln), g.np("adv_padded_gpu"))
+    assert np.allclose(orc.gae_grid(r, v, tp, nv, 0.99, 0.95, lengths=ln), g.np("adv_padded"), rtol=1e-5, atol=1e-5)
+    assert np.allclose(orc.gae_grid(r, v, tp, nv, 0.99, 0.95, ov, ln), g.np("adv_padded_override"), rtol=1e-5, atol=1e-5)
+    for tag, (gm, lm) in {"a": (0.99, 0.95), "b": (1.0, 1.0), "c": (0.9, 0.0), "d": (0.0, 0.5)}.items():
+        a = orc.gae_single(g.np("r1"), g.np("v1"), g.np("d1"), np.float32(0.3), gm, lm)
+        assert np.allclose(a, g.np("adv1_" + tag), rtol=1e-6, atol=1e-6), tag
+    a64 = orc.gae_grid(r[:16, :4], v[:16, :4].astype(np.float64), t[:16, :4], nv[:4].astype(np.float64), 0.99, 0.95)
+    assert a64.dtype == np.float64 and np.allclose(a64, g.np("adv_f64"), rtol=1e-12, atol=1e-12)
+
+
+def test_adam_clip_matches_reference(golden):
+    g = golden("g6_adam")
+    n = 5
+    params = [g[f"p0.{i}"].clone() for i in range(n)]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    for step in range(3):
+        grads = [g[f"g{step}.{i}"].clone() for i in range(n)]
+        norm = orc.clip_and_adam(params, grads, m, v, step + 1, 2e-4, 1.0)
+        assert torch.allclose(norm, g[f"norm{step}"], rtol=1e-6)
+        for i in range(n):
+            assert torch.allclose(params[i], g[f"p{step + 1}.{i}"], rtol=1e-6, atol=1e-7), (step, i)
+    for i in range(n):
+        assert torch.allclose(m[i], g[f"m.{i}"], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(v[i], g[f"v.{i}"], rtol=1e-5, atol=1e-10)
+
+
+def test_full_update_matches_reference(golden):
+    """Replays the reference's KataGoPPOAlgorithm.update() (fixture g5) minibatch by minibatch
+    with the oracle's primitives and the recorded randperm sequences."""
+    g = golden("g5_update")
+    hp = g.np("hyper")
+    lr, gamma, lam, eps, lp, lv, ls, le, clip, epochs, bs, T, N = hp
+    T, N, bs, epochs = int(T), int(N), int(bs), int(epochs)
+    sd = g.sub("sd0.")
+    buf = g.sub("buf.")
+    adv = orc.gae_grid(buf["rewards"].reshape(T, N).numpy(), buf["values"].reshape(T, N).numpy(),
+                       buf["terminated"].reshape(T, N).numpy(), g.np("next_values"), gamma, lam,
+                       buf["next_value_override"].reshape(T, N).numpy())
+    adv = orc.normalize_advantages(torch.from_numpy(adv).reshape(-1))
+    w = orc.LossWeights(lp, lv, ls, le, eps)
+    state, acc, n_upd = None, {}, 0
+    for perm in g["perms"]:
+        for s0 in range(0, T * N, bs):
+            idx = perm[s0:s0 + bs]
+            batch = {"obs": buf["observations"][idx], "legal": buf["legal_masks"][idx], "actions": buf["actions"][idx],
+                     "old_log_probs": buf["log_probs"][idx], "advantages": adv[idx],
+                     "value_cats": buf["value_categories"][idx], "score_targets": buf["score_targets"][idx]}
+            met, state, _ = orc.ppo_minibatch_step(sd, 1, batch, w, state, lr=lr, grad_clip=clip)
+            for k, val in met.items():
+                acc[k] = acc.get(k, 0.0) + val
+            n_upd += 1
+    assert n_upd == epochs * math.ceil(T * N / bs)
+    assert abs(acc["policy_loss"] / n_upd - float(g.np("metric.policy_loss"))) < 1e-4
+    assert abs(acc["entropy"] / n_upd - float(g.np("metric.entropy"))) < 1e-4
+    assert abs(acc["gradient_norm"] / n_upd - float(g.np("metric.gradient_norm"))) < 1e-3
+    combined = (lv * acc["value_loss"] + ls * acc["score_loss"]) / n_upd   # adapter path reports the combined term
+    assert abs(combined - float(g.np("metric.value_loss"))) < 1e-4
+    ref = g.sub("sd1.")
+    for k in ref:
+        if ref[k].dtype.is_floating_point:
+            assert torch.allclose(sd[k], ref[k], rtol=1e-3, atol=2e-5), k
+        else:
+            assert int(sd[k]) == int(ref[k]), k

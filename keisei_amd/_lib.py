@@ -1,0 +1,147 @@
+"""ctypes binding of libkeisei_amd.so (the C ABI declared in include/keisei_amd.h).
+
+The library is the only compute backend for CUDA/HIP tensors: if it is missing or fails to
+load, every GPU entry point raises -- there is no eager/PyTorch fallback on the GPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libkeisei_amd.so"
+
+# signature strings: p = pointer (torch tensor | int | None), i = int, f = float, d = double, q = long long
+_SIGS = {
+    "ka_conv3x3_fwd": "pppppp i pp iii i p",
+    "ka_conv3x3_sqpart_rows": "i",
+    "ka_pack_conv3x3": "pp iiii i i p",
+    "ka_wgrad_splits": "iii",
+    "ka_conv3x3_wgrad": "ppppp i pp iiii i i p",
+    "ka_obs_to_nhwc": "ppp iii i p",
+    "ka_nhwc_to_nchw": "pp ii i p",
+    "ka_bn_reduce": "p i p i i p p",
+    "ka_pair_reduce": "pp ii p p",
+    "ka_bn_coeffs": "p d pppp ff pppp i p",
+    "ka_bn_eval_coeffs": "pppp f pp i p",
+    "ka_bn_bwd_coeffs": "pp d ppp ppp i p",
+    "ka_affine_rows": "ppp f p ii p",
+    "ka_bn_bwd_apply": "pppp ii i p",
+    "ka_block_tail_fwd": "ppppp pp ii i p",
+    "ka_tail_bwd_reduce": "pppppp p ii i p",
+    "ka_tail_bwd_dz": "ppppppp ppp ii i p",
+    "ka_relu_bn_bwd_reduce": "pppppp ppp ii i p",
+    "ka_block_dx": "ppppp p ii i p",
+    "ka_gemm": "pppp iii iii ii iii i i p",
+    "ka_reduce_slabs": "pp i q i p",
+    "ka_colsum": "pppp ii i p",
+    "ka_relu_mask": "pp q p",
+    "ka_rows_affine_relu": "pppp q i p",
+    "ka_rows_bn_bwd": "pppp q i i p",
+    "ka_rows_bn_sums": "pppp pp ii i p",
+    "ka_rows_sq_sums": "ppp ii i p",
+    "ka_policy_loss": "pppppp pppp pp fff ii p",
+    "ka_value_loss": "ppppp pp pp pp p ffff i i p",
+    "ka_scalar_value": "pp f p i p",
+    "ka_adam_chunk": "",
+    "ka_clip_adam_step": "ppp i ppp ppp fffff p",
+    "ka_gae": "ppppp pp ii dd i p",
+    "ka_normalize_advantages": "pp q p",
+    "ka_version": "",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}
+
+_lib: Optional[ctypes.CDLL] = None
+_load_error: Optional[str] = None
+
+
+class KeiseiHipError(RuntimeError):
+    """Raised when a libkeisei_amd.so entry point reports failure (or the library is absent)."""
+
+
+def _load() -> ctypes.CDLL:
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise KeiseiHipError(_load_error)
+    if not _LIB_PATH.exists():
+        _load_error = (f"{_LIB_PATH} is missing: build it with `python -m keisei_amd.build` "
+                       "(hipcc --offload-arch=gfx950). There is no fallback for GPU tensors.")
+        raise KeiseiHipError(_load_error)
+    try:
+        lib = ctypes.CDLL(str(_LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        _load_error = f"cannot load {_LIB_PATH}: {e}"
+        raise KeiseiHipError(_load_error) from e
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_CT[c] for c in sig.replace(" ", "")]
+        fn.restype = ctypes.c_int
+    lib.ka_last_error.restype = ctypes.c_char_p
+    lib.ka_last_error.argtypes = []
+    lib.ka_target_arch.restype = ctypes.c_char_p
+    lib.ka_target_arch.argtypes = []
+    _lib = lib
+    return lib
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def exported_symbols() -> list:
+    """Names this binding expects the shared library to export (checked by the CPU tests)."""
+    return sorted(list(_SIGS) + ["ka_last_error", "ka_target_arch"])
+
+
+def available() -> bool:
+    try:
+        _load()
+        return True
+    except KeiseiHipError:
+        return False
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    return int(x)
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def call(name: str, *args) -> None:
+    """Call a status-returning entry point; raises KeiseiHipError with ka_last_error() on failure."""
+    lib = _load()
+    sig = _SIGS[name].replace(" ", "")
+    if len(args) != len(sig):
+        raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
+    conv = [(_ptr(a) if c == "p" else a) for c, a in zip(sig, args)]
+    rc = getattr(lib, name)(*conv)
+    if rc != 0:
+        raise KeiseiHipError(f"{name} failed ({rc}): {lib.ka_last_error().decode()}")
+
+
+def query(name: str, *args) -> int:
+    """Call an int-returning pure query (no status convention)."""
+    lib = _load()
+    return int(getattr(lib, name)(*args))
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return DTYPE_F32
+    if dt == torch.bfloat16:
+        return DTYPE_BF16
+    raise KeiseiHipError(f"unsupported activation dtype {dt} (float32 or bfloat16)")

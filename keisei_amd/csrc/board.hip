@@ -1,0 +1,597 @@
+// Per-board kernels around the convolutions: BatchNorm statistics/coefficients, the fused
+// SE + residual + ReLU + global-pool tail of GlobalPoolBiasBlock, and their backward passes.
+//
+// All are HBM-bound streaming kernels over NHWC (B,81,C) activations.  One workgroup owns one
+// board; a thread owns 2 adjacent channels (4-byte bf16x2 / 8-byte f32x2 accesses, a wave
+// covers a contiguous 256/512-byte run along the channel axis) and a strided subset of the
+// 81 squares, which it keeps in registers, so every per-(board,channel) reduction -- global
+// pool mean/max/std, SE squeeze, the BN partial sums -- is a register loop plus one small LDS
+// combine, and two-pass statistics (std, tie counts) never re-read HBM.
+//
+// Reference semantics: keisei/training/models/se_resnet.py:68-98 (forward) and the autograd
+// derivatives of mean / amax (ties share the gradient equally) / std(correction=0) (zero where
+// sigma == 0) / BatchNorm2d (training mode) / sigmoid gate.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPPT = 41;     // squares per thread when 2 square-slices are used (81/2)
+
+struct BoardMap {
+    int cpw;      // channel pairs handled per pass
+    int ph;       // square slices
+    int cp;       // this thread's channel pair within the pass
+    int slice;    // this thread's square slice
+    bool active;
+    __device__ BoardMap(int C) {
+        const int pairs = C >> 1;
+        cpw = pairs < 128 ? pairs : 128;
+        ph = kThreads / cpw;
+        if (ph > KA_BOARD) ph = KA_BOARD;
+        cp = threadIdx.x % cpw;
+        slice = threadIdx.x / cpw;
+        active = slice < ph;
+    }
+};
+
+// combine per-slice partials: red[slice][cpw*2]; returns total for this thread's pair (all threads)
+__device__ __forceinline__ f32x2 combine_sum(float* red, const BoardMap& m, f32x2 v) {
+    __syncthreads();
+    if (m.active) { red[(m.slice * m.cpw + m.cp) * 2] = v[0]; red[(m.slice * m.cpw + m.cp) * 2 + 1] = v[1]; }
+    __syncthreads();
+    f32x2 t = {0.f, 0.f};
+    for (int s = 0; s < m.ph; ++s) { t[0] += red[(s * m.cpw + m.cp) * 2]; t[1] += red[(s * m.cpw + m.cp) * 2 + 1]; }
+    return t;
+}
+__device__ __forceinline__ f32x2 combine_max(float* red, const BoardMap& m, f32x2 v) {
+    __syncthreads();
+    if (m.active) { red[(m.slice * m.cpw + m.cp) * 2] = v[0]; red[(m.slice * m.cpw + m.cp) * 2 + 1] = v[1]; }
+    __syncthreads();
+    f32x2 t = {-INFINITY, -INFINITY};
+    for (int s = 0; s < m.ph; ++s) {
+        t[0] = fmaxf(t[0], red[(s * m.cpw + m.cp) * 2]);
+        t[1] = fmaxf(t[1], red[(s * m.cpw + m.cp) * 2 + 1]);
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------- input layout
+// obs (B,Cobs,9,9) f32 NCHW -> (B,81,Cpad) T NHWC, channels >= Cobs zero
+template <typename T>
+__global__ void obs_to_nhwc_kernel(const float* __restrict__ obs, const long long* __restrict__ idx,
+                                   T* __restrict__ out, int B, int Cobs, int Cpad) {
+    __shared__ float tile[KA_BOARD * 65];
+    const int b = blockIdx.x;
+    const long long sb = idx ? idx[b] : b;      // fused minibatch gather (katago_ppo.py:835)
+    for (int c0 = 0; c0 < Cpad; c0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * KA_BOARD; i += blockDim.x) {
+            const int c = i / KA_BOARD, p = i - c * KA_BOARD;
+            tile[p * 65 + c] = (c0 + c < Cobs) ? obs[((size_t)sb * Cobs + c0 + c) * KA_BOARD + p] : 0.f;
+        }
+        __syncthreads();
+        const int w = min(64, Cpad - c0);
+        for (int i = threadIdx.x; i < KA_BOARD * w; i += blockDim.x) {
+            const int p = i / w, c = i - p * w;
+            Elem<T>::st(out + ((size_t)b * KA_BOARD + p) * Cpad + c0 + c, tile[p * 65 + c]);
+        }
+    }
+}
+
+// (B,81,C) T NHWC -> (B,C,9,9) f32 NCHW (API boundary of a stand-alone block)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C) {
+    __shared__ float tile[KA_BOARD * 65];
+    const int b = blockIdx.x;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int w = min(64, C - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < KA_BOARD * w; i += blockDim.x) {
+            const int p = i / w, c = i - p * w;
+            tile[p * 65 + c] = Elem<T>::ld(in + ((size_t)b * KA_BOARD + p) * C + c0 + c);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < w * KA_BOARD; i += blockDim.x) {
+            const int c = i / KA_BOARD, p = i - c * KA_BOARD;
+            out[((size_t)b * C + c0 + c) * KA_BOARD + p] = tile[p * 65 + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- BatchNorm statistics
+// sums[0:C] = sum_b bsum[b,c]; sums[C:2C] = sum_r sqpart[r,c]   (fp64, fixed order)
+__global__ void bn_reduce_kernel(const float* __restrict__ bsum, int B, const float* __restrict__ sqpart, int R,
+                                 int C, double* __restrict__ sums) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;           // 4 row-slices
+    __shared__ double red[2][4][64];
+    double s = 0.0, ss = 0.0;
+    if (c < C) {
+        for (int b = part; b < B; b += 4) s += (double)bsum[(size_t)b * C + c];
+        for (int r = part; r < R; r += 4) ss += (double)sqpart[(size_t)r * C + c];
+    }
+    red[0][part][threadIdx.x & 63] = s;
+    red[1][part][threadIdx.x & 63] = ss;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const int l = threadIdx.x;
+        sums[c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        sums[C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+
+// two (B,C) partial planes -> sums[2C] fp64 (BN backward)
+__global__ void pair_reduce_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int B, int C,
+                                   double* __restrict__ sums) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    __shared__ double red[2][4][64];
+    double s = 0.0, ss = 0.0;
+    if (c < C)
+        for (int b = part; b < B; b += 4) { s += (double)p1[(size_t)b * C + c]; ss += (double)p2[(size_t)b * C + c]; }
+    red[0][part][threadIdx.x & 63] = s;
+    red[1][part][threadIdx.x & 63] = ss;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const int l = threadIdx.x;
+        sums[c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        sums[C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+
+// training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
+// nn.BatchNorm2d (momentum form, unbiased running variance).
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                 float* __restrict__ mean_out, float* __restrict__ invstd_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// dgamma/dbeta from the LOCAL sums; dy = k1*dz + k2 + k3*y from the (possibly all-reduced) sums
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
+                                     double count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ k, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dgamma) { dbeta[c] = (float)sums_local[c]; dgamma[c] = (float)sums_local[C + c]; }
+    const double g = gamma[c], is = invstd[c], mu = mean[c];
+    const double k1 = g * is;
+    const double k3 = -g * is * is * sums_global[C + c] / count;
+    const double k2 = -g * is * sums_global[c] / count - k3 * mu;
+    k[c] = (float)k1; k[C + c] = (float)k2; k[2 * C + c] = (float)k3;
+}
+
+// out[b,c] = a[c]*in[b,c]*mul + s[c]     (SE squeeze of the normalised conv2 output)
+__global__ void affine_rows_kernel(const float* __restrict__ in, const float* __restrict__ a,
+                                   const float* __restrict__ s, float mul, float* __restrict__ out, int B, int C) {
+    const size_t n = (size_t)B * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        out[i] = a[c] * (in[i] * mul) + s[c];
+    }
+}
+
+// dy = k1[c]*dz + k2[c] + k3[c]*y   (BatchNorm backward, elementwise part)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ k,
+                                    T* __restrict__ dy, size_t npairs, int C) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 2) % C);
+        const f32x2 g = ld2(dz + i * 2), v = ld2(y + i * 2);
+        f32x2 o = {k[c] * g[0] + k[C + c] + k[2 * C + c] * v[0],
+                   k[c + 1] * g[1] + k[C + c + 1] + k[2 * C + c + 1] * v[1]};
+        st2(dy + i * 2, o);
+    }
+}
+
+// ---------------------------------------------------------------- forward tail
+// out = relu( (scale*y+shift) [* sigmoid(se[b,c]) + se[b,C+c]] [+ res] ),  pool = [mean|max|std] of out
+template <typename T>
+__global__ __launch_bounds__(kThreads) void block_tail_fwd_kernel(
+    const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 v[kMaxPPT];
+        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
+        if (m.active) {
+            const f32x2 sc = {scale[c], scale[c + 1]}, sh = {shift[c], shift[c + 1]};
+            f32x2 gate = {1.f, 1.f}, bias = {0.f, 0.f};
+            if (se) {
+                gate = f32x2{sigmoidf_(se[(size_t)b * 2 * C + c]), sigmoidf_(se[(size_t)b * 2 * C + c + 1])};
+                bias = f32x2{se[(size_t)b * 2 * C + C + c], se[(size_t)b * 2 * C + C + c + 1]};
+            }
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    const size_t off = base + (size_t)p * C + c;
+                    f32x2 u = ld2(y + off);
+                    u[0] = (u[0] * sc[0] + sh[0]) * gate[0] + bias[0];
+                    u[1] = (u[1] * sc[1] + sh[1]) * gate[1] + bias[1];
+                    if (res) { const f32x2 rr = ld2(res + off); u[0] += rr[0]; u[1] += rr[1]; }
+                    u[0] = rnd<T>(fmaxf(u[0], 0.f));
+                    u[1] = rnd<T>(fmaxf(u[1], 0.f));
+                    st2(out + off, u);
+                    v[i] = u;
+                    sum[0] += u[0]; sum[1] += u[1];
+                    mx[0] = fmaxf(mx[0], u[0]); mx[1] = fmaxf(mx[1], u[1]);
+                }
+            }
+        }
+        const f32x2 tot = combine_sum(red, m, sum);
+        const f32x2 mxx = combine_max(red, m, mx);
+        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
+        f32x2 sq = {0.f, 0.f};
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
+                    sq[0] += d0 * d0; sq[1] += d1 * d1;
+                }
+            }
+        }
+        const f32x2 var = combine_sum(red, m, sq);
+        if (m.active && m.slice == 0 && pool) {
+            float* pr = pool + (size_t)b * 3 * C;
+            pr[c] = mean[0]; pr[c + 1] = mean[1];
+            pr[C + c] = mxx[0]; pr[C + c + 1] = mxx[1];
+            pr[2 * C + c] = sqrtf(var[0] / KA_BOARD); pr[2 * C + c + 1] = sqrtf(var[1] / KA_BOARD);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward tail, pass 1
+// du = dout*[out>0]; z = scale*y+shift; dse[b,c] = sig'(a)*sum_p du*z ; dse[b,C+c] = sum_p du
+template <typename T>
+__global__ __launch_bounds__(kThreads) void tail_bwd_reduce_kernel(
+    const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ se, float* __restrict__ dse, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 r1 = {0.f, 0.f}, r2 = {0.f, 0.f};
+        if (m.active) {
+            const f32x2 sc = {scale[c], scale[c + 1]}, sh = {shift[c], shift[c + 1]};
+            for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+                const size_t off = base + (size_t)p * C + c;
+                const f32x2 g = ld2(dout + off), o = ld2(out + off), yy = ld2(y + off);
+                const float d0 = o[0] > 0.f ? g[0] : 0.f, d1 = o[1] > 0.f ? g[1] : 0.f;
+                r1[0] += d0 * (yy[0] * sc[0] + sh[0]); r1[1] += d1 * (yy[1] * sc[1] + sh[1]);
+                r2[0] += d0; r2[1] += d1;
+            }
+        }
+        const f32x2 t1 = combine_sum(red, m, r1);
+        const f32x2 t2 = combine_sum(red, m, r2);
+        if (m.active && m.slice == 0) {
+            const float s0 = sigmoidf_(se[(size_t)b * 2 * C + c]), s1 = sigmoidf_(se[(size_t)b * 2 * C + c + 1]);
+            float* d = dse + (size_t)b * 2 * C;
+            d[c] = t1[0] * s0 * (1.f - s0); d[c + 1] = t1[1] * s1 * (1.f - s1);
+            d[C + c] = t2[0]; d[C + c + 1] = t2[1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward tail, pass 2
+// dz = du*sigmoid(a) + dsq[b,c]/81 ; per-board partials s1 = sum dz, s2 = sum dz*yhat
+template <typename T>
+__global__ __launch_bounds__(kThreads) void tail_bwd_dz_kernel(
+    const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ se,
+    const float* __restrict__ dsq, const float* __restrict__ mean, const float* __restrict__ invstd,
+    T* __restrict__ dz, float* __restrict__ s1p, float* __restrict__ s2p, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        if (m.active) {
+            const f32x2 gate = {sigmoidf_(se[(size_t)b * 2 * C + c]), sigmoidf_(se[(size_t)b * 2 * C + c + 1])};
+            const f32x2 add = {dsq[(size_t)b * C + c] / KA_BOARD, dsq[(size_t)b * C + c + 1] / KA_BOARD};
+            const f32x2 mu = {mean[c], mean[c + 1]}, is = {invstd[c], invstd[c + 1]};
+            for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+                const size_t off = base + (size_t)p * C + c;
+                const f32x2 g = ld2(dout + off), o = ld2(out + off), yy = ld2(y + off);
+                f32x2 d = {(o[0] > 0.f ? g[0] : 0.f) * gate[0] + add[0], (o[1] > 0.f ? g[1] : 0.f) * gate[1] + add[1]};
+                st2(dz + off, d);
+                a1[0] += d[0]; a1[1] += d[1];
+                a2[0] += d[0] * ((yy[0] - mu[0]) * is[0]); a2[1] += d[1] * ((yy[1] - mu[1]) * is[1]);
+            }
+        }
+        const f32x2 t1 = combine_sum(red, m, a1);
+        const f32x2 t2 = combine_sum(red, m, a2);
+        if (m.active && m.slice == 0) {
+            s1p[(size_t)b * C + c] = t1[0]; s1p[(size_t)b * C + c + 1] = t1[1];
+            s2p[(size_t)b * C + c] = t2[0]; s2p[(size_t)b * C + c + 1] = t2[1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ReLU + BN backward, reduce pass
+// da = dh * [scale*y+shift > 0]  (written), partials s1 = sum da, s2 = sum da*yhat
+template <typename T>
+__global__ __launch_bounds__(kThreads) void relu_bn_bwd_reduce_kernel(
+    const T* __restrict__ dh, const T* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    T* __restrict__ da, float* __restrict__ s1p, float* __restrict__ s2p, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        if (m.active) {
+            const f32x2 sc = {scale[c], scale[c + 1]}, sh = {shift[c], shift[c + 1]};
+            const f32x2 mu = {mean[c], mean[c + 1]}, is = {invstd[c], invstd[c + 1]};
+            for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+                const size_t off = base + (size_t)p * C + c;
+                const f32x2 g = ld2(dh + off), yy = ld2(y + off);
+                f32x2 d = {(yy[0] * sc[0] + sh[0] > 0.f) ? g[0] : 0.f, (yy[1] * sc[1] + sh[1] > 0.f) ? g[1] : 0.f};
+                st2(da + off, d);
+                a1[0] += d[0]; a1[1] += d[1];
+                a2[0] += d[0] * ((yy[0] - mu[0]) * is[0]); a2[1] += d[1] * ((yy[1] - mu[1]) * is[1]);
+            }
+        }
+        const f32x2 t1 = combine_sum(red, m, a1);
+        const f32x2 t2 = combine_sum(red, m, a2);
+        if (m.active && m.slice == 0) {
+            s1p[(size_t)b * C + c] = t1[0]; s1p[(size_t)b * C + c + 1] = t1[1];
+            s2p[(size_t)b * C + c] = t2[0]; s2p[(size_t)b * C + c + 1] = t2[1];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- block input gradient
+// dx = [dxc] + [dout*[out>0]] + pool_bwd(dpool; x)
+//   mean: dpool_mean/81 ; max: dpool_max/ties on every square equal to the max ;
+//   std : dpool_std*(x-mean)/(81*std), 0 where std == 0
+template <typename T>
+__global__ __launch_bounds__(kThreads) void block_dx_kernel(
+    const T* __restrict__ dxc, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+    const float* __restrict__ dpool, T* __restrict__ dx, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 v[kMaxPPT];
+        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    v[i] = ld2(x + base + (size_t)p * C + c);
+                    sum[0] += v[i][0]; sum[1] += v[i][1];
+                    mx[0] = fmaxf(mx[0], v[i][0]); mx[1] = fmaxf(mx[1], v[i][1]);
+                }
+            }
+        }
+        const f32x2 tot = combine_sum(red, m, sum);
+        const f32x2 mxx = combine_max(red, m, mx);
+        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
+        f32x2 sq = {0.f, 0.f}, ties = {0.f, 0.f};
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
+                    sq[0] += d0 * d0; sq[1] += d1 * d1;
+                    ties[0] += (v[i][0] == mxx[0]) ? 1.f : 0.f; ties[1] += (v[i][1] == mxx[1]) ? 1.f : 0.f;
+                }
+            }
+        }
+        const f32x2 var = combine_sum(red, m, sq);
+        const f32x2 nt = combine_sum(red, m, ties);
+        if (m.active) {
+            const float* dp = dpool + (size_t)b * 3 * C;
+            const f32x2 gm = {dp[c] / KA_BOARD, dp[c + 1] / KA_BOARD};
+            const f32x2 gx = {dp[C + c] / nt[0], dp[C + c + 1] / nt[1]};
+            const float sd0 = sqrtf(var[0] / KA_BOARD), sd1 = sqrtf(var[1] / KA_BOARD);
+            const f32x2 gs = {sd0 > 0.f ? dp[2 * C + c] / (KA_BOARD * sd0) : 0.f,
+                              sd1 > 0.f ? dp[2 * C + c + 1] / (KA_BOARD * sd1) : 0.f};
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    const size_t off = base + (size_t)p * C + c;
+                    f32x2 g = {gm[0] + gs[0] * (v[i][0] - mean[0]) + (v[i][0] == mxx[0] ? gx[0] : 0.f),
+                               gm[1] + gs[1] * (v[i][1] - mean[1]) + (v[i][1] == mxx[1] ? gx[1] : 0.f)};
+                    if (dxc) { const f32x2 t = ld2(dxc + off); g[0] += t[0]; g[1] += t[1]; }
+                    if (dout) {
+                        const f32x2 t = ld2(dout + off), o = ld2(out + off);
+                        g[0] += o[0] > 0.f ? t[0] : 0.f; g[1] += o[1] > 0.f ? t[1] : 0.f;
+                    }
+                    st2(dx + off, g);
+                }
+            }
+        }
+    }
+}
+
+template <typename T> size_t red_bytes(int C) {
+    const int pairs = C >> 1, cpw = pairs < 128 ? pairs : 128;
+    int ph = kThreads / cpw; if (ph > KA_BOARD) ph = KA_BOARD;
+    return (size_t)ph * cpw * 2 * sizeof(float);
+}
+
+}  // namespace
+
+#define KA_BOARD_CHECK(name) \
+    KA_REQUIRE(B > 0 && C >= 2 && C % 2 == 0 && (C / 2 >= 128 ? (C / 2) % 128 == 0 : 256 / (C / 2) >= 2), \
+               name ": unsupported channel count %d", C)
+#define KA_DISPATCH_T(dtype, CALL) \
+    do { if ((dtype) == KA_DTYPE_BF16) { typedef bf16_t T; CALL; } \
+         else if ((dtype) == KA_DTYPE_F32) { typedef float T; CALL; } \
+         else { ka_set_error("unknown dtype %d", (dtype)); return KA_ERR_ARG; } } while (0)
+
+extern "C" int ka_obs_to_nhwc(const float* obs, const long long* idx, void* out, int B, int Cobs, int Cpad, int dtype,
+                              void* stream) {
+    KA_REQUIRE(obs && out && B > 0 && Cpad >= Cobs, "obs_to_nhwc: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(obs_to_nhwc_kernel<T>, dim3(B), dim3(256), 0, st, obs, idx, (T*)out, B, Cobs, Cpad));
+    return ka_check_launch("obs_to_nhwc");
+}
+
+extern "C" int ka_nhwc_to_nchw(const void* in, float* out, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(in && out && B > 0, "nhwc_to_nchw: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(B), dim3(256), 0, st, (const T*)in, out, B, C));
+    return ka_check_launch("nhwc_to_nchw");
+}
+
+extern "C" int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R, int C, double* sums, void* stream) {
+    KA_REQUIRE(bsum && sqpart && sums, "bn_reduce: null tensor");
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), bsum, B,
+                       sqpart, R, C, sums);
+    return ka_check_launch("bn_reduce");
+}
+
+extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, void* stream) {
+    KA_REQUIRE(p1 && p2 && sums, "pair_reduce: null tensor");
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), p1, p2,
+                       B, C, sums);
+    return ka_check_launch("pair_reduce");
+}
+
+extern "C" int ka_bn_coeffs(const double* sums, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                            float* shift, float* mean, float* invstd, int C, void* stream) {
+    KA_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && count > 0, "bn_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums,
+                       count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+    return ka_check_launch("bn_coeffs");
+}
+
+extern "C" int ka_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 float* scale, float* shift, int C, void* stream) {
+    KA_REQUIRE(gamma && beta && rm && rv && scale && shift, "bn_eval_coeffs: null tensor");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       gamma, beta, rm, rv, eps, scale, shift, C);
+    return ka_check_launch("bn_eval_coeffs");
+}
+
+extern "C" int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
+                                const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k, int C,
+                                void* stream) {
+    KA_REQUIRE(sums_local && sums_global && gamma && mean && invstd && k && count > 0, "bn_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       sums_local, sums_global, count, gamma, mean, invstd, dgamma, dbeta, k, C);
+    return ka_check_launch("bn_bwd_coeffs");
+}
+
+extern "C" int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C,
+                              void* stream) {
+    KA_REQUIRE(in && a && s && out, "affine_rows: null tensor");
+    const size_t n = (size_t)B * C;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, a, s, mul,
+                       out, B, C);
+    return ka_check_launch("affine_rows");
+}
+
+extern "C" int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, void* dy, int B, int C, int dtype,
+                               void* stream) {
+    KA_REQUIRE(dz && y && k && dy && C % 2 == 0, "bn_bwd_apply: bad arguments");
+    const size_t npairs = (size_t)B * KA_BOARD * C / 2;
+    const int blocks = (int)((npairs + 255) / 256 < 4096 ? (npairs + 255) / 256 : 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dz,
+                                            (const T*)y, k, (T*)dy, npairs, C));
+    return ka_check_launch("bn_bwd_apply");
+}
+
+extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se,
+                                 const void* res, void* out, float* pool, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(y && scale && shift && out, "block_tail_fwd: null tensor");
+    KA_BOARD_CHECK("block_tail_fwd");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_tail_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C));
+    return ka_check_launch("block_tail_fwd");
+}
+
+extern "C" int ka_tail_bwd_reduce(const void* dout, const void* out, const void* y, const float* scale,
+                                  const float* shift, const float* se, float* dse, int B, int C, int dtype,
+                                  void* stream) {
+    KA_REQUIRE(dout && out && y && scale && shift && se && dse, "tail_bwd_reduce: null tensor");
+    KA_BOARD_CHECK("tail_bwd_reduce");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(tail_bwd_reduce_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, dse, C));
+    return ka_check_launch("tail_bwd_reduce");
+}
+
+extern "C" int ka_tail_bwd_dz(const void* dout, const void* out, const void* y, const float* se, const float* dsq,
+                              const float* mean, const float* invstd, void* dz, float* s1p, float* s2p, int B, int C,
+                              int dtype, void* stream) {
+    KA_REQUIRE(dout && out && y && se && dsq && mean && invstd && dz && s1p && s2p, "tail_bwd_dz: null tensor");
+    KA_BOARD_CHECK("tail_bwd_dz");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(tail_bwd_dz_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)dout, (const T*)out, (const T*)y, se, dsq, mean, invstd, (T*)dz,
+                                            s1p, s2p, C));
+    return ka_check_launch("tail_bwd_dz");
+}
+
+extern "C" int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, void* da, float* s1p, float* s2p, int B,
+                                     int C, int dtype, void* stream) {
+    KA_REQUIRE(dh && y && scale && shift && mean && invstd && da && s1p && s2p, "relu_bn_bwd_reduce: null tensor");
+    KA_BOARD_CHECK("relu_bn_bwd_reduce");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(relu_bn_bwd_reduce_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)dh, (const T*)y, scale, shift, mean, invstd, (T*)da, s1p, s2p, C));
+    return ka_check_launch("relu_bn_bwd_reduce");
+}
+
+extern "C" int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* dpool,
+                           void* dx, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(x && dpool && dx && ((dout == nullptr) == (out == nullptr)), "block_dx: bad arguments");
+    KA_BOARD_CHECK("block_dx");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_dx_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)dxc, (const T*)dout, (const T*)out, (const T*)x, dpool, (T*)dx, C));
+    return ka_check_launch("block_dx");
+}

@@ -1,0 +1,366 @@
+// 3x3 "same" convolution over 9x9 boards as an implicit GEMM on the CDNA4 matrix cores.
+//
+//   out[b,p,n] = sum_{tap,c} X'[b, p+tap, c] * W[n,c,tap]      X' = optional fused transform of the input
+//
+// Layout: activations are NHWC (B,81,C), channel-contiguous, so every HBM access is a
+// coalesced run along the channel axis.  One workgroup (4 waves) owns NB=2 whole boards and a
+// slab of output channels: the boards are staged ONCE into LDS as zero-haloed 11x11 tiles
+// ([padded square][channel]), after which each of the 9 taps is just a constant LDS offset
+// ((dy*11+dx)*row_stride) on the MFMA A-operand read -- the input is read from HBM exactly
+// once per output-channel slab.  Weights are pre-packed (pack_conv3x3_kernel) in MFMA
+// B-fragment order so a wave streams them from L2 with perfectly coalesced 1 KiB loads
+// straight into registers; waves split the N (output channel) dimension, so no weight goes
+// through LDS.  M = 162 rows is padded to 11 tiles of 16 (v_mfma_f32_16x16x32_bf16 /
+// 4x v_mfma_f32_16x16x4_f32); the f32 path is an exact fmaf chain (parity mode), the bf16
+// path is the throughput mode.
+//
+// The epilogue fuses what the following BatchNorm / squeeze-excite need: per-board channel
+// sums (= SE squeeze, and summed over boards the BN mean) and per-workgroup sums of squares.
+//
+// The same kernel is the data-gradient conv: pack with flip+transpose (mode 1).
+//
+// Reference semantics replaced: nn.Conv2d(C, C, 3, padding=1, bias=False) at
+// keisei/training/models/se_resnet.py:50,52,110 and its autograd backward.
+#include "common.h"
+
+namespace {
+
+constexpr int kNB = 2;                       // boards per workgroup
+constexpr int kRows = kNB * KA_BOARD;        // 162 GEMM rows
+constexpr int kMT = (kRows + 15) / 16;       // 11 row tiles
+
+struct ConvArgs {
+    const void* in;
+    const void* wpack;
+    void* out;
+    const float* in_scale;   // [Cin] or null: x' = x*scale + shift
+    const float* in_shift;
+    const float* in_bias;    // [B,Cin] or null: per-board bias added after the ReLU
+    float* bsum;             // [B,Cout] or null
+    float* sqpart;           // [gridDim.x, Cout] or null
+    int B, Cin, Cout, KC, relu;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(const bf16x8& a, const bf16x8& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane (r,q) holds channels 4q..4q+3 of its row/column: MFMA i contracts channel 4q+i over q
+    static __device__ __forceinline__ f32x4 run(const f32x4& a, const f32x4& b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T, int NTW>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int ESZ = E::kSize, P16 = E::kPer16, CPK = 4 * P16;   // channels per k-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * kNB;
+    const int NT = a.Cout >> 4;
+    const int nt0 = blockIdx.y * (4 * NTW) + wave * NTW;
+    const int stride = a.KC * ESZ + 16;          // bytes per padded square (+16: bank spread)
+    const int cpr = a.KC * ESZ / 16;             // 16-byte pieces per square
+    const int KSG = a.Cin / CPK;                 // k-steps over all input channels
+    const int KS = a.KC / CPK;                   // k-steps per LDS chunk
+
+    f32x4 acc[kMT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int rowoff[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+        int m = mt * 16 + r;
+        if (m >= kRows) m = 0;                   // dummy rows read valid LDS; never stored
+        rowoff[mt] = ((m / KA_BOARD) * KA_PADBOARD + pad_index(m % KA_BOARD)) * stride + q * 16;
+    }
+
+    // zero the halo once (staging only ever writes interior squares)
+    for (int i = tid; i < kNB * KA_PADBOARD * cpr; i += 256) {
+        int idx = i / cpr, j = i - idx * cpr;
+        int pp = idx % KA_PADBOARD, yy = pp / 11, xx = pp - yy * 11;
+        if (yy == 0 || yy == 10 || xx == 0 || xx == 10)
+            *reinterpret_cast<uint4*>(smem + idx * stride + j * 16) = uint4{0, 0, 0, 0};
+    }
+
+    const int sj = tid % cpr, spos0 = tid / cpr, sstep = 256 / cpr;   // staging role of this thread
+    const char* wbase = static_cast<const char*>(a.wpack) + ((size_t)nt0 * 64 + lane) * 16;
+    const size_t tap_stride = (size_t)KSG * NT * 1024, ks_stride = (size_t)NT * 1024;
+    const bool wave_active = nt0 < NT;
+
+    const int nchunks = a.Cin / a.KC;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        if (kc > 0) __syncthreads();
+        // ---- stage NB boards x KC channels into the haloed LDS tile (fused input transform)
+        {
+            const int c0 = kc * a.KC + sj * P16;
+            float sc[P16], sh[P16];
+            const bool has_aff = a.in_scale != nullptr;
+            if (has_aff) {
+#pragma unroll
+                for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + e]; sh[e] = a.in_shift[c0 + e]; }
+            }
+            for (int pos = spos0; pos < kRows; pos += sstep) {
+                const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
+                vec16 v;
+                if (bb < a.B) {
+                    v = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) +
+                                                        ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ);
+                    if (has_aff || a.relu || a.in_bias) {
+                        float f[P16];
+                        E::unpack(v, f);
+                        if (has_aff) {
+#pragma unroll
+                            for (int e = 0; e < P16; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < P16; ++e) f[e] = fmaxf(f[e], 0.f);
+                        }
+                        if (a.in_bias) {
+                            const float* gb = a.in_bias + (size_t)bb * a.Cin + c0;
+#pragma unroll
+                            for (int e = 0; e < P16; ++e) f[e] += gb[e];
+                        }
+                        v = E::pack(f);
+                    }
+                } else {
+                    float z[P16];
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) z[e] = 0.f;
+                    v = E::pack(z);
+                }
+                *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA phase: 9 taps x KS k-steps; weights prefetched one step ahead
+        if (wave_active) {
+            const int nsteps = 9 * KS;
+            vec16 bcur[NTW], bnext[NTW];
+            {
+                const char* wp = wbase + (size_t)(kc * KS) * ks_stride;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    bcur[j] = (nt0 + j < NT) ? *reinterpret_cast<const vec16*>(wp + j * 1024) : vec16{};
+            }
+            int tap = 0, ks = 0;
+            for (int it = 0; it < nsteps; ++it) {
+                int ntap = tap, nks = ks + 1;
+                if (nks == KS) { nks = 0; ntap = tap + 1; }
+                if (it + 1 < nsteps) {
+                    const char* wp = wbase + (size_t)ntap * tap_stride + (size_t)(kc * KS + nks) * ks_stride;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        bnext[j] = (nt0 + j < NT) ? *reinterpret_cast<const vec16*>(wp + j * 1024) : vec16{};
+                }
+                const int toff = ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * stride + ks * 64;
+#pragma unroll
+                for (int mt = 0; mt < kMT; ++mt) {
+                    const vec16 av = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av, bcur[j], acc[mt][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bcur[j] = bnext[j];
+                tap = ntap; ks = nks;
+            }
+        }
+    }
+
+    // ---- epilogue: statistics from the fp32 accumulators, then the output tile
+    const bool v0 = b0 < a.B, v1 = b0 + 1 < a.B;
+    if (wave_active && (a.bsum || a.sqpart)) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            float s0 = 0.f, s1 = 0.f, ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mt * 16 + q * 4 + i;
+                    const float v = acc[mt][j][i];
+                    if (m < KA_BOARD) { s0 += v; ss += v * v; }
+                    else if (m < kRows) { s1 += v; ss += v * v; }
+                }
+            s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            const int n = (nt0 + j) * 16 + r;
+            if (q == 0 && nt0 + j < NT) {
+                if (a.bsum) {
+                    if (v0) a.bsum[(size_t)b0 * a.Cout + n] = s0;
+                    if (v1) a.bsum[(size_t)(b0 + 1) * a.Cout + n] = s1;
+                }
+                if (a.sqpart) a.sqpart[(size_t)blockIdx.x * a.Cout + n] = ss;
+            }
+        }
+    }
+
+    if constexpr (sizeof(T) == 2) {
+        // transpose through LDS so HBM sees whole 16-byte pieces of contiguous rows
+        const int BN = 4 * NTW * 16;                 // output channels of this workgroup
+        const int ostride = BN * 2 + 16;
+        __syncthreads();                             // all waves done reading the input tile
+        if (wave_active) {
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mt * 16 + q * 4 + i;
+                        *reinterpret_cast<uint16_t*>(smem + m * ostride + ((wave * NTW + j) * 16 + r) * 2) =
+                            f2bf(acc[mt][j][i]);
+                    }
+        }
+        __syncthreads();
+        const int n_wg0 = blockIdx.y * BN;
+        const int ncols = min(BN, a.Cout - n_wg0);   // multiple of 16
+        const int ppr = ncols / 8;                   // 16-byte pieces per row
+        const int rows = v1 ? kRows : (v0 ? KA_BOARD : 0);
+        for (int i = tid; i < rows * ppr; i += 256) {
+            const int m = i / ppr, pc = i - m * ppr;
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + m * ostride + pc * 16);
+            *reinterpret_cast<uint4*>(static_cast<char*>(a.out) +
+                                      ((size_t)(b0 * KA_BOARD + m) * a.Cout + n_wg0 + pc * 8) * 2) = v;
+        }
+    } else {
+        if (wave_active) {
+            float* out = static_cast<float*>(a.out);
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (nt0 + j >= NT) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mt * 16 + q * 4 + i;
+                        const bool ok = (m < KA_BOARD) ? v0 : (m < kRows && v1);
+                        if (ok) out[(size_t)(b0 * KA_BOARD + m) * a.Cout + (nt0 + j) * 16 + r] = acc[mt][j][i];
+                    }
+                }
+        }
+    }
+}
+
+// Pack (Co,Ci,3,3) fp32 weights into MFMA B-fragment order.
+//   mode 0 (forward): out-channel n = co, in-channel c = ci (zero-padded to Ci_pad), tap = ky*3+kx
+//   mode 1 (dgrad)  : out-channel n = ci, in-channel c = co, tap flipped (8 - tap)
+// dst[((tap*KSG + ks)*NT + nt)*64 + lane] (16 bytes) = W'[n = nt*16 + (lane&15)][c = ks*CPK + (lane>>4)*P16 + e][tap]
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, void* __restrict__ dst, int Co, int Ci,
+                                    int Nout, int Kin, int mode) {
+    typedef Elem<T> E;
+    constexpr int P16 = E::kPer16, CPK = 4 * P16;
+    const int KSG = Kin / CPK, NT = Nout / 16;
+    const size_t total = (size_t)9 * KSG * NT * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        size_t t = i >> 6;
+        const int nt = t % NT; t /= NT;
+        const int ks = t % KSG; const int tap = t / KSG;
+        const int n = nt * 16 + (lane & 15);
+        float f[P16];
+#pragma unroll
+        for (int e = 0; e < P16; ++e) {
+            const int c = ks * CPK + (lane >> 4) * P16 + e;
+            float v = 0.f;
+            if (mode == 0) { if (n < Co && c < Ci) v = w[((size_t)n * Ci + c) * 9 + tap]; }
+            else           { if (c < Co && n < Ci) v = w[((size_t)c * Ci + n) * 9 + (8 - tap)]; }
+            f[e] = v;
+        }
+        reinterpret_cast<typename E::vec16*>(dst)[i] = E::pack(f);
+    }
+}
+
+template <typename T, int NTW>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+    typedef Elem<T> E;
+    const int BN = 64 * NTW;
+    const size_t lds_in = (size_t)kNB * KA_PADBOARD * (a.KC * E::kSize + 16);
+    const size_t lds_out = (E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0;
+    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            ka_set_error("conv3x3: hipFuncSetAttribute failed");
+            return KA_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid((a.B + kNB - 1) / kNB, (a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv3x3_kernel<T, NTW>), grid, dim3(256), lds, st, a);
+    return ka_check_launch("conv3x3");
+}
+
+template <typename T>
+int conv_dispatch(ConvArgs a, hipStream_t st) {
+    typedef Elem<T> E;
+    constexpr int CPK = 4 * E::kPer16;
+    KA_REQUIRE(a.B > 0 && a.Cin % CPK == 0 && a.Cout % 16 == 0,
+               "conv3x3: need Cin %% %d == 0 and Cout %% 16 == 0 (got Cin=%d Cout=%d)", CPK, a.Cin, a.Cout);
+    // largest LDS chunk that fits: 2 boards x 121 squares x (KC*size+16) <= 160 KiB
+    int kc = a.Cin;
+    while ((size_t)kNB * KA_PADBOARD * (kc * E::kSize + 16) > 150 * 1024) {
+        KA_REQUIRE(kc % 2 == 0 && (kc / 2) % CPK == 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
+        kc /= 2;
+    }
+    KA_REQUIRE(256 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile 256 threads", kc);
+    a.KC = kc;
+    if (a.Cout > 128) return launch_conv<T, 4>(a, st);
+    if (a.Cout > 64) return launch_conv<T, 2>(a, st);
+    return launch_conv<T, 1>(a, st);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale,
+                              const float* in_shift, const float* in_bias, int relu, float* bsum, float* sqpart,
+                              int B, int Cin, int Cout, int dtype, void* stream) {
+    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu};
+    KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
+    KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KA_DTYPE_BF16) return conv_dispatch<bf16_t>(a, st);
+    if (dtype == KA_DTYPE_F32) return conv_dispatch<float>(a, st);
+    ka_set_error("conv3x3: unknown dtype %d", dtype);
+    return KA_ERR_ARG;
+}
+
+extern "C" int ka_conv3x3_sqpart_rows(int B) { return (B + kNB - 1) / kNB; }
+
+extern "C" int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int Nout, int Kin, int mode, int dtype,
+                               void* stream) {
+    KA_REQUIRE(w && dst && (mode == 0 || mode == 1), "pack_conv3x3: bad arguments");
+    KA_REQUIRE(Nout % 16 == 0, "pack_conv3x3: Nout %% 16 != 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cpk = dtype == KA_DTYPE_BF16 ? 32 : 16;
+    KA_REQUIRE(Kin % cpk == 0, "pack_conv3x3: Kin %% %d != 0", cpk);
+    const size_t total = (size_t)9 * (Kin / cpk) * (Nout / 16) * 64;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (dtype == KA_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w, dst, Co, Ci, Nout, Kin, mode);
+    else if (dtype == KA_DTYPE_F32)
+        hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, st, w, dst, Co, Ci, Nout, Kin, mode);
+    else { ka_set_error("pack_conv3x3: unknown dtype %d", dtype); return KA_ERR_ARG; }
+    return ka_check_launch("pack_conv3x3");
+}

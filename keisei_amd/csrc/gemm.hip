@@ -1,0 +1,261 @@
+// Small dense contractions of the SE-ResNet: global-pool FC, squeeze-excite FC, 1x1 policy
+// convolutions and the value / score heads (forward, input-gradient and weight-gradient forms).
+//
+//   C[M,N] = act( opA(A)[M,K] * opB(B)[K,N] + bias[N] )
+//
+// These are < 0.4 % of the model's FLOPs; they run as an exact-fp32
+// LDS-tiled FMA kernel (64x64x16 tile, 4x4 outputs per thread) with split-K for the
+// weight-gradient forms whose reduction runs over B*81 rows.  Operands may be fp32 or bf16
+// (activations) and are widened on load; accumulation is always fp32.
+//
+// Replaces nn.Linear / 1x1 nn.Conv2d at se_resnet.py:57-61,65-66,120-130 and their backward.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    const void* A; const void* B; void* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    int transA, transB;          // opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k]; same for B[k,n]
+    int a_bf16, b_bf16, c_bf16, relu, ksplit_len;
+};
+
+__device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
+    return bf16 ? bf2f(static_cast<const uint16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+}
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
+    float acc[4][4] = {};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        // A tile: 64 rows x 16 k
+        for (int i = tid; i < 64 * 16; i += 256) {
+            int m, k;
+            if (g.transA) { m = i & 63; k = i >> 6; } else { k = i & 15; m = i >> 4; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < g.M && gk < kend)
+                v = ldx(g.A, g.transA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk, g.a_bf16);
+            As[k][m] = v;
+        }
+        for (int i = tid; i < 64 * 16; i += 256) {
+            int n, k;
+            if (g.transB) { k = i & 15; n = i >> 4; } else { n = i & 63; k = i >> 6; }
+            const int gn = n0 + n, gk = k0 + k;
+            float v = 0.f;
+            if (gn < g.N && gk < kend)
+                v = ldx(g.B, g.transB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn, g.b_bf16);
+            Bs[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= g.N) continue;
+            float v = acc[i][j];
+            if (g.bias) v += g.bias[n];
+            if (g.relu) v = fmaxf(v, 0.f);
+            const size_t o = slab + (size_t)m * g.ldc + n;
+            if (g.c_bf16) static_cast<uint16_t*>(g.C)[o] = f2bf(v);
+            else static_cast<float*>(g.C)[o] = v;
+        }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s*n + i]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, size_t n,
+                                    int accumulate) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// partial[z][n] = sum over rows of slice z of A[m][n]  (bias gradients / BN sums over rows)
+// with optional second output partial2 = sum A[m][n]*Bm[m][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                     float* __restrict__ part, float* __restrict__ part2, int M,
+                                                     int N, int rows_per) {
+    __shared__ float red[2][4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int mbeg = blockIdx.y * rows_per, mend = min(M, mbeg + rows_per);
+    float s = 0.f, s2 = 0.f;
+    if (n < N)
+        for (int m = mbeg + sl; m < mend; m += 4) {
+            const float a = A[(size_t)m * N + n];
+            s += a;
+            if (Bm) s2 += a * Bm[(size_t)m * N + n];
+        }
+    red[0][sl][threadIdx.x & 63] = s; red[1][sl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (sl == 0 && n < N) {
+        const int l = threadIdx.x;
+        part[(size_t)blockIdx.y * N + n] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        if (part2) part2[(size_t)blockIdx.y * N + n] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+
+// g[i] = (h[i] > 0) ? g[i] : 0
+__global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ h, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (!(h[i] > 0.f)) g[i] = 0.f;
+}
+
+// rows of fp32 (M,N): out = relu(in*scale[n]+shift[n])           (policy head BN + ReLU)
+__global__ void rows_affine_relu_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, float* __restrict__ out, size_t total, int N) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = i % N;
+        out[i] = fmaxf(in[i] * scale[n] + shift[n], 0.f);
+    }
+}
+// policy-head BN backward pieces on fp32 rows
+//   mode 0: da = dr * [in*scale+shift > 0]                       (in place on dr)
+//   mode 1: dy = k1*da + k2 + k3*in                              (in place on dr)
+__global__ void rows_bn_bwd_kernel(float* __restrict__ dr, const float* __restrict__ in, const float* __restrict__ p0,
+                                   const float* __restrict__ p1, size_t total, int N, int mode) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = i % N;
+        if (mode == 0) { if (!(in[i] * p0[n] + p1[n] > 0.f)) dr[i] = 0.f; }
+        else dr[i] = p0[n] * dr[i] + p0[N + n] + p0[2 * N + n] * in[i];
+    }
+}
+// yhat-weighted column sums for the policy BN: part[z][n] = sum da, part2[z][n] = sum da*(in-mean)*invstd
+__global__ __launch_bounds__(256) void rows_bn_sums_kernel(const float* __restrict__ da, const float* __restrict__ in,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ part, float* __restrict__ part2, int M,
+                                                           int N, int rows_per) {
+    __shared__ float red[2][4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int mbeg = blockIdx.y * rows_per, mend = min(M, mbeg + rows_per);
+    float s = 0.f, s2 = 0.f;
+    if (n < N) {
+        const float mu = mean[n], is = invstd[n];
+        for (int m = mbeg + sl; m < mend; m += 4) {
+            const float a = da[(size_t)m * N + n];
+            s += a; s2 += a * ((in[(size_t)m * N + n] - mu) * is);
+        }
+    }
+    red[0][sl][threadIdx.x & 63] = s; red[1][sl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (sl == 0 && n < N) {
+        const int l = threadIdx.x;
+        part[(size_t)blockIdx.y * N + n] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        part2[(size_t)blockIdx.y * N + n] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+// column sum and sum of squares of fp32 rows: part[z][n], part2[z][n]
+__global__ __launch_bounds__(256) void rows_sq_sums_kernel(const float* __restrict__ A, float* __restrict__ part,
+                                                           float* __restrict__ part2, int M, int N, int rows_per) {
+    __shared__ float red[2][4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int mbeg = blockIdx.y * rows_per, mend = min(M, mbeg + rows_per);
+    float s = 0.f, s2 = 0.f;
+    if (n < N)
+        for (int m = mbeg + sl; m < mend; m += 4) { const float a = A[(size_t)m * N + n]; s += a; s2 += a * a; }
+    red[0][sl][threadIdx.x & 63] = s; red[1][sl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (sl == 0 && n < N) {
+        const int l = threadIdx.x;
+        part[(size_t)blockIdx.y * N + n] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        part2[(size_t)blockIdx.y * N + n] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
+}
+
+inline int grid1d(size_t n, int cap) { size_t b = (n + 255) / 256; return (int)(b < (size_t)cap ? (b ? b : 1) : cap); }
+
+}  // namespace
+
+// nsplit > 1: C must hold nsplit slabs of M*ldc floats (no bias/relu/bf16 then); reduce with ka_reduce_slabs.
+extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                       int ldc, int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int nsplit,
+                       void* stream) {
+    KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "gemm: bad arguments");
+    KA_REQUIRE(nsplit == 1 || (!bias && !relu && !c_bf16), "gemm: split-K output must be raw fp32 slabs");
+    int len = (K + nsplit - 1) / nsplit;
+    len = (len + 15) / 16 * 16;
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, a_bf16, b_bf16, c_bf16, relu, len};
+    dim3 grid((N + 63) / 64, (M + 63) / 64, nsplit);
+    KA_REQUIRE(grid.y <= 65535, "gemm: M too large for grid.y (%d rows)", M);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return ka_check_launch("gemm");
+}
+
+extern "C" int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream) {
+    KA_REQUIRE(slab && out && nsplit >= 1 && n > 0, "reduce_slabs: bad arguments");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid1d((size_t)n, 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), slab, out, nsplit, (size_t)n, accumulate);
+    return ka_check_launch("reduce_slabs");
+}
+
+// part (and part2) must hold nsplit*N floats; rows are split evenly over nsplit slices
+extern "C" int ka_colsum(const float* A, const float* Bm, float* part, float* part2, int M, int N, int nsplit,
+                         void* stream) {
+    KA_REQUIRE(A && part && M > 0 && N > 0 && nsplit >= 1, "colsum: bad arguments");
+    const int rows_per = (M + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, static_cast<hipStream_t>(stream), A, Bm,
+                       part, part2, M, N, rows_per);
+    return ka_check_launch("colsum");
+}
+
+extern "C" int ka_relu_mask(float* g, const float* h, long long n, void* stream) {
+    KA_REQUIRE(g && h && n > 0, "relu_mask: bad arguments");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d((size_t)n, 2048)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       g, h, (size_t)n);
+    return ka_check_launch("relu_mask");
+}
+
+extern "C" int ka_rows_affine_relu(const float* in, const float* scale, const float* shift, float* out, long long M,
+                                   int N, void* stream) {
+    KA_REQUIRE(in && scale && shift && out, "rows_affine_relu: null tensor");
+    hipLaunchKernelGGL(rows_affine_relu_kernel, dim3(grid1d((size_t)M * N, 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, scale, shift, out, (size_t)M * N, N);
+    return ka_check_launch("rows_affine_relu");
+}
+
+extern "C" int ka_rows_bn_bwd(float* dr, const float* in, const float* p0, const float* p1, long long M, int N,
+                              int mode, void* stream) {
+    KA_REQUIRE(dr && in && p0 && (mode == 1 || p1), "rows_bn_bwd: null tensor");
+    hipLaunchKernelGGL(rows_bn_bwd_kernel, dim3(grid1d((size_t)M * N, 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dr, in, p0, p1, (size_t)M * N, N, mode);
+    return ka_check_launch("rows_bn_bwd");
+}
+
+extern "C" int ka_rows_bn_sums(const float* da, const float* in, const float* mean, const float* invstd, float* part,
+                               float* part2, int M, int N, int nsplit, void* stream) {
+    KA_REQUIRE(da && in && mean && invstd && part && part2, "rows_bn_sums: null tensor");
+    const int rows_per = (M + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(rows_bn_sums_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       da, in, mean, invstd, part, part2, M, N, rows_per);
+    return ka_check_launch("rows_bn_sums");
+}
+
+extern "C" int ka_rows_sq_sums(const float* A, float* part, float* part2, int M, int N, int nsplit, void* stream) {
+    KA_REQUIRE(A && part && part2, "rows_sq_sums: null tensor");
+    const int rows_per = (M + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(rows_sq_sums_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       A, part, part2, M, N, rows_per);
+    return ka_check_launch("rows_sq_sums");
+}

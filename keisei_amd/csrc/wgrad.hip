@@ -1,0 +1,282 @@
+// Weight gradient of the 3x3 board convolution on the CDNA4 matrix cores.
+//
+//   dW[n,c,tap] = sum_{b,p} dY[b,p,n] * X'[b, p+tap, c]
+//
+// A "TN" GEMM whose reduction axis (b,p) is the slow axis of both NHWC operands.  One
+// workgroup (8 waves) owns a 128(n) x 64(c) x 9(tap) slab of dW in registers (144 accumulator
+// VGPRs per lane) and walks its share of the boards: per board the dY tile [81->96 rows][128]
+// and the zero-haloed X' tile [121 squares][64] are staged into LDS (global loads for board
+// i+1 are in flight while board i is multiplied), and the 9 taps reuse both tiles -- the tap
+// is again a constant LDS row offset on the B operand.  bf16 operands are read with the
+// hardware transpose read (ds_read_b64_tr_b16) so no transposed copy of either tensor ever
+// exists; the f32 (parity) path needs one element per lane (v_mfma_f32_16x16x4_f32) and reads
+// with plain ds_read_b32.  The batch is split over workgroups (split-K); partial slabs are
+// summed by wgrad_reduce_kernel in a fixed order, so the result is run-to-run deterministic.
+//
+// Replaces: autograd's conv2d weight backward for se_resnet.py:50,52,110.
+#include "common.h"
+
+namespace {
+
+constexpr int kTN = 128, kTC = 64;
+
+struct WgradArgs {
+    const void* dy;      // (B,81,Cout)
+    const void* x;       // (B,81,Cin)
+    const float* in_scale;
+    const float* in_shift;
+    const float* in_bias;    // [B,Cin]
+    float* slab;             // [nsplit][9][Cout][Cin]
+    int B, Cin, Cout, relu, boards_per_split, ntn;
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+template <typename T> struct WG;
+template <> struct WG<bf16_t> {
+    static constexpr int KROWS = 96;                 // 81 -> 3 k-steps of 32
+    static constexpr int SY = kTN * 2 + 32;          // dY tile row stride (bytes)
+    static constexpr int SX = kTC * 2 + 32;
+};
+template <> struct WG<float> {
+    static constexpr int KROWS = 84;                 // 81 -> 21 k-steps of 4
+    static constexpr int SY = kTN * 4 + 64;
+    static constexpr int SX = kTC * 4 + 64;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int ESZ = E::kSize, P16 = E::kPer16;
+    constexpr int SY = WG<T>::SY, SX = WG<T>::SX, KROWS = WG<T>::KROWS;
+    constexpr int PY = kTN * ESZ / 16, PX = kTC * ESZ / 16;      // 16-byte pieces per tile row
+    constexpr int NY = (KA_BOARD * PY + 511) / 512, NX = (KA_BOARD * PX + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ytile = smem;
+    char* xtile = smem + KROWS * SY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nh = wave & 1, cq = wave >> 1;
+    const int tn = blockIdx.x % a.ntn, tc = blockIdx.x / a.ntn;
+    const int n0 = tn * kTN, c0 = tc * kTC;
+    const int split = blockIdx.y;
+    const int bbeg = split * a.boards_per_split;
+    const int bend = min(a.B, bbeg + a.boards_per_split);
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // zero both tiles once: dY pad rows (81..KROWS) and the X halo stay zero forever
+    for (int i = tid; i < (KROWS * SY + KA_PADBOARD * SX) / 16; i += 512)
+        reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+
+    // staging roles
+    const int yj = tid % PY, xj = tid % PX;
+    const bool ycol_ok = n0 + yj * P16 < a.Cout, xcol_ok = c0 + xj * P16 < a.Cin;
+    float sc[P16], sh[P16];
+    const bool has_aff = a.in_scale != nullptr;
+    if (has_aff && xcol_ok) {
+#pragma unroll
+        for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + xj * P16 + e]; sh[e] = a.in_shift[c0 + xj * P16 + e]; }
+    }
+    vec16 ry[NY], rx[NX];
+    auto zero16 = [&] { float z[P16];
+#pragma unroll
+        for (int e = 0; e < P16; ++e) z[e] = 0.f;
+        return E::pack(z); };
+
+    auto load_board = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = (tid + i * 512) / PY;
+            ry[i] = (row < KA_BOARD && ycol_ok)
+                        ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.dy) +
+                              ((size_t)(b * KA_BOARD + row) * a.Cout + n0 + yj * P16) * ESZ)
+                        : zero16();
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = (tid + i * 512) / PX;
+            rx[i] = (row < KA_BOARD && xcol_ok)
+                        ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.x) +
+                              ((size_t)(b * KA_BOARD + row) * a.Cin + c0 + xj * P16) * ESZ)
+                        : zero16();
+        }
+    };
+    auto store_board = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = (tid + i * 512) / PY;
+            if (row < KA_BOARD) *reinterpret_cast<vec16*>(ytile + row * SY + yj * 16) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = (tid + i * 512) / PX;
+            if (row < KA_BOARD) {
+                vec16 v = rx[i];
+                if (xcol_ok && (has_aff || a.relu || a.in_bias)) {
+                    float f[P16];
+                    E::unpack(v, f);
+                    if (has_aff) {
+#pragma unroll
+                        for (int e = 0; e < P16; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < P16; ++e) f[e] = fmaxf(f[e], 0.f);
+                    }
+                    if (a.in_bias) {
+                        const float* gb = a.in_bias + (size_t)b * a.Cin + c0 + xj * P16;
+#pragma unroll
+                        for (int e = 0; e < P16; ++e) f[e] += gb[e];
+                    }
+                    v = E::pack(f);
+                }
+                *reinterpret_cast<vec16*>(xtile + pad_index(row) * SX + xj * 16) = v;
+            }
+        }
+    };
+
+    // wave-uniform validity of this wave's tiles
+    const int ntn_valid = min(4, max(0, (a.Cout - n0 - nh * 64 + 15) / 16));   // valid n-tiles of this wave
+    const bool c_ok = c0 + cq * 16 < a.Cin;
+
+    if (bbeg < bend) load_board(bbeg);
+    for (int b = bbeg; b < bend; ++b) {
+        __syncthreads();                 // previous board fully consumed
+        store_board(b);
+        __syncthreads();
+        if (b + 1 < bend) load_board(b + 1);      // in flight during the MFMA phase
+        if (!c_ok || ntn_valid == 0) continue;    // wave-uniform; barriers are above
+
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll 1
+            for (int ks = 0; ks < 3; ++ks) {
+                const int k1 = ks * 32 + 8 * q + (r >> 2), k2 = k1 + 4;
+                bf16x8 af[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int colb = ((nh * 4 + t) * 16 + 4 * (r & 3)) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ytile + k1 * SY + colb));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ytile + k2 * SY + colb));
+                    af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const int i1 = (k1 < KA_BOARD) ? pad_index(k1) : 12, i2 = (k2 < KA_BOARD) ? pad_index(k2) : 12;
+                const int colx = (cq * 16 + 4 * (r & 3)) * 2;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i1 + toff) * SX + colx));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i2 + toff) * SX + colx));
+                    const bf16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < ntn_valid) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bv, acc[tap][t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int ks = 0; ks < KROWS / 4; ++ks) {
+                const int k = ks * 4 + q;
+                float af[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    af[t] = *reinterpret_cast<const float*>(ytile + k * SY + ((nh * 4 + t) * 16 + r) * 4);
+                const int ik = (k < KA_BOARD) ? pad_index(k) : 12;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
+                    const float bv = *reinterpret_cast<const float*>(xtile + (ik + toff) * SX + (cq * 16 + r) * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < ntn_valid) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv, acc[tap][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
+    if (c_ok) {
+        const int c = c0 + cq * 16 + r;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + (nh * 4 + t) * 16 + q * 4 + i;
+                    if (n < a.Cout && c < a.Cin)
+                        a.slab[(((size_t)split * 9 + tap) * a.Cout + n) * a.Cin + c] = acc[tap][t][i];
+                }
+    }
+}
+
+// dW[n][c][tap] (Cout, Cin_real, 3, 3) = sum_s slab[s][tap][n][c]; optional accumulate into dW
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout,
+                                    int Cin, int Cin_real, int accumulate) {
+    const size_t total = (size_t)Cout * Cin_real * 9;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = i % 9;
+        const size_t nc = i / 9;
+        const int c = nc % Cin_real, n = nc / Cin_real;
+        const size_t src = ((size_t)tap * Cout + n) * Cin + c, sstride = (size_t)9 * Cout * Cin;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[src + k * sstride];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+}  // namespace
+
+extern "C" int ka_wgrad_splits(int B, int Cin, int Cout) {
+    const int tiles = ((Cout + kTN - 1) / kTN) * ((Cin + kTC - 1) / kTC);
+    int s = 256 / tiles;
+    if (s < 1) s = 1;
+    if (s > B) s = B;
+    const int bps = (B + s - 1) / s;
+    return (B + bps - 1) / bps;
+}
+
+extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift,
+                                const float* in_bias, int relu, float* slab, float* dw, int B, int Cin, int Cin_real,
+                                int Cout, int accumulate, int dtype, void* stream) {
+    KA_REQUIRE(dy && x && slab && dw && B > 0, "wgrad: null tensor");
+    KA_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin_real <= Cin, "wgrad: need Cin,Cout %% 16 == 0");
+    KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad: scale/shift must come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nsplit = ka_wgrad_splits(B, Cin, Cout);
+    const int bps = (B + nsplit - 1) / nsplit;
+    WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, (Cout + kTN - 1) / kTN};
+    dim3 grid(a.ntn * ((Cin + kTC - 1) / kTC), nsplit);
+    if (dtype == KA_DTYPE_BF16) {
+        const size_t lds = WG<bf16_t>::KROWS * WG<bf16_t>::SY + KA_PADBOARD * WG<bf16_t>::SX;
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(512), lds, st, a);
+    } else if (dtype == KA_DTYPE_F32) {
+        const size_t lds = WG<float>::KROWS * WG<float>::SY + KA_PADBOARD * WG<float>::SX;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                ka_set_error("wgrad: hipFuncSetAttribute failed");
+                return KA_ERR_HIP;
+            }
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(512), lds, st, a);
+    } else {
+        ka_set_error("wgrad: unknown dtype %d", dtype);
+        return KA_ERR_ARG;
+    }
+    int rc = ka_check_launch("wgrad");
+    if (rc) return rc;
+    const size_t total = (size_t)Cout * Cin_real * 9;
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, nsplit, Cout, Cin, Cin_real,
+                       accumulate);
+    return ka_check_launch("wgrad_reduce");
+}

@@ -1,0 +1,474 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (keisei_amd._lib.call)
+and compared with plain fp32 PyTorch CPU math / the oracle / the golden fixtures.
+
+fp32 kernels (exact-fp32 MFMA / FMA paths) are held to rtol=atol=1e-5-class bounds scaled by the
+tensor magnitude; bf16 kernels are compared against the same fp32 math evaluated on bf16-rounded
+operands, with a bound of a few bf16 ulps (2^-8 relative) of the output magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from keisei_amd import _lib
+from oracle import keisei_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def to_nhwc(x, dt):       # (B,C,9,9) cpu f32 -> (B,81,C) cuda T
+    return x.permute(0, 2, 3, 1).reshape(x.shape[0], 81, x.shape[1]).contiguous().to(dt).to(DEV)
+
+
+def from_nhwc(y):         # (B,81,C) cuda -> (B,C,9,9) cpu f32
+    return y.float().cpu().reshape(y.shape[0], 9, 9, y.shape[2]).permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dt):
+    return x.to(dt).float()
+
+
+def close(got, ref, dt, scale=None, k=1.0):
+    scale = float(ref.abs().max()) if scale is None else scale
+    tol = (2e-5 if dt == torch.float32 else 1.2e-2) * k * max(scale, 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol, f"max err {err:.3e} > tol {tol:.3e} (scale {scale:.3e})"
+
+
+def pack(w, dt, mode, n_out, k_in):
+    cpk = 32 if dt == torch.bfloat16 else 16
+    nbytes = 9 * (k_in // cpk) * (n_out // 16) * 64 * 16
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    wd = w.contiguous().to(DEV)
+    _lib.call("ka_pack_conv3x3", wd, buf, w.shape[0], w.shape[1], n_out, k_in, mode, _lib.dtype_code(dt), st())
+    return buf
+
+
+def run_conv(x_nhwc, wp, B, cin, cout, dt, scale=None, shift=None, bias=None, relu=0, stats=True):
+    out = torch.empty(B, 81, cout, dtype=dt, device=DEV)
+    rows = _lib.query("ka_conv3x3_sqpart_rows", B)
+    bsum = torch.full((B, cout), float("nan"), device=DEV) if stats else None
+    sq = torch.full((rows, cout), float("nan"), device=DEV) if stats else None
+    _lib.call("ka_conv3x3_fwd", x_nhwc, wp, out, scale, shift, bias, relu, bsum, sq, B, cin, cout,
+              _lib.dtype_code(dt), st())
+    torch.cuda.synchronize()
+    return out, bsum, sq
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("B,cin,cout", [(3, 32, 32), (4, 64, 128), (2, 128, 128), (5, 256, 256), (2, 128, 256)])
+def test_conv3x3_forward(dtn, B, cin, cout):
+    dt = DT[dtn]
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    x = torch.randn(B, cin, 9, 9, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    ref = F.conv2d(rnd(x, dt), rnd(w, dt), padding=1)
+    out, bsum, sq = run_conv(to_nhwc(x, dt), pack(w, dt, 0, cout, cin), B, cin, cout, dt)
+    close(from_nhwc(out), ref, dt)
+    close(bsum.cpu(), ref.sum(dim=(2, 3)), torch.float32, k=20 if dt == torch.float32 else 200)
+    close(sq.sum(0).cpu(), (ref ** 2).sum(dim=(0, 2, 3)), torch.float32, k=20 if dt == torch.float32 else 200)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_conv3x3_fused_input_transform(dtn):
+    dt = DT[dtn]
+    B, C = 3, 128
+    g = torch.Generator().manual_seed(7)
+    y = torch.randn(B, C, 9, 9, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
+    gb = 0.5 * torch.randn(B, C, generator=g)
+    h = torch.relu(rnd(y, dt) * sc[None, :, None, None] + sh[None, :, None, None]) + gb[:, :, None, None]
+    ref = F.conv2d(rnd(h, dt), rnd(w, dt), padding=1)
+    out, _, _ = run_conv(to_nhwc(y, dt), pack(w, dt, 0, C, C), B, C, C, dt, sc.to(DEV), sh.to(DEV), gb.to(DEV), 1, False)
+    close(from_nhwc(out), ref, dt, k=2)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_conv3x3_stem_padded_channels(dtn):
+    dt = DT[dtn]
+    B, cobs, cpad, C = 3, 50, 64, 64
+    g = torch.Generator().manual_seed(9)
+    obs = torch.randn(B, cobs, 9, 9, generator=g)
+    w = torch.randn(C, cobs, 3, 3, generator=g) / 21.0
+    xin = torch.empty(B, 81, cpad, dtype=dt, device=DEV)
+    idx = torch.tensor([2, 0, 1], device=DEV)
+    _lib.call("ka_obs_to_nhwc", obs.to(DEV), idx, xin, B, cobs, cpad, _lib.dtype_code(dt), st())
+    out, _, _ = run_conv(xin, pack(w, dt, 0, C, cpad), B, cpad, C, dt, stats=False)
+    ref = F.conv2d(rnd(obs[[2, 0, 1]], dt), rnd(w, dt), padding=1)
+    close(from_nhwc(out), ref, dt)
+    back = torch.empty(B, C, 9, 9, device=DEV)
+    _lib.call("ka_nhwc_to_nchw", out, back, B, C, _lib.dtype_code(dt), st())
+    assert torch.equal(back.cpu(), from_nhwc(out))
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("B,cin,cout", [(3, 32, 32), (2, 128, 128), (3, 256, 256)])
+def test_conv3x3_dgrad(dtn, B, cin, cout):
+    dt = DT[dtn]
+    g = torch.Generator().manual_seed(11 + cin)
+    dy = torch.randn(B, cout, 9, 9, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cout ** 0.5)
+    ref = torch.nn.grad.conv2d_input((B, cin, 9, 9), rnd(w, dt), rnd(dy, dt), padding=1)
+    out, bsum, _ = run_conv(to_nhwc(dy, dt), pack(w, dt, 1, cin, cout), B, cout, cin, dt)
+    close(from_nhwc(out), ref, dt)
+    close(bsum.cpu(), ref.sum(dim=(2, 3)), torch.float32, k=20 if dt == torch.float32 else 200)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("B,cin,cin_real,cout", [(3, 32, 32, 32), (5, 64, 50, 128), (70, 128, 128, 128), (9, 256, 256, 256)])
+def test_conv3x3_wgrad(dtn, B, cin, cin_real, cout):
+    dt = DT[dtn]
+    g = torch.Generator().manual_seed(13 + cin)
+    x = torch.randn(B, cin, 9, 9, generator=g)
+    x[:, cin_real:] = 0
+    dy = torch.randn(B, cout, 9, 9, generator=g) / 9.0
+    ref = torch.nn.grad.conv2d_weight(rnd(x, dt), (cout, cin, 3, 3), rnd(dy, dt), padding=1)[:, :cin_real]
+    ns = _lib.query("ka_wgrad_splits", B, cin, cout)
+    slab = torch.empty(ns * 9 * cout * cin, device=DEV)
+    dw = torch.full((cout, cin_real, 3, 3), float("nan"), device=DEV)
+    _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(x, dt), None, None, None, 0, slab, dw, B, cin, cin_real, cout,
+              0, _lib.dtype_code(dt), st())
+    torch.cuda.synchronize()
+    tol_dt = torch.float32 if dt == torch.float32 else torch.bfloat16
+    scale = float(ref.abs().max())
+    err = float((dw.cpu() - ref).abs().max())
+    assert err <= (3e-5 if tol_dt == torch.float32 else 2e-3) * scale, (err, scale)
+    # accumulate flag
+    _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(x, dt), None, None, None, 0, slab, dw, B, cin, cin_real, cout,
+              1, _lib.dtype_code(dt), st())
+    assert float((dw.cpu() - 2 * ref).abs().max()) <= (6e-5 if tol_dt == torch.float32 else 4e-3) * scale
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_wgrad_fused_input_transform(dtn):
+    dt = DT[dtn]
+    B, C = 4, 128
+    g = torch.Generator().manual_seed(17)
+    y = torch.randn(B, C, 9, 9, generator=g)
+    dy = torch.randn(B, C, 9, 9, generator=g) / 9
+    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
+    gb = 0.5 * torch.randn(B, C, generator=g)
+    h = rnd(torch.relu(rnd(y, dt) * sc[None, :, None, None] + sh[None, :, None, None]) + gb[:, :, None, None], dt)
+    ref = torch.nn.grad.conv2d_weight(h, (C, C, 3, 3), rnd(dy, dt), padding=1)
+    ns = _lib.query("ka_wgrad_splits", B, C, C)
+    slab = torch.empty(ns * 9 * C * C, device=DEV)
+    dw = torch.empty(C, C, 3, 3, device=DEV)
+    _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(y, dt), sc.to(DEV), sh.to(DEV), gb.to(DEV), 1, slab, dw, B, C, C, C,
+              0, _lib.dtype_code(dt), st())
+    scale = float(ref.abs().max())
+    assert float((dw.cpu() - ref).abs().max()) <= (3e-5 if dt == torch.float32 else 3e-3) * scale
+
+
+# ------------------------------------------------------------------ BN + tail kernels
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("C", [32, 128, 256])
+def test_bn_stats_and_tail_forward(dtn, C):
+    dt = DT[dtn]
+    B = 5
+    g = torch.Generator().manual_seed(23 + C)
+    y = torch.randn(B, C, 9, 9, generator=g) * 1.7 + 0.3
+    x = torch.relu(torch.randn(B, C, 9, 9, generator=g))
+    x[1, 3] = 0.0
+    se = torch.randn(B, 2 * C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    yq, xq = rnd(y, dt), rnd(x, dt)
+    # statistics from per-board sums (as the conv epilogue would produce them)
+    bsum = yq.sum(dim=(2, 3)).to(DEV)
+    sq = (yq ** 2).sum(dim=(0, 2, 3))[None].to(DEV)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    _lib.call("ka_bn_reduce", bsum, B, sq, 1, C, sums, st())
+    scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    _lib.call("ka_bn_coeffs", sums, float(B * 81), gamma.to(DEV), beta.to(DEV), rmd, rvd, 0.1, 1e-5, scale, shift, mean,
+              invstd, C, st())
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(yq, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    zk = yq * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]
+    assert torch.allclose(zk, z, rtol=1e-4, atol=1e-5)
+    # tail
+    ref = torch.relu(z * torch.sigmoid(se[:, :C])[:, :, None, None] + se[:, C:, None, None] + xq)
+    out = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    pool = torch.empty(B, 3 * C, device=DEV)
+    _lib.call("ka_block_tail_fwd", to_nhwc(y, dt), scale, shift, se.to(DEV), to_nhwc(x, dt), out, pool, B, C,
+              _lib.dtype_code(dt), st())
+    got = from_nhwc(out)
+    close(got, ref, dt, k=2)
+    assert torch.allclose(pool.cpu(), orc.global_pool(got), rtol=1e-5, atol=1e-5)
+    # eval coefficients
+    es, eh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("ka_bn_eval_coeffs", gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, es, eh, C, st())
+    ze = F.batch_norm(yq, rm, rv, gamma, beta, training=False, eps=1e-5)
+    assert torch.allclose(yq * es.cpu()[None, :, None, None] + eh.cpu()[None, :, None, None], ze, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("C", [32, 256])
+def test_block_tail_backward_chain(dtn, C):
+    """tail_bwd_reduce -> tail_bwd_dz -> bn_bwd_coeffs -> bn_bwd_apply  ==  autograd through
+    relu(bn(y)*sigmoid(a)+b+x) w.r.t. y, a, b, gamma, beta (SE squeeze path via dsq)."""
+    dt = DT[dtn]
+    B = 4
+    g = torch.Generator().manual_seed(31 + C)
+    y = rnd(torch.randn(B, C, 9, 9, generator=g), dt).requires_grad_(True)
+    x = rnd(torch.relu(torch.randn(B, C, 9, 9, generator=g)), dt)
+    se = torch.randn(B, 2 * C, generator=g).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    dsq = 0.1 * torch.randn(B, C, generator=g)        # gradient arriving at mean_p(z) from the SE FCs
+    dout = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
+    z = F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5)
+    out = torch.relu(z * torch.sigmoid(se[:, :C])[:, :, None, None] + se[:, C:, None, None] + x)
+    loss = (out * dout).sum() + (z.mean(dim=(2, 3)) * dsq).sum()
+    gy, gse, gg, gb = torch.autograd.grad(loss, [y, se, gamma, beta])
+    # device side
+    yd, outd, doutd = to_nhwc(y.detach(), dt), to_nhwc(rnd(out.detach(), dt), dt), to_nhwc(dout, dt)
+    mu = y.detach().mean(dim=(0, 2, 3)); var = y.detach().var(dim=(0, 2, 3), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    scale = (gamma.detach() * invstd).to(DEV); shift = (beta.detach() - mu * gamma.detach() * invstd).to(DEV)
+    dse = torch.empty(B, 2 * C, device=DEV)
+    _lib.call("ka_tail_bwd_reduce", doutd, outd, yd, scale, shift, se.detach().to(DEV), dse, B, C, _lib.dtype_code(dt), st())
+    close(dse.cpu(), gse, dt, k=3)
+    dz = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    s1, s2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.call("ka_tail_bwd_dz", doutd, outd, yd, se.detach().to(DEV), dsq.to(DEV), mu.to(DEV), invstd.to(DEV), dz, s1, s2,
+              B, C, _lib.dtype_code(dt), st())
+    sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
+    dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
+    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam, dbet,
+              k, C, st())
+    close(dgam.cpu(), gg, dt, k=3); close(dbet.cpu(), gb, dt, k=3)
+    dy = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    _lib.call("ka_bn_bwd_apply", dz, yd, k, dy, B, C, _lib.dtype_code(dt), st())
+    close(from_nhwc(dy), gy, dt, k=3)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_relu_bn_backward_and_block_dx(dtn):
+    dt = DT[dtn]
+    B, C = 4, 128
+    g = torch.Generator().manual_seed(41)
+    y = rnd(torch.randn(B, C, 9, 9, generator=g), dt).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    dh = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
+    h = torch.relu(F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5))
+    gy, gg, gb = torch.autograd.grad((h * dh).sum(), [y, gamma, beta])
+    mu = y.detach().mean(dim=(0, 2, 3)); invstd = 1 / torch.sqrt(y.detach().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    scale = (gamma.detach() * invstd).to(DEV); shift = (beta.detach() - mu * gamma.detach() * invstd).to(DEV)
+    yd = to_nhwc(y.detach(), dt)
+    da = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    s1, s2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.call("ka_relu_bn_bwd_reduce", to_nhwc(dh, dt), yd, scale, shift, mu.to(DEV), invstd.to(DEV), da, s1, s2, B, C,
+              _lib.dtype_code(dt), st())
+    sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
+    dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
+    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam, dbet,
+              k, C, st())
+    dy = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    _lib.call("ka_bn_bwd_apply", da, yd, k, dy, B, C, _lib.dtype_code(dt), st())
+    close(from_nhwc(dy), gy, dt, k=3); close(dgam.cpu(), gg, dt, k=3); close(dbet.cpu(), gb, dt, k=3)
+
+    # block_dx: residual + pool backward with ties / dead channels / constant planes
+    x = rnd(torch.relu(torch.randn(B, C, 9, 9, generator=g)), dt)
+    x[1, 3] = 0.0; x[2, 5] = 0.75; x[0, 7, 0, :3] = 9.0
+    xr = x.clone().requires_grad_(True)
+    dpool = torch.randn(B, 3 * C, generator=g)
+    dxc = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
+    dout = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
+    outv = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
+    ref = torch.autograd.grad((orc.global_pool(xr) * dpool).sum(), xr)[0] + dxc + dout * (outv > 0)
+    dx = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    _lib.call("ka_block_dx", to_nhwc(dxc, dt), to_nhwc(dout, dt), to_nhwc(outv, dt), to_nhwc(x, dt), dpool.to(DEV), dx, B, C,
+              _lib.dtype_code(dt), st())
+    close(from_nhwc(dx), ref, dt, k=2)
+    dx2 = torch.empty(B, 81, C, dtype=dt, device=DEV)
+    _lib.call("ka_block_dx", None, None, None, to_nhwc(x, dt), dpool.to(DEV), dx2, B, C, _lib.dtype_code(dt), st())
+    close(from_nhwc(dx2), ref - dxc - dout * (outv > 0), dt, k=2)
+
+
+# ------------------------------------------------------------------ small GEMMs
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(37, 50, 70, 0, 1), (130, 16, 768, 0, 1), (65, 96, 33, 0, 0), (40, 24, 1000, 1, 0)])
+def test_gemm_variants(M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.t() if ta else A) @ (Bm.t() if tb else Bm)
+    C = torch.empty(M, N, device=DEV)
+    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), C, bias.to(DEV), M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 0, 1, 1, st())
+    assert torch.allclose(C.cpu(), torch.relu(ref + bias), rtol=1e-5, atol=1e-4)
+    # split-K + reduce, bf16 operand
+    ns = 3
+    slab = torch.empty(ns, M, N, device=DEV)
+    _lib.call("ka_gemm", A.bfloat16().to(DEV), Bm.to(DEV), slab, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 1, 0, 0, 0, ns, st())
+    out = torch.ones(M, N, device=DEV)
+    _lib.call("ka_reduce_slabs", slab, out, ns, M * N, 1, st())
+    ref2 = (A.bfloat16().float().t() if ta else A.bfloat16().float()) @ (Bm.t() if tb else Bm)
+    assert torch.allclose(out.cpu(), ref2 + 1, rtol=1e-4, atol=1e-3)
+    # bf16 output
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), Cb, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 1, 0, 1, st())
+    assert torch.allclose(Cb.float().cpu(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+def test_row_kernels():
+    g = torch.Generator().manual_seed(5)
+    M, N = 1000, 24
+    A, Bm = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    p1, p2 = torch.empty(4, N, device=DEV), torch.empty(4, N, device=DEV)
+    _lib.call("ka_colsum", A.to(DEV), Bm.to(DEV), p1, p2, M, N, 4, st())
+    assert torch.allclose(p1.sum(0).cpu(), A.sum(0), atol=1e-3) and torch.allclose(p2.sum(0).cpu(), (A * Bm).sum(0), atol=1e-3)
+    _lib.call("ka_rows_sq_sums", A.to(DEV), p1, p2, M, N, 4, st())
+    assert torch.allclose(p2.sum(0).cpu(), (A * A).sum(0), atol=1e-3)
+    gd, h = A.clone().to(DEV), Bm.to(DEV)
+    _lib.call("ka_relu_mask", gd, h, M * N, st())
+    assert torch.equal(gd.cpu(), A * (Bm > 0))
+    sc, sh = torch.rand(N, generator=g), torch.randn(N, generator=g)
+    out = torch.empty(M, N, device=DEV)
+    _lib.call("ka_rows_affine_relu", A.to(DEV), sc.to(DEV), sh.to(DEV), out, M, N, st())
+    assert torch.allclose(out.cpu(), torch.relu(A * sc + sh), atol=1e-6)
+    af = torch.empty(7, N, device=DEV)
+    _lib.call("ka_affine_rows", A[:7].contiguous().to(DEV), sc.to(DEV), sh.to(DEV), 0.5, af, 7, N, st())
+    assert torch.allclose(af.cpu(), sc * (A[:7] * 0.5) + sh, atol=1e-6)
+
+
+# ------------------------------------------------------------------ GAE / loss / optimiser vs golden
+
+def test_gae_bit_exact(golden):
+    g = golden("g4_gae")
+    r, v, nv = g["rewards"].to(DEV), g["values"].to(DEV), g["next_value"].to(DEV)
+    T, N = r.shape
+    adv = torch.empty_like(r)
+
+    def run(term, ov=None, ln=None):
+        _lib.call("ka_gae", r, v, term.float().to(DEV), nv, None if ov is None else ov.to(DEV),
+                  None if ln is None else ln.to(DEV), adv, T, N, 0.99, 0.95, 0, st())
+        return adv.cpu().numpy()
+
+    assert np.array_equal(run(g["terminated"]), g.np("adv_gpu"))
+    assert np.array_equal(run(g["terminated"], g["override"]), g.np("adv_override_gpu"))
+    assert np.array_equal(run(g["terminated_padded"], None, g["lengths"]), g.np("adv_padded_gpu"))
+    assert np.allclose(run(g["terminated_padded"], g["override"], g["lengths"]), g.np("adv_padded_override"), rtol=1e-5, atol=1e-5)
+    # f64
+    r64, v64 = r[:16, :4].double().contiguous(), v[:16, :4].double().contiguous()
+    a64 = torch.empty_like(r64)
+    _lib.call("ka_gae", r64, v64, g["terminated"][:16, :4].float().contiguous().to(DEV), nv[:4].double().contiguous(), None,
+              None, a64, 16, 4, 0.99, 0.95, 1, st())
+    assert np.allclose(a64.cpu().numpy(), g.np("adv_f64"), rtol=1e-12, atol=1e-12)
+    # advantage normalisation (unbiased std)
+    flat = torch.from_numpy(g.np("adv_gpu")).reshape(-1)
+    out = torch.empty_like(flat, device=DEV)
+    _lib.call("ka_normalize_advantages", flat.to(DEV), out, flat.numel(), st())
+    assert torch.allclose(out.cpu(), orc.normalize_advantages(flat), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["third.", "ragged."])
+def test_fused_loss_matches_reference(golden, tag):
+    g = golden("g3_loss")
+    B, A = 4, 11259
+    logits = g[tag + "logits"].reshape(B, A).to(DEV)
+    dl = torch.empty(B, A, device=DEV)
+    nlp, rl, re = (torch.empty(B, device=DEV) for _ in range(3))
+    flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+    lp, lv, ls, ce, eps = 1.0, 1.5, 0.1, 0.01, 0.2
+    _lib.call("ka_policy_loss", logits, g[tag + "legal"].to(DEV), g[tag + "actions"].to(DEV), g[tag + "old_log_probs"].to(DEV),
+              g[tag + "advantages"].to(DEV), None, dl, nlp, rl, re, flags, None, eps, lp / B, ce / B, B, A, st())
+    out = torch.zeros(16, device=DEV)
+    acc = torch.zeros(4, device=DEV)
+    dv, ds = torch.empty(B, 3, device=DEV), torch.empty(B, device=DEV)
+    _lib.call("ka_value_loss", g[tag + "value_logits"].to(DEV), g[tag + "score"].reshape(B).to(DEV), g[tag + "value_cats"].to(DEV),
+              g[tag + "score_targets"].to(DEV), None, rl, re, dv, ds, out, acc, None, lp, lv, ls, ce, 1, B, st())
+    o = out.cpu()
+    assert flags.cpu().tolist() == [0, 0]
+    assert torch.allclose(nlp.cpu(), g[tag + "new_log_probs"], rtol=1e-5, atol=1e-5)
+    for i, k in enumerate(["policy_loss", "value_loss", "score_loss", "entropy", "total"]):
+        assert abs(float(o[i]) - float(g[tag + k])) <= 1e-5 * max(1.0, abs(float(g[tag + k]))), k
+    assert torch.allclose(dl.cpu(), g[tag + "grad.logits"].reshape(B, A), rtol=1e-4, atol=1e-8)
+    assert torch.allclose(dv.cpu(), g[tag + "grad.value_logits"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(ds.cpu(), g[tag + "grad.score"].reshape(B), rtol=1e-4, atol=1e-8)
+    assert abs(float(acc[1]) - (lv * float(g[tag + "value_loss"]) + ls * float(g[tag + "score_loss"]))) < 1e-5
+    # scalar value projection
+    sv = torch.empty(B, device=DEV)
+    _lib.call("ka_scalar_value", g[tag + "value_logits"].to(DEV), (g[tag + "score"] * 3).reshape(B).to(DEV), 0.1, sv, B, st())
+    assert torch.allclose(sv.cpu(), g[tag + "scalar_blended"], rtol=1e-5, atol=1e-6)
+
+
+def test_loss_guards_and_gather():
+    B, A, S = 3, 11259, 6
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, A, generator=g)
+    mb = orc.synth_minibatch(S, seed=9, legal_kind="ragged")
+    idx = torch.tensor([4, 1, 5])
+    old = mb["old_log_probs"]
+    ref_lp, ref_ent = orc.masked_policy_terms(logits, mb["legal"][idx], mb["actions"][idx])
+    nlp, rl, re = (torch.empty(B, device=DEV) for _ in range(3))
+    flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+    args = lambda lg, legal: ("ka_policy_loss", lg.to(DEV), legal.to(DEV), mb["actions"].to(DEV), old.to(DEV),
+                              mb["advantages"].to(DEV), idx.to(DEV), None, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B, B, A, st())
+    _lib.call(*args(logits, mb["legal"]))
+    assert flags.cpu().tolist() == [0, 0]
+    assert torch.allclose(nlp.cpu(), ref_lp, rtol=1e-5, atol=1e-5)
+    assert abs(float(re.mean()) - float(ref_ent)) < 1e-5
+    bad = logits.clone(); bad[1, 77] = float("nan")
+    _lib.call(*args(bad, mb["legal"]))
+    assert flags.cpu().tolist() == [1, 0]
+    flags.zero_()
+    legal = mb["legal"].clone(); legal[5] = False
+    _lib.call(*args(logits, legal))
+    assert flags.cpu().tolist() == [0, 1]
+
+
+def test_clip_adam_matches_reference(golden):
+    g = golden("g6_adam")
+    n = 5
+    params = [g[f"p0.{i}"].clone().to(DEV) for i in range(n)]
+    grads = [torch.empty_like(p) for p in params]
+    ms = [torch.zeros_like(p) for p in params]
+    vs = [torch.zeros_like(p) for p in params]
+    chunk = _lib.query("ka_adam_chunk")
+    recs, bt, bo = [], [], []
+    for i, p in enumerate(params):
+        recs += [p.data_ptr(), grads[i].data_ptr(), ms[i].data_ptr(), vs[i].data_ptr(), p.numel()]
+        for off in range(0, p.numel(), chunk):
+            bt.append(i); bo.append(off)
+    tab = torch.tensor(recs, dtype=torch.int64, device=DEV)
+    btd, bod = torch.tensor(bt, dtype=torch.int32, device=DEV), torch.tensor(bo, dtype=torch.int64, device=DEV)
+    partial = torch.empty(len(bt), dtype=torch.float64, device=DEV)
+    ctl, step = torch.zeros(4, device=DEV), torch.zeros(1, device=DEV)
+    accn = torch.zeros(1, device=DEV)
+    for s in range(3):
+        for i in range(n):
+            grads[i].copy_(g[f"g{s}.{i}"])
+        _lib.call("ka_clip_adam_step", tab, btd, bod, len(bt), partial, ctl, step, None, None, accn, 1.0, 2e-4, 0.9, 0.999, 1e-8, st())
+        assert abs(float(ctl[0]) - float(g[f"norm{s}"])) <= 1e-5 * float(g[f"norm{s}"])
+        for i in range(n):
+            assert torch.allclose(params[i].cpu(), g[f"p{s + 1}.{i}"], rtol=1e-6, atol=1e-7), (s, i)
+    assert float(step) == 3.0
+    for i in range(n):
+        assert torch.allclose(ms[i].cpu(), g[f"m.{i}"], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(vs[i].cpu(), g[f"v.{i}"], rtol=1e-5, atol=1e-10)
+    # inf gradient -> step skipped, scaler backs off; guard flag -> skipped too
+    before = [p.clone() for p in params]
+    grads[0][0] = float("inf")
+    scaler = torch.tensor([65536.0, 5.0], device=DEV)
+    _lib.call("ka_clip_adam_step", tab, btd, bod, len(bt), partial, ctl, step, scaler, None, None, 1.0, 2e-4, 0.9, 0.999, 1e-8, st())
+    assert float(step) == 3.0 and all(torch.equal(a, b) for a, b in zip(before, params))
+    assert scaler.cpu().tolist() == [32768.0, 0.0]
+    grads[0][0] = 1.0
+    flags = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    _lib.call("ka_clip_adam_step", tab, btd, bod, len(bt), partial, ctl, step, scaler, flags, None, 1.0, 2e-4, 0.9, 0.999, 1e-8, st())
+    assert float(step) == 3.0 and all(torch.equal(a, b) for a, b in zip(before, params))
+    assert scaler.cpu().tolist() == [32768.0, 1.0]

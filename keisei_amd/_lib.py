@@ -25,17 +25,18 @@ _SIGS = {
     "ka_nhwc_to_nchw": "pp ii i p",
     "ka_bn_reduce": "p i p i i p p",
     "ka_pair_reduce": "pp ii p p",
-    "ka_bn_coeffs": "p d pppp ff pppp i p",
+    "ka_bn_coeffs": "p d p pppp p ff pppp i p",
     "ka_bn_eval_coeffs": "pppp f pp i p",
-    "ka_bn_bwd_coeffs": "pp d ppp ppp i p",
+    "ka_bn_bwd_coeffs": "pp d p ppp ppp i i p",
     "ka_affine_rows": "ppp f p ii p",
     "ka_bn_bwd_apply": "pppp ii i p",
     "ka_block_tail_fwd": "ppppp pp ii i p",
+    "ka_pool_fwd": "pp ii i p",
     "ka_tail_bwd_reduce": "pppppp p ii i p",
     "ka_tail_bwd_dz": "ppppppp ppp ii i p",
     "ka_relu_bn_bwd_reduce": "pppppp ppp ii i p",
     "ka_block_dx": "ppppp p ii i p",
-    "ka_gemm": "pppp iii iii ii iii i i p",
+    "ka_gemm": "pppp iii iii ii iii i i i p",
     "ka_reduce_slabs": "pp i q i p",
     "ka_colsum": "pppp ii i p",
     "ka_relu_mask": "pp q p",

@@ -142,12 +142,15 @@ __global__ void pair_reduce_kernel(const float* __restrict__ p1, const float* __
 
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
-__global__ void bn_coeffs_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* running_mean, float* running_var,
-                                 float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                 float* __restrict__ mean_out, float* __restrict__ invstd_out, int C) {
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, double count, const double* __restrict__ count_dev,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                 float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                 float* __restrict__ invstd_out, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;          // global element count after a cross-rank all-reduce
     const double mean = sums[c] / count;
     double var = sums[C + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -176,16 +179,19 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 
 // dgamma/dbeta from the LOCAL sums; dy = k1*dz + k2 + k3*y from the (possibly all-reduced) sums
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
-                                     double count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     double count, const double* __restrict__ count_dev,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ k, int C) {
+                                     float* __restrict__ dbeta, float* __restrict__ k, int C, int train) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;
     if (dgamma) { dbeta[c] = (float)sums_local[c]; dgamma[c] = (float)sums_local[C + c]; }
     const double g = gamma[c], is = invstd[c], mu = mean[c];
     const double k1 = g * is;
-    const double k3 = -g * is * is * sums_global[C + c] / count;
-    const double k2 = -g * is * sums_global[c] / count - k3 * mu;
+    // eval mode (running statistics are constants): dy = gamma*invstd*dz
+    const double k3 = train ? -g * is * is * sums_global[C + c] / count : 0.0;
+    const double k2 = train ? -g * is * sums_global[c] / count - k3 * mu : 0.0;
     k[c] = (float)k1; k[C + c] = (float)k2; k[2 * C + c] = (float)k3;
 }
 
@@ -267,6 +273,52 @@ __global__ __launch_bounds__(kThreads) void block_tail_fwd_kernel(
         }
         const f32x2 var = combine_sum(red, m, sq);
         if (m.active && m.slice == 0 && pool) {
+            float* pr = pool + (size_t)b * 3 * C;
+            pr[c] = mean[0]; pr[c + 1] = mean[1];
+            pr[C + c] = mxx[0]; pr[C + c + 1] = mxx[1];
+            pr[2 * C + c] = sqrtf(var[0] / KA_BOARD); pr[2 * C + c + 1] = sqrtf(var[1] / KA_BOARD);
+        }
+    }
+}
+
+// pool = [mean|max|std] of an arbitrary (B,81,C) tensor (se_resnet.py:93-98)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pool, int C) {
+    extern __shared__ float red[];
+    const BoardMap m(C);
+    const int b = blockIdx.x;
+    const size_t base = (size_t)b * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        f32x2 v[kMaxPPT];
+        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    v[i] = ld2(x + base + (size_t)p * C + c);
+                    sum[0] += v[i][0]; sum[1] += v[i][1];
+                    mx[0] = fmaxf(mx[0], v[i][0]); mx[1] = fmaxf(mx[1], v[i][1]);
+                }
+            }
+        }
+        const f32x2 tot = combine_sum(red, m, sum);
+        const f32x2 mxx = combine_max(red, m, mx);
+        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
+        f32x2 sq = {0.f, 0.f};
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < kMaxPPT; ++i) {
+                const int p = m.slice + i * m.ph;
+                if (p < KA_BOARD) {
+                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
+                    sq[0] += d0 * d0; sq[1] += d1 * d1;
+                }
+            }
+        }
+        const f32x2 var = combine_sum(red, m, sq);
+        if (m.active && m.slice == 0) {
             float* pr = pool + (size_t)b * 3 * C;
             pr[c] = mean[0]; pr[c + 1] = mean[1];
             pr[C + c] = mxx[0]; pr[C + c + 1] = mxx[1];
@@ -495,12 +547,14 @@ extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, do
     return ka_check_launch("pair_reduce");
 }
 
-extern "C" int ka_bn_coeffs(const double* sums, double count, const float* gamma, const float* beta,
-                            float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                            float* shift, float* mean, float* invstd, int C, void* stream) {
+extern "C" int ka_bn_coeffs(const double* sums, double count, const double* count_dev, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                            float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                            void* stream) {
     KA_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && count > 0, "bn_coeffs: bad arguments");
     hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums,
-                       count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+                       count, count_dev, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                       shift, mean, invstd, C);
     return ka_check_launch("bn_coeffs");
 }
 
@@ -512,12 +566,12 @@ extern "C" int ka_bn_eval_coeffs(const float* gamma, const float* beta, const fl
     return ka_check_launch("bn_eval_coeffs");
 }
 
-extern "C" int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
-                                const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k, int C,
-                                void* stream) {
+extern "C" int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count,
+                                const double* count_dev, const float* gamma, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* k, int C, int train, void* stream) {
     KA_REQUIRE(sums_local && sums_global && gamma && mean && invstd && k && count > 0, "bn_bwd_coeffs: bad arguments");
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
-                       sums_local, sums_global, count, gamma, mean, invstd, dgamma, dbeta, k, C);
+                       sums_local, sums_global, count, count_dev, gamma, mean, invstd, dgamma, dbeta, k, C, train);
     return ka_check_launch("bn_bwd_coeffs");
 }
 
@@ -550,6 +604,15 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_tail_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
                                             (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C));
     return ka_check_launch("block_tail_fwd");
+}
+
+extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(x && pool, "pool_fwd: null tensor");
+    KA_BOARD_CHECK("pool_fwd");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
+                                            (const T*)x, pool, C));
+    return ka_check_launch("pool_fwd");
 }
 
 extern "C" int ka_tail_bwd_reduce(const void* dout, const void* out, const void* y, const float* scale,

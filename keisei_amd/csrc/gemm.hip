@@ -17,7 +17,7 @@ struct GemmArgs {
     const void* A; const void* B; void* C; const float* bias;
     int M, N, K, lda, ldb, ldc;
     int transA, transB;          // opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k]; same for B[k,n]
-    int a_bf16, b_bf16, c_bf16, relu, ksplit_len;
+    int a_bf16, b_bf16, c_bf16, relu, ksplit_len, accumulate;
 };
 
 __device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             if (g.relu) v = fmaxf(v, 0.f);
             const size_t o = slab + (size_t)m * g.ldc + n;
             if (g.c_bf16) static_cast<uint16_t*>(g.C)[o] = f2bf(v);
-            else static_cast<float*>(g.C)[o] = v;
+            else static_cast<float*>(g.C)[o] = g.accumulate ? static_cast<float*>(g.C)[o] + v : v;
         }
     }
 }
@@ -190,13 +190,14 @@ inline int grid1d(size_t n, int cap) { size_t b = (n + 255) / 256; return (int)(
 
 // nsplit > 1: C must hold nsplit slabs of M*ldc floats (no bias/relu/bf16 then); reduce with ka_reduce_slabs.
 extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
-                       int ldc, int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int nsplit,
-                       void* stream) {
+                       int ldc, int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int accumulate,
+                       int nsplit, void* stream) {
     KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "gemm: bad arguments");
-    KA_REQUIRE(nsplit == 1 || (!bias && !relu && !c_bf16), "gemm: split-K output must be raw fp32 slabs");
+    KA_REQUIRE(nsplit == 1 || (!bias && !relu && !c_bf16 && !accumulate), "gemm: split-K output must be raw fp32 slabs");
+    KA_REQUIRE(!(accumulate && c_bf16), "gemm: accumulate needs an fp32 output");
     int len = (K + nsplit - 1) / nsplit;
     len = (len + 15) / 16 * 16;
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, a_bf16, b_bf16, c_bf16, relu, len};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, a_bf16, b_bf16, c_bf16, relu, len, accumulate};
     dim3 grid((N + 63) / 64, (M + 63) / 64, nsplit);
     KA_REQUIRE(grid.y <= 65535, "gemm: M too large for grid.y (%d rows)", M);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);

@@ -1,0 +1,438 @@
+"""HIP execution engine for the SE-ResNet (forward + hand-written backward).
+
+Drives libkeisei_amd.so for CUDA/HIP tensors: activations live in NHWC (B,81,C) as bf16 (AMP on)
+or fp32 (AMP off), convolutions run on the MFMA kernels with weights re-packed into fragment
+order as *derived caches* (the stored parameters keep the reference's shapes and names), and the
+whole network is a single autograd node whose backward is the explicit kernel sequence below --
+there is no eager/PyTorch arithmetic on this path.
+
+Kernel sequence per GlobalPoolBiasBlock (reference: se_resnet.py:68-90)
+  forward : conv1(+BN1 stats) | bn_coeffs | global_fc (2 gemm) | conv2 with fused
+            relu(bn1(.))+g input transform (+BN2 stats, SE squeeze) | bn_coeffs | SE FCs (2 gemm)
+            | tail: relu(bn2(.)*sigmoid+shift+x) fused with the next block's global pool
+  backward: tail_bwd_reduce | SE FC backward | tail_bwd_dz (+BN2 sums) | bn_bwd_coeffs/apply |
+            conv2 dgrad (+ dg sums) | conv2 wgrad (input transform recomputed on the fly) |
+            global_fc backward | relu_bn_bwd_reduce | bn_bwd_coeffs/apply | conv1 dgrad |
+            conv1 wgrad | block_dx (residual + mean/max/std pool backward)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from keisei_amd import _lib
+
+_call = _lib.call
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _Saved:
+    """Activations kept between forward and backward."""
+    __slots__ = ("B", "T", "train", "xin", "stem", "blocks", "heads", "sync")
+
+
+class SEResNetEngine:
+    def __init__(self, model: nn.Module) -> None:
+        self.model = model
+        self._packs: Dict[tuple, tuple] = {}
+        self._pack_key = None
+        self._scratch: Optional[torch.Tensor] = None
+        self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
+
+    # ------------------------------------------------------------------ helpers
+    def notify_weights_updated(self) -> None:
+        self.weights_epoch += 1
+
+    def _scratch_f32(self, n: int, device) -> torch.Tensor:
+        if self._scratch is None or self._scratch.numel() < n or self._scratch.device != device:
+            self._scratch = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        return self._scratch
+
+    def _conv_layers(self):
+        m = self.model
+        yield "input_conv", m.input_conv
+        for i, blk in enumerate(m.blocks):
+            yield f"blocks.{i}.conv1", blk.conv1
+            yield f"blocks.{i}.conv2", blk.conv2
+
+    def _get_packs(self, T: torch.dtype, device) -> Dict[str, tuple]:
+        """fragment-ordered weight copies: name -> (forward pack, dgrad pack | None)."""
+        convs = list(self._conv_layers())
+        key = (T, self.weights_epoch, sum(c.weight._version for _, c in convs), convs[0][1].weight.data_ptr())
+        if key == self._pack_key:
+            return self._packs
+        code, st = _lib.dtype_code(T), _lib.stream_ptr(device)
+        cpk = 32 if T == torch.bfloat16 else 16
+        packs = {}
+        for name, conv in convs:
+            w = conv.weight.detach()
+            co, ci = w.shape[0], w.shape[1]
+            ci_pad = _round_up(ci, 64) if name == "input_conv" else ci   # only the 50-plane stem input is padded
+            fwd = torch.empty(9 * (ci_pad // cpk) * (co // 16) * 1024, dtype=torch.uint8, device=device)
+            _call("ka_pack_conv3x3", w, fwd, co, ci, co, ci_pad, 0, code, st)
+            dg = None
+            if name != "input_conv":
+                dg = torch.empty(9 * (co // cpk) * (ci // 16) * 1024, dtype=torch.uint8, device=device)
+                _call("ka_pack_conv3x3", w, dg, co, ci, ci, co, 1, code, st)
+            packs[name] = (fwd, dg)
+        self._packs, self._pack_key = packs, key
+        return packs
+
+    @staticmethod
+    def _sync_group(bn: nn.Module):
+        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return True
+        return False
+
+    def _bn_forward(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
+        """returns scale, shift, mean, invstd (fp32 [C])"""
+        scale = torch.empty(C, device=device); shift = torch.empty(C, device=device)
+        if not train:
+            _call("ka_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C, st)
+            return scale, shift, None, None
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
+        _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, st)
+        if self._sync_group(bn):
+            sums[2 * C] = float(count)
+            dist.all_reduce(sums)
+            count_t = sums[2 * C:]
+        else:
+            count_t = None
+        mean = torch.empty(C, device=device); invstd = torch.empty(C, device=device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track and bn.momentum is None:
+            momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)      # cumulative average (host sync; non-default)
+        else:
+            momentum = float(bn.momentum if bn.momentum is not None else 0.0)
+        _call("ka_bn_coeffs", sums, float(count), count_t, bn.weight, bn.bias,
+              bn.running_mean if track else None, bn.running_var if track else None,
+              bn.num_batches_tracked if track else None, momentum, float(bn.eps), scale, shift, mean, invstd, C, st)
+        return scale, shift, mean, invstd
+
+    def _gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, st, abf=0, bbf=0, cbf=0, relu=0, acc=0, ns=1):
+        _call("ka_gemm", A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, abf, bbf, cbf, relu, acc, ns, st)
+
+    def _linear(self, x, lin: nn.Linear, relu: int, st):
+        M, K = x.shape
+        N = lin.weight.shape[0]
+        y = torch.empty(M, N, device=x.device)
+        self._gemm(x, lin.weight, y, lin.bias, M, N, K, K, K, N, 0, 1, st, relu=relu)
+        return y
+
+    def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0):
+        """dW = dy^T x (split over rows), db = colsum(dy), dx = dy W."""
+        M, N = dy.shape
+        K = lin.weight.shape[1] if lin.weight.ndim == 2 else lin.weight.shape[1]
+        dev = dy.device
+        ns = max(1, min(64, (M + 511) // 512))
+        dW = torch.empty(N, K, device=dev)
+        if ns == 1:
+            self._gemm(dy, x, dW, None, N, K, M, N, K, K, 1, 0, st, bbf=x_bf16)
+        else:
+            slab = self._scratch_f32(ns * N * K, dev)
+            self._gemm(dy, x, slab, None, N, K, M, N, K, K, 1, 0, st, bbf=x_bf16, ns=ns)
+            _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
+        grads[wname] = dW.view_as(lin.weight)
+        if bname is not None:
+            nsb = max(1, min(256, (M + 2047) // 2048))
+            db = torch.empty(N, device=dev)
+            if nsb == 1:
+                _call("ka_colsum", dy, None, db, None, M, N, 1, st)
+            else:
+                part = self._scratch_f32(nsb * N, dev)
+                _call("ka_colsum", dy, None, part, None, M, N, nsb, st)
+                _call("ka_reduce_slabs", part, db, nsb, N, 0, st)
+            grads[bname] = db
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else torch.empty(M, K, device=dev)
+        self._gemm(dy, lin.weight, dx, None, M, K, N, N, K, K, 0, 0, st, acc=acc_dx)
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, obs: torch.Tensor, train: bool, keep: bool, T: torch.dtype, idx: Optional[torch.Tensor] = None):
+        m = self.model
+        p = m.params
+        dev = obs.device
+        st = _lib.stream_ptr(dev)
+        code = _lib.dtype_code(T)
+        C = p.channels
+        B = obs.shape[0] if idx is None else idx.shape[0]
+        if obs.dtype != torch.float32 or not obs.is_contiguous():
+            obs = obs.float().contiguous()
+        packs = self._get_packs(T, dev)
+        rows = _lib.query("ka_conv3x3_sqpart_rows", B)
+        count = B * 81
+        sv = _Saved()
+        sv.B, sv.T, sv.train = B, T, train
+
+        def new_act(ch):
+            return torch.empty(B, 81, ch, dtype=T, device=dev)
+
+        # ---- stem
+        cin_pad = _round_up(p.obs_channels, 64)
+        xin = new_act(cin_pad)
+        _call("ka_obs_to_nhwc", obs, idx, xin, B, p.obs_channels, cin_pad, code, st)
+        y0 = new_act(C)
+        bsum = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)
+        _call("ka_conv3x3_fwd", xin, packs["input_conv"][0], y0, None, None, None, 0,
+              bsum if train else None, sq if train else None, B, cin_pad, C, code, st)
+        sc0, sh0, mu0, is0 = self._bn_forward(m.input_bn, bsum, B, sq, rows, C, count, train, dev, st)
+        x = new_act(C)
+        pool = torch.empty(B, 3 * C, device=dev)
+        _call("ka_block_tail_fwd", y0, sc0, sh0, None, None, x, pool, B, C, code, st)
+        sv.xin = xin
+        sv.stem = (y0, sc0, sh0, mu0, is0)
+        sv.blocks = []
+
+        # ---- tower
+        for i, blk in enumerate(m.blocks):
+            y1 = new_act(C)
+            bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
+            _call("ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
+                  bsum1 if train else None, sq1 if train else None, B, C, C, code, st)
+            sc1, sh1, mu1, is1 = self._bn_forward(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
+            g1 = self._linear(pool, blk.global_fc[0], 1, st)
+            g = self._linear(g1, blk.global_fc[2], 0, st)
+            y2 = new_act(C)
+            bsum2 = torch.empty(B, C, device=dev); sq2 = torch.empty(rows, C, device=dev)
+            _call("ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
+                  bsum2, sq2 if train else None, B, C, C, code, st)
+            sc2, sh2, mu2, is2 = self._bn_forward(blk.bn2, bsum2, B, sq2, rows, C, count, train, dev, st)
+            sqz = torch.empty(B, C, device=dev)
+            _call("ka_affine_rows", bsum2, sc2, sh2, 1.0 / 81.0, sqz, B, C, st)
+            se1 = self._linear(sqz, blk.se_fc1, 1, st)
+            se = self._linear(se1, blk.se_fc2, 0, st)
+            out = new_act(C)
+            pool_out = torch.empty(B, 3 * C, device=dev)
+            _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
+            if keep:
+                sv.blocks.append((x, pool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out))
+            x, pool = out, pool_out
+
+        # ---- heads
+        P = p.policy_channels
+        M = B * 81
+        p1 = torch.empty(M, P, device=dev)
+        wp1 = m.policy_conv1.weight
+        self._gemm(x, wp1, p1, None, M, P, C, C, C, P, 0, 1, st, abf=int(T == torch.bfloat16))
+        nsp = max(1, min(256, (M + 2047) // 2048))
+        if train:
+            part = torch.empty(nsp, P, device=dev); part2 = torch.empty(nsp, P, device=dev)
+            _call("ka_rows_sq_sums", p1, part, part2, M, P, nsp, st)
+        else:
+            part = part2 = None
+        scp, shp, mup, isp = self._bn_forward(m.policy_bn1, part, nsp, part2, nsp, P, M, train, dev, st)
+        p1r = torch.empty(M, P, device=dev)
+        _call("ka_rows_affine_relu", p1, scp, shp, p1r, M, P, st)
+        A = m.SPATIAL_MOVE_TYPES
+        logits = torch.empty(B, 9, 9, A, device=dev)
+        wp2 = m.policy_conv2.weight
+        self._gemm(p1r, wp2, logits, m.policy_conv2.bias, M, A, P, P, P, A, 0, 1, st)
+        v1 = self._linear(pool, m.value_fc1, 1, st)
+        v = self._linear(v1, m.value_fc2, 0, st)
+        s1 = self._linear(pool, m.score_fc1, 1, st)
+        s = self._linear(s1, m.score_fc2, 0, st)
+        if keep:
+            sv.heads = (x, pool, p1, scp, shp, mup, isp, p1r, v1, s1)
+        return logits, v, s, (sv if keep else None)
+
+    # ------------------------------------------------------------------ backward
+    def _bn_backward(self, bn, s1p, s2p, rows, C, count, mu, istd, train, grads, prefix, dev, st):
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        _call("ka_pair_reduce", s1p, s2p, rows, C, sums, st)
+        gsums, count_t = sums, None
+        if train and self._sync_group(bn):
+            gsums = sums.clone()
+            gsums[2 * C] = float(count)
+            dist.all_reduce(gsums)
+            count_t = gsums[2 * C:]
+        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
+        k = torch.empty(3 * C, device=dev)
+        _call("ka_bn_bwd_coeffs", sums, gsums, float(count), count_t, bn.weight, mu, istd, dgam, dbet, k, C,
+              1 if train else 0, st)
+        grads[prefix + ".weight"], grads[prefix + ".bias"] = dgam, dbet
+        return k
+
+    def backward(self, sv: _Saved, dlogits, dv, ds) -> Dict[str, torch.Tensor]:
+        m = self.model
+        p = m.params
+        B, T, train = sv.B, sv.T, sv.train
+        code = _lib.dtype_code(T)
+        bf = int(T == torch.bfloat16)
+        C, P, A = p.channels, p.policy_channels, m.SPATIAL_MOVE_TYPES
+        x, pool, p1, scp, shp, mup, isp, p1r, v1, s1 = sv.heads
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        packs = self._get_packs(T, dev)
+        grads: Dict[str, torch.Tensor] = {}
+        M = B * 81
+        count = M
+
+        def new_act(ch=C):
+            return torch.empty(B, 81, ch, dtype=T, device=dev)
+
+        def eval_stats(bn):
+            return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+
+        # ---- value / score heads -> dpool
+        dpool = torch.zeros(B, 3 * C, device=dev)
+        for d_out, hid, fc1, fc2, n1, n2 in ((dv, v1, m.value_fc1, m.value_fc2, "value_fc1", "value_fc2"),
+                                              (ds, s1, m.score_fc1, m.score_fc2, "score_fc1", "score_fc2")):
+            if d_out is None:
+                grads[n2 + ".weight"] = torch.zeros_like(fc2.weight); grads[n2 + ".bias"] = torch.zeros_like(fc2.bias)
+                grads[n1 + ".weight"] = torch.zeros_like(fc1.weight); grads[n1 + ".bias"] = torch.zeros_like(fc1.bias)
+                continue
+            d_out = d_out.float().contiguous()
+            dh = self._linear_bwd(d_out, hid, fc2, grads, n2 + ".weight", n2 + ".bias", st)
+            _call("ka_relu_mask", dh, hid, dh.numel(), st)
+            self._linear_bwd(dh, pool, fc1, grads, n1 + ".weight", n1 + ".bias", st, dx_out=dpool, acc_dx=1)
+
+        # ---- policy head
+        dxc = None
+        if dlogits is not None:
+            dl = dlogits.float().contiguous().view(M, A)
+            w2 = _FakeLinear(m.policy_conv2.weight.view(A, P), m.policy_conv2.bias)
+            dp = self._linear_bwd(dl, p1r, w2, grads, "policy_conv2.weight", "policy_conv2.bias", st)
+            grads["policy_conv2.weight"] = grads["policy_conv2.weight"].view_as(m.policy_conv2.weight)
+            _call("ka_rows_bn_bwd", dp, p1, scp, shp, M, P, 0, st)                # ReLU mask
+            nsp = max(1, min(256, (M + 2047) // 2048))
+            part = torch.empty(nsp, P, device=dev); part2 = torch.empty(nsp, P, device=dev)
+            mu_p, is_p = (mup, isp) if train else eval_stats(m.policy_bn1)
+            _call("ka_rows_bn_sums", dp, p1, mu_p, is_p, part, part2, M, P, nsp, st)
+            k = self._bn_backward(m.policy_bn1, part, part2, nsp, P, M, mu_p, is_p, train, grads, "policy_bn1", dev, st)
+            _call("ka_rows_bn_bwd", dp, p1, k, None, M, P, 1, st)
+            w1 = _FakeLinear(m.policy_conv1.weight.view(P, C), None)
+            dxc = new_act()
+            self._linear_bwd_act(dp, x, w1, grads, "policy_conv1.weight", dxc, bf, st)
+            grads["policy_conv1.weight"] = grads["policy_conv1.weight"].view_as(m.policy_conv1.weight)
+        else:
+            for n, t in (("policy_conv2.weight", m.policy_conv2.weight), ("policy_conv2.bias", m.policy_conv2.bias),
+                         ("policy_bn1.weight", m.policy_bn1.weight), ("policy_bn1.bias", m.policy_bn1.bias),
+                         ("policy_conv1.weight", m.policy_conv1.weight)):
+                grads[n] = torch.zeros_like(t)
+        dout = new_act()
+        _call("ka_block_dx", dxc, None, None, x, dpool, dout, B, C, code, st)
+
+        s1p = torch.empty(B, C, device=dev); s2p = torch.empty(B, C, device=dev)
+        nsplit = _lib.query("ka_wgrad_splits", B, C, C)
+        slab = self._scratch_f32(max(nsplit * 9 * C * C, _lib.query("ka_wgrad_splits", B, 64, C) * 9 * C * 64), dev)
+
+        # ---- tower, last block first
+        for i in range(len(sv.blocks) - 1, -1, -1):
+            blk = m.blocks[i]
+            (bx, bpool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out) = sv.blocks[i]
+            pre = f"blocks.{i}."
+            if not train:
+                mu1, is1 = eval_stats(blk.bn1); mu2, is2 = eval_stats(blk.bn2)
+            dse = torch.empty(B, 2 * C, device=dev)
+            _call("ka_tail_bwd_reduce", dout, out, y2, sc2, sh2, se, dse, B, C, code, st)
+            dse1 = self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st)
+            _call("ka_relu_mask", dse1, se1, dse1.numel(), st)
+            dsq = self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st)
+            dz = new_act()
+            _call("ka_tail_bwd_dz", dout, out, y2, se, dsq, mu2, is2, dz, s1p, s2p, B, C, code, st)
+            k2 = self._bn_backward(blk.bn2, s1p, s2p, B, C, count, mu2, is2, train, grads, pre + "bn2", dev, st)
+            _call("ka_bn_bwd_apply", dz, y2, k2, dz, B, C, code, st)                         # dz -> dy2 in place
+            dh = new_act()
+            dg = torch.empty(B, C, device=dev)
+            _call("ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
+            dW2 = torch.empty_like(blk.conv2.weight)
+            _call("ka_conv3x3_wgrad", dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, code, st)
+            grads[pre + "conv2.weight"] = dW2
+            dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
+            _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
+            dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
+                                       pre + "global_fc.0.bias", st)
+            _call("ka_relu_bn_bwd_reduce", dh, y1, sc1, sh1, mu1, is1, dh, s1p, s2p, B, C, code, st)   # dh -> da1 in place
+            k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
+            _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
+            dxc = dz                                                                          # reuse buffer
+            _call("ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
+            dW1 = torch.empty_like(blk.conv1.weight)
+            _call("ka_conv3x3_wgrad", dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, code, st)
+            grads[pre + "conv1.weight"] = dW1
+            dx = dh                                                                           # reuse buffer
+            _call("ka_block_dx", dxc, dout, out, bx, dpool_x, dx, B, C, code, st)
+            dout = dx
+
+        # ---- stem
+        y0, sc0, sh0, mu0, is0 = sv.stem
+        if not train:
+            mu0, is0 = eval_stats(m.input_bn)
+        _call("ka_relu_bn_bwd_reduce", dout, y0, sc0, sh0, mu0, is0, dout, s1p, s2p, B, C, code, st)
+        k0 = self._bn_backward(m.input_bn, s1p, s2p, B, C, count, mu0, is0, train, grads, "input_bn", dev, st)
+        _call("ka_bn_bwd_apply", dout, y0, k0, dout, B, C, code, st)
+        dW0 = torch.empty_like(m.input_conv.weight)
+        cin_pad = sv.xin.shape[2]
+        _call("ka_conv3x3_wgrad", dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad, p.obs_channels, C, 0, code, st)
+        grads["input_conv.weight"] = dW0
+        return grads
+
+    def _linear_bwd_act(self, dy, x_act, lin, grads, wname, dx_act, bf, st):
+        """policy conv1x1 backward where the input / its gradient are activation tensors (B*81, C) of dtype T."""
+        M, N = dy.shape
+        K = lin.weight.shape[1]
+        dev = dy.device
+        ns = max(1, min(64, (M + 4095) // 4096))
+        dW = torch.empty(N, K, device=dev)
+        slab = self._scratch_f32(ns * N * K, dev)
+        self._gemm(dy, x_act, slab, None, N, K, M, N, K, K, 1, 0, st, bbf=bf, ns=ns)
+        _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
+        grads[wname] = dW
+        self._gemm(dy, lin.weight, dx_act, None, M, K, N, N, K, K, 0, 0, st, cbf=bf)
+
+
+class _FakeLinear:
+    """weight/bias pair with nn.Linear's attribute names (1x1 convolutions viewed as linear maps)."""
+    __slots__ = ("weight", "bias")
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+
+
+class _SEResNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine: SEResNetEngine, obs, idx, train, keep, T, names, *params):
+        logits, v, s, saved = engine.forward(obs, train, keep, T, idx)
+        ctx.engine, ctx.saved, ctx.names = engine, saved, names
+        ctx.set_materialize_grads(False)
+        return logits, v, s
+
+    @staticmethod
+    def backward(ctx, dlogits, dv, ds):
+        if ctx.saved is None:
+            raise RuntimeError("SE-ResNet HIP backward called without saved activations")
+        grads = ctx.engine.backward(ctx.saved, dlogits, dv, ds)
+        ctx.saved = None
+        return (None, None, None, None, None, None, None, *[grads.get(n) for n in ctx.names])
+
+
+def run_model(model: nn.Module, obs: torch.Tensor, idx: Optional[torch.Tensor] = None):
+    """Forward of SEResNetModel on a CUDA/HIP device.  Returns (policy (B,9,9,139), value (B,3), score (B,1))."""
+    engine = getattr(model, "_hip_engine", None)
+    if engine is None:
+        engine = SEResNetEngine(model)
+        object.__setattr__(model, "_hip_engine", engine)
+    bf16 = False
+    if model._amp_enabled and model._amp_dtype == torch.bfloat16:
+        bf16 = True
+    elif torch.is_autocast_enabled("cuda"):
+        if torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            bf16 = True
+        else:
+            raise _lib.KeiseiHipError("the HIP path supports fp32 and bf16 autocast only (fp16 requested)")
+    elif model._amp_enabled:
+        raise _lib.KeiseiHipError("the HIP path supports fp32 and bf16 autocast only")
+    T = torch.bfloat16 if bf16 else torch.float32
+    named = [(n, p) for n, p in model.named_parameters()]
+    keep = torch.is_grad_enabled() and any(p.requires_grad for _, p in named)
+    names = tuple(n for n, _ in named)
+    with torch.autocast("cuda", enabled=False):
+        return _SEResNetFunction.apply(engine, obs, idx, model.training, keep, T, names, *[p for _, p in named])

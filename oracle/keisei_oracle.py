@@ -124,7 +124,7 @@ def synth_state_dict(s: NetShape, salt: int = 0) -> Dict[str, torch.Tensor]:
             v = 0.05 * wave
         else:
             fan_in = int(np.prod(shape[1:]))
-            v = wave * math.sqrt(2.0 / fan_in)
+            v = wave * math.sqrt(0.5 / fan_in)
         out[key] = v.to(torch.float32).reshape(shape)
     return out
 
@@ -219,6 +219,49 @@ def seresnet_forward(sd, obs: torch.Tensor, num_blocks: int, train: bool,
     s = torch.relu(F.linear(pool, sd["score_fc1.weight"], sd["score_fc1.bias"]))
     s = F.linear(s, sd["score_fc2.weight"], sd["score_fc2.bias"])
     return policy, v, s
+
+
+def seresnet_policy_bf16_storage(sd, obs: torch.Tensor, num_blocks: int, train: bool) -> torch.Tensor:
+    """fp32 math with bf16 rounding at exactly the points where the HIP bf16 mode stores bf16
+    (conv operands, y1/y2/out activations, the fused relu(bn1)+g conv2 input); BN statistics come
+    from the unrounded conv results, as in the conv epilogue.  This DEFINES the bf16 mode's stated
+    numerics: tests hold the HIP bf16 path to a few bf16 ulps of this emulation, and report the
+    (inherent, input-dependent) distance of both from the fp32 reference side by side."""
+    def q(t):
+        return t.bfloat16().float()
+
+    def coeffs(y, pre):
+        if train:
+            mu, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+        else:
+            mu, var = sd[pre + ".running_mean"], sd[pre + ".running_var"]
+        sc = sd[pre + ".weight"] / torch.sqrt(var + BN_EPS)
+        return sc, sd[pre + ".bias"] - mu * sc
+
+    def aff(y, sc, sh):
+        return y * sc[None, :, None, None] + sh[None, :, None, None]
+
+    y0 = F.conv2d(q(obs), q(sd["input_conv.weight"]), padding=1)
+    sc, sh = coeffs(y0, "input_bn")
+    x = q(torch.relu(aff(q(y0), sc, sh)))
+    for i in range(num_blocks):
+        pre = f"blocks.{i}."
+        C = x.shape[1]
+        y1 = F.conv2d(x, q(sd[pre + "conv1.weight"]), padding=1)
+        sc1, sh1 = coeffs(y1, pre + "bn1")
+        g = torch.relu(F.linear(global_pool(x), sd[pre + "global_fc.0.weight"], sd[pre + "global_fc.0.bias"]))
+        g = F.linear(g, sd[pre + "global_fc.2.weight"], sd[pre + "global_fc.2.bias"])
+        h = q(torch.relu(aff(q(y1), sc1, sh1)) + g[:, :, None, None])
+        y2 = F.conv2d(h, q(sd[pre + "conv2.weight"]), padding=1)
+        sc2, sh2 = coeffs(y2, pre + "bn2")
+        sqz = sc2 * y2.mean(dim=(2, 3)) + sh2
+        e = torch.relu(F.linear(sqz, sd[pre + "se_fc1.weight"], sd[pre + "se_fc1.bias"]))
+        e = F.linear(e, sd[pre + "se_fc2.weight"], sd[pre + "se_fc2.bias"])
+        x = q(torch.relu(aff(q(y2), sc2, sh2) * torch.sigmoid(e[:, :C])[:, :, None, None] + e[:, C:, None, None] + x))
+    p1 = F.conv2d(x, sd["policy_conv1.weight"])
+    scp, shp = coeffs(p1, "policy_bn1")
+    p = F.conv2d(torch.relu(aff(p1, scp, shp)), sd["policy_conv2.weight"], sd["policy_conv2.bias"])
+    return p.permute(0, 2, 3, 1)
 
 
 # --------------------------------------------------------------------------- losses

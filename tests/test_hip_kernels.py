@@ -188,8 +188,10 @@ def test_bn_stats_and_tail_forward(dtn, C):
     _lib.call("ka_bn_reduce", bsum, B, sq, 1, C, sums, st())
     scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
     rmd, rvd = rm.to(DEV), rv.to(DEV)
-    _lib.call("ka_bn_coeffs", sums, float(B * 81), gamma.to(DEV), beta.to(DEV), rmd, rvd, 0.1, 1e-5, scale, shift, mean,
-              invstd, C, st())
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    _lib.call("ka_bn_coeffs", sums, float(B * 81), None, gamma.to(DEV), beta.to(DEV), rmd, rvd, nbt, 0.1, 1e-5, scale, shift,
+              mean, invstd, C, st())
+    assert int(nbt) == 1
     rm_ref, rv_ref = rm.clone(), rv.clone()
     z = F.batch_norm(yq, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
     assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
@@ -245,8 +247,8 @@ def test_block_tail_backward_chain(dtn, C):
     sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
     _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
     dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
-    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam, dbet,
-              k, C, st())
+    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), None, gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam,
+              dbet, k, C, 1, st())
     close(dgam.cpu(), gg, dt, k=3); close(dbet.cpu(), gb, dt, k=3)
     dy = torch.empty(B, 81, C, dtype=dt, device=DEV)
     _lib.call("ka_bn_bwd_apply", dz, yd, k, dy, B, C, _lib.dtype_code(dt), st())
@@ -274,8 +276,8 @@ def test_relu_bn_backward_and_block_dx(dtn):
     sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
     _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
     dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
-    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam, dbet,
-              k, C, st())
+    _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), None, gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam,
+              dbet, k, C, 1, st())
     dy = torch.empty(B, 81, C, dtype=dt, device=DEV)
     _lib.call("ka_bn_bwd_apply", da, yd, k, dy, B, C, _lib.dtype_code(dt), st())
     close(from_nhwc(dy), gy, dt, k=3); close(dgam.cpu(), gg, dt, k=3); close(dbet.cpu(), gb, dt, k=3)
@@ -308,19 +310,19 @@ def test_gemm_variants(M, N, K, ta, tb):
     bias = torch.randn(N, generator=g)
     ref = (A.t() if ta else A) @ (Bm.t() if tb else Bm)
     C = torch.empty(M, N, device=DEV)
-    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), C, bias.to(DEV), M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 0, 1, 1, st())
+    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), C, bias.to(DEV), M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 0, 1, 0, 1, st())
     assert torch.allclose(C.cpu(), torch.relu(ref + bias), rtol=1e-5, atol=1e-4)
     # split-K + reduce, bf16 operand
     ns = 3
     slab = torch.empty(ns, M, N, device=DEV)
-    _lib.call("ka_gemm", A.bfloat16().to(DEV), Bm.to(DEV), slab, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 1, 0, 0, 0, ns, st())
+    _lib.call("ka_gemm", A.bfloat16().to(DEV), Bm.to(DEV), slab, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 1, 0, 0, 0, 0, ns, st())
     out = torch.ones(M, N, device=DEV)
     _lib.call("ka_reduce_slabs", slab, out, ns, M * N, 1, st())
     ref2 = (A.bfloat16().float().t() if ta else A.bfloat16().float()) @ (Bm.t() if tb else Bm)
     assert torch.allclose(out.cpu(), ref2 + 1, rtol=1e-4, atol=1e-3)
     # bf16 output
     Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), Cb, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 1, 0, 1, st())
+    _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), Cb, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 1, 0, 0, 1, st())
     assert torch.allclose(Cb.float().cpu(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
 
 

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""PPO samples/sec of the Keisei SE-ResNet hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one KataGo-PPO minibatch through the product path
+(keisei_amd.training.katago_ppo.KataGoPPOAlgorithm._fused_step): fused row-gather + SE-ResNet
+forward (train-mode BN), fused loss+gradient kernel, hand-written backward, fused
+GradScaler/clip/Adam -- on a device-resident synthetic epoch dataset (inputs already in HBM).
+Default workload = BASELINE.json configs[2]: se_resnet 40x256, minibatch 4096, bf16 activations/MFMA
+(the reference's production AMP mode), one rank per GPU, DDP (+SyncBatchNorm, as keisei-ddp.toml)
+gradient all-reduce over RCCL when N > 1; per-rank batch fixed (weak scaling).
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  roofline     -- dominant kernel (conv3x3 implicit-GEMM, fwd+dgrad): achieved MFMA TFLOP/s from the
+                  algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream)
+  cpu_baseline -- the oracle (CPU restatement of the reference) timed on this host, bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (num_blocks, channels, se_reduction, global_pool_channels, policy_channels, value_fc, score_fc, T, N, B)
+    "40x256": (40, 256, 16, 128, 32, 256, 128, 128, 128, 4096),
+    "6x128": (6, 128, 16, 128, 32, 256, 128, 128, 64, 2048),
+    "2x32": (2, 32, 8, 16, 8, 32, 16, 8, 8, 32),
+}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_bytes_per_sample(nb, C, P, n_params, B, act_bytes):
+    """SURVEY 8d contract figure, scaled to the activation storage actually used (4 -> act_bytes)."""
+    act = act_bytes * 81 * C * (23 * nb + 10) + 4 * 81 * (100 + 556 + 4 * P)
+    return act + 40.0 * n_params / B
+
+
+def train_flops_per_sample(nb, C, G, R, P, V, S):
+    fwd = 2 * 81 * 9 * 50 * C + nb * (2 * (2 * 81 * 9 * C * C) + 2 * (3 * C * G + G * C + C * R + R * 2 * C)) \
+        + 2 * 81 * (C * P + P * 139) + 2 * (3 * C * V + 3 * V + 3 * C * S + S)
+    return 3.0 * fwd
+
+
+def synth_dataset(total, seed, device):
+    """Mirror of the reference's scripts/profile_hotpath.py:436-454 synthetic update inputs."""
+    g = torch.Generator().manual_seed(seed)
+    A = 11259
+    obs = torch.randn(total, 50, 9, 9, generator=g)
+    masks = torch.zeros(total, A, dtype=torch.bool)
+    masks[:, : A // 3] = True
+    actions = torch.randint(0, A // 3, (total,), generator=g)
+    cats = torch.randint(-1, 3, (total,), generator=g)
+    return {
+        "obs": obs.to(device), "masks": masks.to(device), "actions": actions.to(device),
+        "old_lp": (-8.2 + 0.05 * torch.randn(total, generator=g)).to(device),
+        "adv": torch.randn(total, generator=g).to(device), "cats": cats.to(device),
+        "score_t": torch.randn(total, generator=g).clamp(-1.5, 1.5).to(device),
+    }
+
+
+def cpu_baseline(shape, seconds_budget=25.0):
+    """Times the oracle's PPO minibatch step (fp32 CPU PyTorch restatement of the reference) on this host."""
+    from oracle import keisei_oracle as orc
+
+    nb, C, Rr, G, P, V, S = shape
+    ns = orc.NetShape(nb, C, Rr, G, P, V, S)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = orc.synth_state_dict(ns)
+    Bc = 32 if C >= 256 and nb >= 20 else 256
+    mb = orc.synth_minibatch(Bc, seed=1234)
+    w = orc.LossWeights(1.0, 1.5, 0.1, 0.01, 0.2)
+    state = None
+    _, state, _ = orc.ppo_minibatch_step(sd, nb, mb, w, state)       # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
+        t0 = time.perf_counter()
+        _, state, _ = orc.ppo_minibatch_step(sd, nb, mb, w, state)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(Bc / med, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle ppo_minibatch_step (fp32 CPU PyTorch), se_resnet {nb}x{C}, minibatch {Bc}, "
+                      f"median of {len(times)} steps after 1 warm-up"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="40x256", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=0, help="override the minibatch size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams
+    from keisei_amd.training.model_registry import build_model
+    from keisei_amd.training.value_adapter import MultiHeadValueAdapter
+    from keisei_amd.hip import seresnet as eng_mod
+
+    nb, C, Rr, G, P, V, S, T, N, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(1234 + rank)
+    model = build_model("se_resnet", dict(num_blocks=nb, channels=C, se_reduction=Rr, global_pool_channels=G,
+                                          policy_channels=P, value_fc_size=V, score_fc_size=S, obs_channels=50))
+    model.to(device)
+    n_params = sum(p.numel() for p in model.parameters())
+    fwd_model = model
+    if world > 1:
+        fwd_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        fwd_model = torch.nn.parallel.DistributedDataParallel(fwd_model, device_ids=[local_rank], gradient_as_bucket_view=True)
+        model = fwd_model.module
+    pp = KataGoPPOParams(batch_size=B, use_amp=(args.dtype == "bf16"), lambda_score=0.1, score_blend_alpha=0.1,
+                         compile_mode="default")        # keisei-katago.toml:33-49 (compile_mode accepted, unused)
+    algo = KataGoPPOAlgorithm(pp, model, forward_model=fwd_model)
+    adapter = MultiHeadValueAdapter(pp.lambda_value, pp.lambda_score, pp.score_blend_alpha)
+    assert algo._fused_path_available(device, adapter), "fused HIP path unavailable"
+    total = T * N
+    data = synth_dataset(total, 1234 + rank, device)
+    fs = algo._fused_begin(data, device, adapter)
+    fwd_model.train()
+    perm = torch.randperm(total, device=device)
+    nmb = total // B
+
+    def one_step(i):
+        lo = (i % nmb) * B
+        algo._fused_step(fs, perm[lo:lo + B], device)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    engine = model._hip_engine
+    if not args.no_kernel_events:
+        engine.kernel_events = {"conv3x3": [], "wgrad": []}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    metrics = algo._fused_end(fs)
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        act_bytes = 2 if args.dtype == "bf16" else 4
+        bps = algorithmic_bytes_per_sample(nb, C, P, n_params, B, act_bytes)
+        flops = train_flops_per_sample(nb, C, G, C // Rr, P, V, S)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        roof = None
+        extra = {}
+        ev = getattr(engine, "kernel_events", None)
+        if ev and ev["conv3x3"]:
+            conv_ms = [a.elapsed_time(b) for a, b in ev["conv3x3"]]
+            conv_flop = 2.0 * B * 81 * 9 * C * C
+            avg = sum(conv_ms) / len(conv_ms)
+            ach = conv_flop / (avg * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv, forward + dgrad launches)",
+                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
+                    "flop_per_launch": conv_flop}
+            if ev["wgrad"]:
+                w_ms = [a.elapsed_time(b) for a, b in ev["wgrad"]]
+                wavg = sum(w_ms) / len(w_ms)
+                extra["wgrad_kernel"] = {"avg_launch_ms": round(wavg, 4), "achieved_tflops": round(conv_flop / (wavg * 1e-3) / 1e12, 1),
+                                         "launches_timed": len(w_ms)}
+            extra["conv_share_of_step"] = round((sum(conv_ms) + sum(w_ms if ev["wgrad"] else [])) / (elapsed * 1e3), 3)
+        out = {
+            "metric": "PPO samples/sec, se_resnet 40x256 on 50x9x9" if args.workload == "40x256" else f"PPO samples/sec, se_resnet {args.workload}",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"se_resnet {nb}x{C} KataGo-PPO minibatch step (gather+fwd+loss+bwd+clip+Adam), "
+                                   f"minibatch {B}/GPU from a {total}-sample device-resident epoch dataset, obs 50x9x9",
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+            "roofline": roof,
+            "hbm_roofline": {"algorithmic_bytes_per_sample": round(bps), "activation_storage_bytes": act_bytes,
+                             "achieved_GBps": round(value / world * bps / 1e9, 1), "peak_GBps": PEAK_HBM_GBS,
+                             "frac": round(value / world * bps / 1e9 / PEAK_HBM_GBS, 4)},
+            "model_tflops": {"train_flop_per_sample": flops, "achieved": round(value / world * flops / 1e12, 1), "peak": peak,
+                             "frac": round(value / world * flops / 1e12 / peak, 4)},
+            "train_metrics": {k: round(v, 5) for k, v in metrics.items()},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline((nb, C, Rr, G, P, V, S))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

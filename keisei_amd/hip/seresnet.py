@@ -43,9 +43,23 @@ class SEResNetEngine:
         self._packs: Dict[tuple, tuple] = {}
         self._pack_key = None
         self._scratch: Optional[torch.Tensor] = None
+        self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
 
     # ------------------------------------------------------------------ helpers
+    def _timed(self, kind: str, name: str, *args) -> None:
+        """Launch `name`; when bench.py set ``kernel_events`` bracket the launch with events on the launch stream."""
+        ev = self.kernel_events
+        if ev is None:
+            _call(name, *args)
+            return
+        stream = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        _call(name, *args)
+        b.record(stream)
+        ev[kind].append((a, b))
+
     def notify_weights_updated(self) -> None:
         self.weights_epoch += 1
 
@@ -195,14 +209,14 @@ class SEResNetEngine:
         for i, blk in enumerate(m.blocks):
             y1 = new_act(C)
             bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
-            _call("ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
+            self._timed("conv3x3", "ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
                   bsum1 if train else None, sq1 if train else None, B, C, C, code, st)
             sc1, sh1, mu1, is1 = self._bn_forward(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
             g1 = self._linear(pool, blk.global_fc[0], 1, st)
             g = self._linear(g1, blk.global_fc[2], 0, st)
             y2 = new_act(C)
             bsum2 = torch.empty(B, C, device=dev); sq2 = torch.empty(rows, C, device=dev)
-            _call("ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
+            self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
                   bsum2, sq2 if train else None, B, C, C, code, st)
             sc2, sh2, mu2, is2 = self._bn_forward(blk.bn2, bsum2, B, sq2, rows, C, count, train, dev, st)
             sqz = torch.empty(B, C, device=dev)
@@ -342,9 +356,9 @@ class SEResNetEngine:
             _call("ka_bn_bwd_apply", dz, y2, k2, dz, B, C, code, st)                         # dz -> dy2 in place
             dh = new_act()
             dg = torch.empty(B, C, device=dev)
-            _call("ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
+            self._timed("conv3x3", "ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
             dW2 = torch.empty_like(blk.conv2.weight)
-            _call("ka_conv3x3_wgrad", dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, code, st)
+            self._timed("wgrad", "ka_conv3x3_wgrad", dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, code, st)
             grads[pre + "conv2.weight"] = dW2
             dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
             _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
@@ -354,9 +368,9 @@ class SEResNetEngine:
             k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
             _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
             dxc = dz                                                                          # reuse buffer
-            _call("ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
+            self._timed("conv3x3", "ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
             dW1 = torch.empty_like(blk.conv1.weight)
-            _call("ka_conv3x3_wgrad", dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, code, st)
+            self._timed("wgrad", "ka_conv3x3_wgrad", dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, code, st)
             grads[pre + "conv1.weight"] = dW1
             dx = dh                                                                           # reuse buffer
             _call("ka_block_dx", dxc, dout, out, bx, dpool_x, dx, B, C, code, st)

@@ -1,0 +1,688 @@
+"""KataGo-style multi-head PPO: rollout buffer, action selection and the clipped-surrogate
+minibatch update (mirror of keisei/training/katago_ppo.py:19-991).
+
+Public names, signatures, validation messages, returned metric keys and side effects follow the
+reference.  Two execution paths share this front end:
+
+* **fused HIP path** (model is an ``SEResNetModel`` on a CUDA/HIP device, optimiser is a plain
+  ``torch.optim.Adam``): GAE, advantage normalisation, minibatch gather, forward, the fused
+  loss+gradient kernel, the hand-written backward and the fused GradScaler/clip/Adam step all run
+  as HIP kernels from libkeisei_amd.so with **no host synchronisation inside the minibatch loop**
+  (the reference's NaN / zero-legal-action guards become device flags that veto the optimiser
+  step and raise after the loop).
+* **generic path** (CPU tensors -- the reference's whole test-suite -- or any other module /
+  adapter / optimiser): the same algorithm in ordinary tensor ops.
+"""
+from __future__ import annotations
+
+import dataclasses
+import logging
+from typing import Any, Callable
+
+import torch
+import torch.nn.functional as F
+from torch.amp import GradScaler, autocast
+
+from keisei_amd import _lib
+from keisei_amd.training.gae import compute_gae_gpu
+from keisei_amd.training.models.katago_base import KataGoBaseModel
+from keisei_amd.training.models.se_resnet import SEResNetModel
+from keisei_amd.training.value_adapter import MultiHeadValueAdapter
+
+SCORE_NORMALIZATION = 76.0      # keisei/sl/dataset.py:32
+_log = logging.getLogger(__name__)
+
+
+def _amp_dtype_and_device(use_amp: bool, device: torch.device) -> tuple[torch.dtype, str]:
+    """(autocast dtype, autocast device type); the dtype is a placeholder when AMP is off."""
+    if use_amp and (device.type == "cpu" or torch.cuda.is_bf16_supported()):
+        return torch.bfloat16, device.type
+    return torch.float16, device.type
+
+
+def ppo_clip_loss(new_log_probs: torch.Tensor, old_log_probs: torch.Tensor, advantages: torch.Tensor,
+                  clip_epsilon: float) -> torch.Tensor:
+    """-mean(min(r*A, clamp(r, 1-eps, 1+eps)*A)) with r = exp(new - old)."""
+    ratio = torch.exp(new_log_probs - old_log_probs)
+    clipped = torch.clamp(ratio, 1 - clip_epsilon, 1 + clip_epsilon)
+    return -torch.min(ratio * advantages, clipped * advantages).mean()
+
+
+def wdl_cross_entropy_loss(value_logits: torch.Tensor, value_cats: torch.Tensor) -> torch.Tensor:
+    """W/D/L cross-entropy, ignore_index = -1; all-ignored batches give a graph-connected zero."""
+    if not bool((value_cats >= 0).any()):
+        return value_logits.sum() * 0.0
+    return F.cross_entropy(value_logits, value_cats, ignore_index=-1)
+
+
+def compute_value_metrics(value_logits: torch.Tensor, value_targets: torch.Tensor) -> dict[str, float]:
+    pred = value_logits.argmax(dim=-1)
+    frac = lambda mask: mask.float().mean().item()  # noqa: E731
+    return {"value_accuracy": frac(pred == value_targets), "frac_predicted_win": frac(pred == 0),
+            "frac_predicted_draw": frac(pred == 1), "frac_predicted_loss": frac(pred == 2)}
+
+
+@dataclasses.dataclass(frozen=True)
+class KataGoPPOParams:
+    learning_rate: float = 2e-4
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_epsilon: float = 0.2
+    epochs_per_batch: int = 4
+    batch_size: int = 256
+    lambda_policy: float = 1.0
+    lambda_value: float = 1.5
+    lambda_score: float = 0.02
+    lambda_entropy: float = 0.01
+    score_normalization: float = SCORE_NORMALIZATION
+    grad_clip: float = 1.0
+    use_amp: bool = False
+    compile_mode: str | None = None     # accepted for config compatibility; no tracing compiler is used here
+    compile_dynamic: bool = True
+    entropy_decay_epochs: int = 0
+    score_blend_alpha: float = 0.0
+    use_terminated_for_gae: bool = True
+
+    def __post_init__(self) -> None:
+        if self.batch_size <= 0:
+            raise ValueError(f"batch_size must be > 0, got {self.batch_size}")
+        if self.epochs_per_batch <= 0:
+            raise ValueError(f"epochs_per_batch must be > 0, got {self.epochs_per_batch}")
+        if not 0.0 <= self.gamma <= 1.0:
+            raise ValueError(f"gamma must be in [0, 1], got {self.gamma}")
+        if not 0.0 <= self.gae_lambda <= 1.0:
+            raise ValueError(f"gae_lambda must be in [0, 1], got {self.gae_lambda}")
+        if self.clip_epsilon < 0.0:
+            raise ValueError(f"clip_epsilon must be >= 0, got {self.clip_epsilon}")
+        if self.learning_rate <= 0.0:
+            raise ValueError(f"learning_rate must be > 0, got {self.learning_rate}")
+        if self.grad_clip <= 0.0:
+            raise ValueError(f"grad_clip must be > 0, got {self.grad_clip}")
+
+
+_FIELDS = ("observations", "actions", "log_probs", "values", "rewards", "dones", "terminated", "legal_masks",
+           "value_categories", "score_targets")
+
+
+class KataGoRolloutBuffer:
+    """CPU structure-of-arrays rollout store (katago_ppo.py:128-388): pre-allocated, doubling growth
+    (at least 512*num_envs rows), optional ``env_ids`` and NaN-sentinel ``next_value_override`` columns."""
+
+    def __init__(self, num_envs: int, obs_shape: tuple[int, ...], action_space: int) -> None:
+        self.num_envs = num_envs
+        self.obs_shape = obs_shape
+        self.action_space = action_space
+        self._alloc_samples = 0
+        self._write_offset = 0
+        self._step_count = 0
+        self._storage: dict[str, torch.Tensor] = {}
+        self._has_env_ids = False
+        self._has_next_value_override = False
+
+    def _fresh(self, key: str, rows: int) -> torch.Tensor:
+        if key == "observations":
+            return torch.empty(rows, *self.obs_shape)
+        if key == "legal_masks":
+            return torch.empty(rows, self.action_space, dtype=torch.bool)
+        if key in ("actions", "value_categories", "env_ids"):
+            return torch.empty(rows, dtype=torch.long)
+        if key in ("dones", "terminated"):
+            return torch.empty(rows, dtype=torch.bool)
+        if key == "next_value_override":
+            return torch.full((rows,), float("nan"))
+        return torch.empty(rows)
+
+    def _ensure_capacity(self, n_samples: int) -> None:
+        need = self._write_offset + n_samples
+        if need <= self._alloc_samples:
+            return
+        cap = max(2 * need, 512 * self.num_envs)
+        keys = list(_FIELDS)
+        if self._has_env_ids:
+            keys.append("env_ids")
+        if self._has_next_value_override:
+            keys.append("next_value_override")
+        grown = {k: self._fresh(k, cap) for k in keys}
+        used = self._write_offset
+        if used:
+            for k, t in grown.items():
+                if k in self._storage:
+                    t[:used] = self._storage[k][:used]
+        self._storage, self._alloc_samples = grown, cap
+
+    @property
+    def size(self) -> int:
+        return self._step_count
+
+    def clear(self) -> None:
+        self._write_offset = 0
+        self._step_count = 0
+
+    def add(self, obs: torch.Tensor, actions: torch.Tensor, log_probs: torch.Tensor, values: torch.Tensor,
+            rewards: torch.Tensor, dones: torch.Tensor, terminated: torch.Tensor, legal_masks: torch.Tensor,
+            value_categories: torch.Tensor, score_targets: torch.Tensor, env_ids: torch.Tensor | None = None,
+            next_value_override: torch.Tensor | None = None) -> None:
+        """Append one timestep (n rows).  ``score_targets`` must already be normalised."""
+        host = lambda t: t.detach().cpu()  # noqa: E731
+        obs_c, act_c, lp_c, val_c, rew_c = host(obs), host(actions), host(log_probs), host(values), host(rewards)
+        done_c, term_c = host(dones), host(terminated)
+        if bool((term_c.bool() & ~done_c.bool()).any()):
+            raise AssertionError(
+                "terminated must be a subset of dones: every terminated position must also be done. "
+                "Got terminated=True where dones=False — likely a call site passing the merged signal.")
+        mask_c, cat_c, score_c = host(legal_masks), host(value_categories), host(score_targets)
+        bad = set(cat_c.unique().tolist()) - {-1, 0, 1, 2}
+        if bad:
+            raise ValueError(f"value_categories contains invalid values {bad}. "
+                             f"Expected only {{-1=ignore, 0=W, 1=D, 2=L}}.")
+        if bool(score_c.isnan().any()):
+            raise ValueError("score_targets contains NaN. With per-step material balance, "
+                             "all targets should be real-valued.")
+        peak = score_c.abs().max()
+        if peak > 3.5:
+            raise ValueError(f"score_targets appear unnormalized: max abs value = {peak.item():.1f}. "
+                             f"Expected in [-1.7, +1.7] typical, theoretical max 2.58 (guard 3.5).")
+        n = obs_c.shape[0]
+        if self._step_count == 0:
+            self._has_env_ids = self._has_env_ids or env_ids is not None
+            self._has_next_value_override = self._has_next_value_override or next_value_override is not None
+        self._ensure_capacity(n)
+        lo, hi = self._write_offset, self._write_offset + n
+        for key, val in zip(_FIELDS, (obs_c, act_c, lp_c, val_c, rew_c, done_c, term_c, mask_c, cat_c, score_c)):
+            self._storage[key][lo:hi] = val
+        if env_ids is not None:
+            if "env_ids" not in self._storage:
+                self._storage["env_ids"] = self._fresh("env_ids", self._alloc_samples)
+            self._storage["env_ids"][lo:hi] = host(env_ids)
+        if next_value_override is not None:
+            if "next_value_override" not in self._storage:
+                self._storage["next_value_override"] = self._fresh("next_value_override", self._alloc_samples)
+                self._has_next_value_override = True
+            self._storage["next_value_override"][lo:hi] = host(next_value_override).to(torch.float32)
+        elif self._has_next_value_override and "next_value_override" in self._storage:
+            self._storage["next_value_override"][lo:hi] = float("nan")     # no stale cells from a previous epoch
+        self._write_offset = hi
+        self._step_count += 1
+
+    def fill_alternating_perspective_overrides(self) -> None:
+        """Two-player frames alternate every ply: where no override was supplied and the transition is not
+        terminal, bootstrap from -V[t+1] (katago_ppo.py:320-362).  No-op for the env_ids (split-merge) layout."""
+        T, N = self._step_count, self.num_envs
+        if self._has_env_ids or T <= 1 or self._write_offset != T * N:
+            return
+        if "next_value_override" not in self._storage:
+            self._storage["next_value_override"] = self._fresh("next_value_override", self._alloc_samples)
+            self._has_next_value_override = True
+        ov = self._storage["next_value_override"][:T * N].view(T, N)
+        vals = self._storage["values"][:T * N].view(T, N)
+        term = self._storage["terminated"][:T * N].view(T, N).bool()
+        head = ov[:-1]
+        fill = torch.isnan(head) & ~term[:-1]
+        head[fill] = -vals[1:][fill]
+
+    def flatten(self) -> dict[str, torch.Tensor]:
+        if self._step_count == 0:
+            raise ValueError("Cannot flatten an empty buffer. Call add() at least once before flatten().")
+        n = self._write_offset
+        out = {"observations": self._storage["observations"][:n].reshape(-1, *self.obs_shape),
+               "legal_masks": self._storage["legal_masks"][:n].reshape(-1, self.action_space)}
+        for key in _FIELDS:
+            if key not in out:
+                out[key] = self._storage[key][:n].reshape(-1)
+        if self._has_env_ids and "env_ids" in self._storage:
+            out["env_ids"] = self._storage["env_ids"][:n].reshape(-1)
+        if self._has_next_value_override and "next_value_override" in self._storage:
+            out["next_value_override"] = self._storage["next_value_override"][:n].reshape(-1)
+        return out
+
+
+class _ModeBoundForward:
+    """Stand-in for the reference's torch.compile wrappers (katago_ppo.py:436-459): a callable with
+    ``_orig_mod`` that runs the wrapped module.  No tracing compiler is involved -- the GPU path is
+    already hand-written kernels -- but callers that look for ``compiled_train`` / ``compiled_eval``
+    keep working."""
+
+    def __init__(self, module: torch.nn.Module) -> None:
+        self._orig_mod = module
+
+    def __call__(self, *args, **kwargs):
+        return self._orig_mod(*args, **kwargs)
+
+
+class KataGoPPOAlgorithm:
+    def __init__(self, params: KataGoPPOParams, model: KataGoBaseModel, forward_model: torch.nn.Module | None = None,
+                 warmup_epochs: int = 0, warmup_entropy: float = 0.05) -> None:
+        self.params = params
+        self.model = model
+        self.forward_model = forward_model or model
+        unwrap = lambda m: m.module if hasattr(m, "module") else m  # noqa: E731
+        assert unwrap(self.forward_model) is unwrap(self.model), (
+            "forward_model and model must share parameters — compile + grad clipping requires this")
+
+        self.compiled_train: Callable[..., Any] | None = None
+        self.compiled_eval: Callable[..., Any] | None = None
+        if params.compile_mode is not None:
+            if params.compile_mode == "reduce-overhead" and params.compile_dynamic:
+                _log.warning("compile_mode='reduce-overhead' with compile_dynamic=True disables CUDA graph capture "
+                             "(the main benefit of reduce-overhead). Set compile_dynamic=False for fixed-batch-size runs.")
+            self.compiled_train = _ModeBoundForward(self.forward_model)
+            self.compiled_eval = _ModeBoundForward(self.forward_model)
+            self.forward_model.train()
+            _log.info("compile_mode=%s accepted; forward passes run on hand-written HIP kernels (no tracing compiler)",
+                      params.compile_mode)
+
+        self._timing_events: dict[str, list] = {"select_actions_forward_ms": [], "update_forward_backward_ms": [],
+                                                "gae_ms": []}
+        self.timings: dict[str, list[float]] = {k: [] for k in self._timing_events}
+
+        device = next(model.parameters()).device
+        if hasattr(model, "configure_amp"):
+            amp_dtype, amp_device = _amp_dtype_and_device(params.use_amp, device)
+            model.configure_amp(enabled=params.use_amp, dtype=amp_dtype, device_type=amp_device)
+            if self.compiled_train is not None:
+                model._amp_frozen = True
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=params.learning_rate)
+        self.scaler = GradScaler(enabled=params.use_amp and device.type == "cuda")
+        self.warmup_epochs = warmup_epochs
+        self.warmup_entropy = warmup_entropy
+        self.current_entropy_coeff = params.lambda_entropy
+        self._hip_state: dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ small helpers
+    def get_entropy_coeff(self, epoch: int) -> float:
+        if epoch < self.warmup_epochs:
+            return self.warmup_entropy
+        span = self.params.entropy_decay_epochs
+        done = epoch - self.warmup_epochs
+        if span <= 0 or done >= span:
+            return self.params.lambda_entropy
+        return self.warmup_entropy + (done / span) * (self.params.lambda_entropy - self.warmup_entropy)
+
+    def flush_timings(self) -> None:
+        """Event pairs -> milliseconds (the only synchronisation point of the timers)."""
+        for key, pairs in self._timing_events.items():
+            self.timings[key] = [a.elapsed_time(b) for a, b in pairs]
+            pairs.clear()
+
+    @staticmethod
+    def scalar_value(value_logits: torch.Tensor) -> torch.Tensor:
+        probs = torch.softmax(value_logits, dim=-1)
+        return probs[:, 0] - probs[:, 2]
+
+    def _event_pair(self, device):
+        stream = torch.cuda.current_stream(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        return a, b, stream
+
+    # ------------------------------------------------------------------ rollout side
+    @torch.no_grad()
+    def select_actions(self, obs: torch.Tensor, legal_masks: torch.Tensor, value_adapter: Any | None = None,
+                       ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        device = next(self.model.parameters()).device
+        net = self.compiled_eval if self.compiled_eval is not None else self.forward_model
+        self.forward_model.eval()
+        try:
+            if device.type == "cuda":
+                start, end, stream = self._event_pair(device)
+            out = net(obs)
+            if device.type == "cuda":
+                end.record(stream)
+                self._timing_events["select_actions_forward_ms"].append((start, end))
+            n_legal = legal_masks.sum(dim=-1)
+            if bool((n_legal == 0).any()):
+                empty = (n_legal == 0).nonzero(as_tuple=True)[0].tolist()
+                raise RuntimeError(f"Environments {empty} have zero legal actions — "
+                                   f"all-False legal mask would produce NaN")
+            logits = out.policy_logits.reshape(obs.shape[0], -1).float().masked_fill(~legal_masks, float("-inf"))
+            dist = torch.distributions.Categorical(torch.softmax(logits, dim=-1), validate_args=False)
+            actions = dist.sample()
+            log_probs = dist.log_prob(actions)
+            if value_adapter is not None:
+                values = value_adapter.scalar_value_blended(out.value_logits, out.score_lead)
+            else:
+                values = self.scalar_value(out.value_logits)
+            return actions, log_probs, values
+        finally:
+            self.forward_model.train()
+
+    # ------------------------------------------------------------------ advantages
+    def _advantages(self, data, buffer, next_values, device) -> torch.Tensor:
+        """GAE over the buffer layout (grid / per-env / flat), result on CPU (katago_ppo.py:651-773)."""
+        from keisei_amd.training.gae import compute_gae  # resolved at call time (tests patch the module attribute)
+
+        p = self.params
+        T, N = buffer.size, buffer.num_envs
+        total = data["rewards"].numel()
+        key = "terminated" if p.use_terminated_for_gae else "dones"
+        boot_cpu = next_values.detach().float().cpu()
+        if total == T * N:
+            grid = lambda name: data[name].reshape(T, N)  # noqa: E731
+            rewards, values, term = grid("rewards").float(), grid("values").float(), grid(key)
+            ov = grid("next_value_override").float() if "next_value_override" in data else None
+            if device.type == "cuda":
+                start, end, stream = self._event_pair(device)
+                adv = compute_gae_gpu(rewards.to(device), values.to(device), term.to(device),
+                                      next_values.detach().float().to(device), gamma=p.gamma, lam=p.gae_lambda,
+                                      next_value_override=None if ov is None else ov.to(device)).reshape(-1).cpu()
+                end.record(stream)
+                self._timing_events["gae_ms"].append((start, end))
+                return adv
+            return compute_gae(rewards, values, term, boot_cpu, gamma=p.gamma, lam=p.gae_lambda,
+                               next_value_override=ov).reshape(-1)
+        if "env_ids" in data:
+            from keisei_amd.training.gae import compute_gae_padded
+
+            env_ids = data["env_ids"]
+            order = torch.argsort(env_ids, stable=True)
+            envs, counts = env_ids[order].unique_consecutive(return_counts=True)
+            lengths = counts.tolist()
+            groups = torch.split(order, lengths)
+            n_env, t_max = len(lengths), max(lengths)
+            if envs.max() >= boot_cpu.shape[0]:
+                raise IndexError(f"env_id {envs.max().item()} >= next_values size {boot_cpu.shape[0]}")
+            r_pad, v_pad = torch.zeros(t_max, n_env), torch.zeros(t_max, n_env)
+            term_pad = torch.ones(t_max, n_env)                   # padding = terminated, zeroes propagation
+            ov_pad = torch.full((t_max, n_env), float("nan")) if "next_value_override" in data else None
+            boot = torch.zeros(n_env)
+            for j, rows in enumerate(groups):
+                L = lengths[j]
+                r_pad[:L, j], v_pad[:L, j] = data["rewards"][rows], data["values"][rows]
+                term_pad[:L, j] = data[key][rows]
+                boot[j] = boot_cpu[envs[j]]
+                if ov_pad is not None:
+                    ov_pad[:L, j] = data["next_value_override"][rows].float()
+            len_t = torch.tensor(lengths)
+            if device.type == "cuda":
+                from keisei_amd.training.gae import compute_gae_padded_gpu
+
+                padded = compute_gae_padded_gpu(r_pad.to(device), v_pad.to(device), term_pad.to(device), boot.to(device),
+                                                len_t, gamma=p.gamma, lam=p.gae_lambda,
+                                                next_value_override=None if ov_pad is None else ov_pad.to(device)).cpu()
+            else:
+                padded = compute_gae_padded(r_pad, v_pad, term_pad, boot, len_t, gamma=p.gamma, lam=p.gae_lambda,
+                                            next_value_override=ov_pad)
+            adv = torch.zeros(total)
+            for j, rows in enumerate(groups):
+                adv[rows] = padded[:lengths[j], j]
+            return adv
+        # legacy flat layout: one chain, bootstrap from the mean next value
+        return compute_gae(data["rewards"].float(), data["values"].float(), data[key], boot_cpu.mean(),
+                           gamma=p.gamma, lam=p.gae_lambda)
+
+    # ------------------------------------------------------------------ update
+    def update(self, buffer: KataGoRolloutBuffer, next_values: torch.Tensor, value_adapter: Any | None = None,
+               heartbeat_fn: Any | None = None) -> dict[str, float]:
+        self.forward_model.train()
+        assert self.forward_model.training, (
+            "forward_model must be in train mode at start of update() — compiled_train graph requires this")
+        self._timing_events["update_forward_backward_ms"].clear()
+        self._timing_events["gae_ms"].clear()
+
+        data = buffer.flatten()
+        total = data["rewards"].numel()
+        device = next(self.model.parameters()).device
+        advantages = self._advantages(data, buffer, next_values, device)
+        if advantages.numel() > 1:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+        batch = min(self.params.batch_size, total)
+
+        if self._fused_path_available(device, value_adapter):
+            metrics = self._update_fused(data, advantages, total, batch, device, value_adapter, heartbeat_fn)
+        else:
+            metrics = self._update_generic(data, advantages, total, batch, device, value_adapter, heartbeat_fn)
+        buffer.clear()
+        self.forward_model.train()
+        return metrics
+
+    # ---- generic path -------------------------------------------------------------------
+    def _update_generic(self, data, advantages, total, batch, device, value_adapter, heartbeat_fn):
+        p = self.params
+        amp_dtype, amp_device = _amp_dtype_and_device(p.use_amp, device)
+        if device.type == "cuda":
+            side = torch.cuda.Stream(device)
+            with torch.cuda.stream(side):
+                obs = data["observations"].pin_memory().to(device, non_blocking=True)
+                masks = data["legal_masks"].pin_memory().to(device, non_blocking=True)
+        else:
+            side = None
+            obs, masks = data["observations"].to(device), data["legal_masks"].to(device)
+        move = lambda t: t.to(device, non_blocking=True)  # noqa: E731
+        actions, old_lp, adv = move(data["actions"]), move(data["log_probs"]), move(advantages)
+        cats, score_t = move(data["value_categories"]), move(data["score_targets"])
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+
+        acc = {k: torch.zeros((), device=device) for k in ("policy", "value", "score", "entropy", "gnorm")}
+        zero = torch.zeros((), device=device)
+        n_updates = 0
+        last_logits = last_cats = None
+        net = self.compiled_train if self.compiled_train is not None else self.forward_model
+        for _ in range(p.epochs_per_batch):
+            perm = torch.randperm(total, device=device)
+            for lo in range(0, total, batch):
+                idx = perm[lo:lo + batch]
+                b_obs, b_mask, b_cats = obs[idx], masks[idx], cats[idx]
+                if device.type == "cuda":
+                    start, end, stream = self._event_pair(device)
+                with autocast(device_type=amp_device, dtype=amp_dtype, enabled=p.use_amp):
+                    out = net(b_obs)
+                    logits = out.policy_logits.reshape(b_obs.shape[0], -1)
+                    if bool(logits.isnan().any()):
+                        raise RuntimeError("NaN in raw policy logits from model forward pass")
+                    if bool((b_mask.sum(dim=-1) == 0).any()):
+                        raise RuntimeError("Batch contains samples with zero legal actions in update(). "
+                                           "Check that terminal-state masks are not stored in the buffer.")
+                    logp = F.log_softmax(logits.masked_fill(~b_mask, float("-inf")), dim=-1)
+                    new_lp = logp.gather(1, actions[idx].unsqueeze(1)).squeeze(1)
+                    policy_loss = ppo_clip_loss(new_lp, old_lp[idx], adv[idx], p.clip_epsilon)
+                    entropy = -(logp.exp() * logp.masked_fill(~b_mask, 0.0)).sum(dim=-1).mean()
+                    if value_adapter is not None:
+                        vs_loss = value_adapter.compute_value_loss(out.value_logits, returns=None, value_cats=b_cats,
+                                                                   score_targets=score_t[idx], score_pred=out.score_lead)
+                        value_loss, score_loss = vs_loss, zero
+                    else:
+                        value_loss = wdl_cross_entropy_loss(out.value_logits, b_cats)
+                        score_loss = F.mse_loss(out.score_lead.squeeze(-1), score_t[idx])
+                        vs_loss = p.lambda_value * value_loss + p.lambda_score * score_loss
+                    loss = p.lambda_policy * policy_loss + vs_loss - self.current_entropy_coeff * entropy
+                self.optimizer.zero_grad(set_to_none=True)
+                self.scaler.scale(loss).backward()
+                self.scaler.unscale_(self.optimizer)
+                gnorm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), p.grad_clip)
+                self.scaler.step(self.optimizer)
+                self.scaler.update()
+                self._notify_weights_changed()
+                if device.type == "cuda":
+                    end.record(stream)
+                    self._timing_events["update_forward_backward_ms"].append((start, end))
+                acc["policy"] += policy_loss.detach(); acc["value"] += value_loss.detach()
+                acc["score"] += score_loss.detach(); acc["entropy"] += entropy.detach()
+                acc["gnorm"] += gnorm.detach() if isinstance(gnorm, torch.Tensor) else float(gnorm)
+                n_updates += 1
+                last_logits, last_cats = out.value_logits.detach(), b_cats
+                if heartbeat_fn is not None:
+                    heartbeat_fn()
+        d = max(n_updates, 1)
+        metrics = {"policy_loss": (acc["policy"] / d).item(), "value_loss": (acc["value"] / d).item(),
+                   "score_loss": (acc["score"] / d).item(), "entropy": (acc["entropy"] / d).item(),
+                   "gradient_norm": (acc["gnorm"] / d).item()}
+        if last_logits is not None:
+            valid = last_cats >= 0
+            if bool(valid.any()):
+                metrics.update(compute_value_metrics(last_logits[valid], last_cats[valid]))
+        return metrics
+
+    def _notify_weights_changed(self) -> None:
+        eng = getattr(self.model, "_hip_engine", None)
+        if eng is not None:
+            eng.notify_weights_updated()
+
+    # ---- fused HIP path -----------------------------------------------------------------
+    def _fused_path_available(self, device, value_adapter) -> bool:
+        if device.type != "cuda" or not isinstance(self.model, SEResNetModel):
+            return False
+        if value_adapter is not None and type(value_adapter) is not MultiHeadValueAdapter:
+            return False
+        opt = self.optimizer
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            return False
+        return all(q.dtype == torch.float32 and q.is_contiguous() for q in g["params"])
+
+    def _adam_tables(self, device):
+        """(Re)build the multi-tensor descriptor table for the fused clip+Adam kernel.  State tensors are the
+        optimiser's own (``exp_avg`` / ``exp_avg_sq``), so checkpoints stay interchangeable with torch.optim.Adam."""
+        st = self._hip_state
+        opt = self.optimizer
+        params = [q for q in opt.param_groups[0]["params"] if q.requires_grad]
+        chunk = _lib.query("ka_adam_chunk")
+        step0 = 0.0
+        for q in params:
+            s = opt.state[q]
+            if "exp_avg" not in s:
+                s["step"] = torch.tensor(0.0, dtype=torch.float32)
+                s["exp_avg"] = torch.zeros_like(q, memory_format=torch.preserve_format)
+                s["exp_avg_sq"] = torch.zeros_like(q, memory_format=torch.preserve_format)
+            step0 = max(step0, float(s["step"]))
+        key = (id(opt), tuple(q.data_ptr() for q in params))
+        if st.get("key") != key:
+            blk_t, blk_o = [], []
+            for i, q in enumerate(params):
+                for off in range(0, q.numel(), chunk):
+                    blk_t.append(i); blk_o.append(off)
+            st["key"] = key
+            st["params"] = params
+            st["blk_t"] = torch.tensor(blk_t, dtype=torch.int32, device=device)
+            st["blk_o"] = torch.tensor(blk_o, dtype=torch.int64, device=device)
+            st["nblocks"] = len(blk_t)
+            st["partial"] = torch.empty(len(blk_t), dtype=torch.float64, device=device)
+            st["tab_host"] = [torch.empty(len(params) * 5, dtype=torch.int64).pin_memory() for _ in range(2)]
+            st["tab_dev"] = [torch.empty(len(params) * 5, dtype=torch.int64, device=device) for _ in range(2)]
+            st["tab_evt"] = [None, None]
+            st["flip"] = 0
+            st["ctl"] = torch.zeros(4, device=device)
+        st["step_dev"] = torch.tensor([step0], device=device)
+        return st
+
+    def _upload_table(self, st, device):
+        """pointer table for this step's (freshly allocated) gradient tensors; double-buffered pinned upload,
+        so the host never blocks on the stream."""
+        i = st["flip"]
+        st["flip"] ^= 1
+        if st["tab_evt"][i] is not None:
+            st["tab_evt"][i].synchronize()
+        host = st["tab_host"][i]
+        opt = self.optimizer
+        rows = []
+        for q in st["params"]:
+            s = opt.state[q]
+            g = q.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                raise _lib.KeiseiHipError("fused optimiser step needs a contiguous fp32 gradient for every parameter")
+            rows += [q.data_ptr(), g.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), q.numel()]
+        host.copy_(torch.tensor(rows, dtype=torch.int64))
+        st["tab_dev"][i].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        st["tab_evt"][i] = ev
+        return st["tab_dev"][i]
+
+    def _fused_begin(self, dataset: dict, device, value_adapter) -> dict:
+        """Device-side state of one fused update: epoch dataset tensors (already on `device`), loss weights,
+        Adam tables, GradScaler mirror, metric accumulators."""
+        p = self.params
+        st = self._adam_tables(device)
+        scaler_t = None
+        if self.scaler.is_enabled():
+            if self.scaler._scale is None:
+                self.scaler._lazy_init_scale_growth_tracker(device)
+            scaler_t = torch.stack([self.scaler._scale.float().reshape(()),
+                                    self.scaler._growth_tracker.float().reshape(())])
+        return {
+            "data": dataset, "st": st, "scaler_t": scaler_t,
+            "gscale": scaler_t[0:1] if scaler_t is not None else None,
+            "lam_v": value_adapter.lambda_value if value_adapter is not None else p.lambda_value,
+            "lam_s": value_adapter.lambda_score if value_adapter is not None else p.lambda_score,
+            "combined": int(value_adapter is not None),
+            "acc": torch.zeros(5, device=device),          # policy, value, score, entropy, grad-norm sums
+            "flags": torch.zeros(2, dtype=torch.int32, device=device),
+            "out_m": torch.zeros(16, device=device), "n_updates": 0,
+        }
+
+    def _fused_step(self, fs: dict, idx: torch.Tensor, device) -> None:
+        """One PPO minibatch: fused gather+forward, loss+gradient kernel, hand-written backward, clip+Adam.
+        Pure launches -- nothing here waits for the GPU."""
+        p = self.params
+        call, sp = _lib.call, _lib.stream_ptr(device)
+        d, st = fs["data"], fs["st"]
+        group = self.optimizer.param_groups[0]
+        beta1, beta2 = group["betas"]
+        B, A = idx.shape[0], d["masks"].shape[1]
+        out = self.forward_model(d["obs"], gather_idx=idx)
+        logits = out.policy_logits.reshape(B, A)
+        dlogits = torch.empty_like(logits)
+        new_lp = torch.empty(B, device=device); rowloss = torch.empty(B, device=device); rowent = torch.empty(B, device=device)
+        dv = torch.empty(B, 3, device=device); ds = torch.empty(B, 1, device=device)
+        call("ka_policy_loss", logits, d["masks"], d["actions"], d["old_lp"], d["adv"], idx, dlogits, new_lp, rowloss,
+             rowent, fs["flags"], fs["gscale"], float(p.clip_epsilon), float(p.lambda_policy) / B,
+             float(self.current_entropy_coeff) / B, B, A, sp)
+        call("ka_value_loss", out.value_logits, out.score_lead, d["cats"], d["score_t"], idx, rowloss, rowent, dv, ds,
+             fs["out_m"], fs["acc"], fs["gscale"], float(p.lambda_policy), float(fs["lam_v"]), float(fs["lam_s"]),
+             float(self.current_entropy_coeff), fs["combined"], B, sp)
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.autograd.backward([out.policy_logits, out.value_logits, out.score_lead],
+                                [dlogits.view_as(out.policy_logits), dv, ds])
+        tab = self._upload_table(st, device)
+        call("ka_clip_adam_step", tab, st["blk_t"], st["blk_o"], st["nblocks"], st["partial"], st["ctl"],
+             st["step_dev"], fs["scaler_t"], fs["flags"], fs["acc"][4:5], float(p.grad_clip), float(group["lr"]),
+             float(beta1), float(beta2), float(group["eps"]), sp)
+        self._notify_weights_changed()
+        fs["n_updates"] += 1
+
+    def _fused_end(self, fs: dict) -> dict[str, float]:
+        """The single host synchronisation of an update: metrics, optimiser step counters, scaler, guards."""
+        st, scaler_t = fs["st"], fs["scaler_t"]
+        host = torch.cat([fs["acc"], fs["out_m"][:9], st["step_dev"], fs["flags"].float()]).cpu().tolist()
+        sums, last, step_now, fl = host[:5], host[5:14], host[14], host[15:17]
+        for q in st["params"]:
+            self.optimizer.state[q]["step"].fill_(step_now)
+        if scaler_t is not None:
+            self.scaler._scale.copy_(scaler_t[0]); self.scaler._growth_tracker.copy_(scaler_t[1].to(torch.int32))
+        if fl[0]:
+            raise RuntimeError("NaN in raw policy logits from model forward pass")
+        if fl[1]:
+            raise RuntimeError("Batch contains samples with zero legal actions in update(). "
+                               "Check that terminal-state masks are not stored in the buffer.")
+        d = max(fs["n_updates"], 1)
+        metrics = {"policy_loss": sums[0] / d, "value_loss": sums[1] / d, "score_loss": sums[2] / d,
+                   "entropy": sums[3] / d, "gradient_norm": sums[4] / d}
+        if last[5] > 0:      # valid W/D/L labels in the last minibatch
+            metrics.update({"value_accuracy": last[6], "frac_predicted_win": last[7], "frac_predicted_draw": last[8],
+                            "frac_predicted_loss": max(0.0, 1.0 - last[7] - last[8])})
+        return metrics
+
+    def _update_fused(self, data, advantages, total, batch, device, value_adapter, heartbeat_fn):
+        p = self.params
+        side = torch.cuda.Stream(device)
+        with torch.cuda.stream(side):
+            obs = data["observations"].pin_memory().to(device, non_blocking=True)
+            masks = data["legal_masks"].pin_memory().to(device, non_blocking=True)
+        move = lambda t: t.to(device, non_blocking=True)  # noqa: E731
+        dataset = {"obs": obs, "masks": masks, "actions": move(data["actions"]), "old_lp": move(data["log_probs"].float()),
+                   "adv": move(advantages.float()), "cats": move(data["value_categories"]),
+                   "score_t": move(data["score_targets"].float())}
+        torch.cuda.current_stream(device).wait_stream(side)
+        fs = self._fused_begin(dataset, device, value_adapter)
+        for _ in range(p.epochs_per_batch):
+            perm = torch.randperm(total, device=device)
+            for lo in range(0, total, batch):
+                start, end, stream = self._event_pair(device)
+                self._fused_step(fs, perm[lo:lo + batch], device)
+                end.record(stream)
+                self._timing_events["update_forward_backward_ms"].append((start, end))
+                if heartbeat_fn is not None:
+                    heartbeat_fn()
+        return self._fused_end(fs)

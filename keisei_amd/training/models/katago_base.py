@@ -42,11 +42,14 @@ class KataGoBaseModel(abc.ABC, nn.Module):
             )
         self._amp_enabled, self._amp_dtype, self._amp_device_type = enabled, dtype, device_type
 
-    def forward(self, obs: torch.Tensor) -> KataGoOutput:
+    def forward(self, obs: torch.Tensor, gather_idx: torch.Tensor | None = None) -> KataGoOutput:
+        """``gather_idx`` (extension, optional): evaluate ``obs[gather_idx]`` with the row gather fused
+        into the first kernel -- used by the PPO minibatch loop on a device-resident epoch dataset."""
+        extra = () if gather_idx is None else (gather_idx,)
         if self._amp_enabled:
             with torch.amp.autocast(device_type=self._amp_device_type, dtype=self._amp_dtype):
-                return self._forward_impl(obs)
-        return self._forward_impl(obs)
+                return self._forward_impl(obs, *extra)
+        return self._forward_impl(obs, *extra)
 
     @abc.abstractmethod
     def _forward_impl(self, obs: torch.Tensor) -> KataGoOutput: ...

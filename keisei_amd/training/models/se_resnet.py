@@ -97,23 +97,17 @@ class SEResNetModel(KataGoBaseModel):
         if obs.ndim != 4 or obs.shape[1] != c or obs.shape[2] != 9 or obs.shape[3] != 9:
             raise ValueError(f"Expected obs shape (batch, {c}, 9, 9), got {tuple(obs.shape)}")
 
-    def _forward_impl(self, obs: torch.Tensor) -> KataGoOutput:
+    def _forward_impl(self, obs: torch.Tensor, gather_idx: torch.Tensor | None = None) -> KataGoOutput:
         self._check_obs(obs)
         if obs.is_cuda:
             from keisei_amd.hip.seresnet import run_model
-            policy, value, score = run_model(self, obs)
+            policy, value, score = run_model(self, obs, gather_idx)
             return KataGoOutput(policy_logits=policy, value_logits=value, score_lead=score)
+        if gather_idx is not None:
+            obs = obs[gather_idx]
         x = self.blocks(F.relu(self.input_bn(self.input_conv(obs))))
         policy = self.policy_conv2(F.relu(self.policy_bn1(self.policy_conv1(x)))).permute(0, 2, 3, 1)
         pooled = _global_pool(x)
         value = self.value_fc2(F.relu(self.value_fc1(pooled)))
         score = self.score_fc2(F.relu(self.score_fc1(pooled)))
-        return KataGoOutput(policy_logits=policy, value_logits=value, score_lead=score)
-
-    def forward_gathered(self, dataset_obs: torch.Tensor, idx: torch.Tensor) -> KataGoOutput:
-        """forward(dataset_obs[idx]) with the row gather fused into the input-layout kernel (GPU only)."""
-        if not dataset_obs.is_cuda:
-            return self.forward(dataset_obs[idx])
-        from keisei_amd.hip.seresnet import run_model
-        policy, value, score = run_model(self, dataset_obs, idx)
         return KataGoOutput(policy_logits=policy, value_logits=value, score_lead=score)

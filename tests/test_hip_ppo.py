@@ -1,0 +1,117 @@
+"""GPU: the fused KataGoPPOAlgorithm.update() (GAE kernel, fused gather/forward/loss/backward/clip/Adam, no
+host sync in the loop) against the reference's own update() result (golden g5, recorded randperm)."""
+import math
+
+import pytest
+import torch
+
+from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams, KataGoRolloutBuffer
+from keisei_amd.training.model_registry import build_model
+from keisei_amd.training.value_adapter import MultiHeadValueAdapter
+from oracle import keisei_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+MP = dict(num_blocks=1, channels=32, se_reduction=8, global_pool_channels=16, policy_channels=8,
+          value_fc_size=32, score_fc_size=16, obs_channels=50)
+
+
+def make(golden, use_amp=False):
+    g = golden("g5_update")
+    m = build_model("se_resnet", MP)
+    m.load_state_dict(g.sub("sd0."))
+    m.to(DEV)
+    pp = KataGoPPOParams(learning_rate=1e-3, epochs_per_batch=2, batch_size=8, lambda_score=0.1,
+                         score_blend_alpha=0.1, use_amp=use_amp)
+    algo = KataGoPPOAlgorithm(pp, m)
+    T, N = 4, 4
+    buf = KataGoRolloutBuffer(N, (50, 9, 9), 11259)
+    d = g.sub("buf.")
+    for t in range(T):
+        sl = slice(t * N, (t + 1) * N)
+        buf.add(d["observations"][sl], d["actions"][sl], d["log_probs"][sl], d["values"][sl], d["rewards"][sl], d["dones"][sl],
+                d["terminated"][sl], d["legal_masks"][sl], d["value_categories"][sl], d["score_targets"][sl],
+                next_value_override=d["next_value_override"][sl])
+    return g, m, algo, buf
+
+
+def replay_perms(monkeypatch, g):
+    it = iter(list(g["perms"]))
+    monkeypatch.setattr(torch, "randperm", lambda n, *a, device=None, **k: next(it).to(device or "cpu"))
+
+
+def test_fused_update_matches_reference(golden, monkeypatch):
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    assert algo._fused_path_available(torch.device(DEV), MultiHeadValueAdapter())
+    beats = []
+    met = algo.update(buf, g["next_values"].to(DEV), value_adapter=MultiHeadValueAdapter(1.5, 0.1, 0.1),
+                      heartbeat_fn=lambda: beats.append(1))
+    assert len(beats) == 4 and buf.size == 0 and m.training
+    for k in ("policy_loss", "value_loss", "score_loss", "entropy", "gradient_norm", "value_accuracy",
+              "frac_predicted_win", "frac_predicted_draw", "frac_predicted_loss"):
+        ref = float(g.np("metric." + k))
+        assert abs(met[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, met[k], ref)
+    ref_sd = g.sub("sd1.")
+    got = m.state_dict()
+    # Adam divides by sqrt(v): an element whose gradient is numerically ~0 moves by +-lr on rounding noise alone,
+    # so post-step weights are compared as "all but 0.2 % within 3e-5, none further than 5 % of one update (4 lr)".
+    for k, v in ref_sd.items():
+        if v.dtype.is_floating_point:
+            diff = (got[k].cpu() - v).abs()
+            assert float(diff.max()) <= 0.05 * 4e-3, (k, float(diff.max()))
+            assert float((diff > 3e-5).float().mean()) <= 2e-3, k
+        else:
+            assert int(got[k]) == int(v), k
+    st = algo.optimizer.state_dict()["state"]
+    assert float(st[0]["step"]) == float(g.np("opt.step"))
+    ref_m = g["opt.exp_avg.0"]      # 4-step trajectory: later gradients inherit the (Adam-amplified) weight noise
+    assert float((st[0]["exp_avg"].cpu() - ref_m).abs().max()) <= 0.02 * float(ref_m.abs().max())
+    algo.flush_timings()
+    assert len(algo.timings["update_forward_backward_ms"]) == 4 and len(algo.timings["gae_ms"]) == 1
+
+
+def test_fused_update_inline_value_loss_and_bf16(golden, monkeypatch):
+    """No adapter -> value/score reported separately; bf16 AMP (GradScaler active on the GPU) runs and learns."""
+    g, m, algo, buf = make(golden, use_amp=True)
+    replay_perms(monkeypatch, g)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    met = algo.update(buf, g["next_values"].to(DEV))
+    assert met["score_loss"] > 0 and all(math.isfinite(v) for v in met.values())
+    assert abs(met["entropy"] - float(g.np("metric.entropy"))) < 0.05
+    changed = [k for k, v in m.state_dict().items() if v.dtype.is_floating_point and not torch.equal(v, before[k])]
+    assert len(changed) > 30
+    assert algo.scaler.is_enabled() and float(algo.scaler.get_scale()) == 65536.0
+
+
+def test_guards_raise_and_veto_the_step(golden, monkeypatch):
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    buf._storage["legal_masks"][3] = False        # one sample without any legal action
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" not in k and "num_batches" not in k}
+    with pytest.raises(RuntimeError, match="zero legal actions"):
+        algo.update(buf, g["next_values"].to(DEV), value_adapter=MultiHeadValueAdapter(1.5, 0.1, 0.1))
+    # every optimiser step from the offending minibatch on was vetoed on the device
+    g2, m2, algo2, buf2 = make(golden)
+    it = iter(list(g["perms"]))
+    monkeypatch.setattr(torch, "randperm", lambda n, *a, device=None, **k: next(it).to(device or "cpu"))
+    with torch.no_grad():
+        m2.policy_conv2.bias[0] = float("nan")
+    with pytest.raises(RuntimeError, match="NaN in raw policy logits"):
+        algo2.update(buf2, g["next_values"].to(DEV))
+    assert float(algo2._hip_state["step_dev"]) == 0.0
+
+
+def test_select_actions_on_gpu(golden):
+    g, m, algo, _ = make(golden)
+    obs = g.sub("buf.")["observations"][:6].to(DEV)
+    legal = g.sub("buf.")["legal_masks"][:6].to(DEV)
+    actions, logp, values = algo.select_actions(obs, legal, MultiHeadValueAdapter(1.5, 0.1, 0.1))
+    assert actions.shape == (6,) and bool(legal[torch.arange(6), actions].all())
+    assert m.training                                   # train mode restored
+    ref_p, ref_v, ref_s = orc.seresnet_forward(dict(g.sub("sd0.")), obs.cpu(), 1, train=False)
+    ref_lp, _ = orc.masked_policy_terms(ref_p.reshape(6, -1), legal.cpu(), actions.cpu())
+    assert torch.allclose(logp.cpu(), ref_lp, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(values.cpu(), orc.scalar_value_blended(ref_v, ref_s, 0.1), rtol=1e-4, atol=1e-5)
+    with pytest.raises(RuntimeError, match="zero legal actions"):
+        algo.select_actions(obs, torch.zeros_like(legal))

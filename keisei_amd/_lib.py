@@ -23,8 +23,9 @@ _SIGS = {
     "ka_conv3x3_wgrad": "ppppp i pp iiii i i p",
     "ka_obs_to_nhwc": "ppp iii i p",
     "ka_nhwc_to_nchw": "pp ii i p",
-    "ka_bn_reduce": "p i p i i p p",
-    "ka_pair_reduce": "pp ii p p",
+    "ka_bn_reduce": "p i p i i pp p",
+    "ka_reduce_workspace_doubles": "i",
+    "ka_pair_reduce": "pp ii pp p",
     "ka_bn_coeffs": "p d p pppp p ff pppp i p",
     "ka_bn_eval_coeffs": "pppp f pp i p",
     "ka_bn_bwd_coeffs": "pp d p ppp ppp i i p",
@@ -35,7 +36,7 @@ _SIGS = {
     "ka_tail_bwd_reduce": "pppppp p ii i p",
     "ka_tail_bwd_dz": "ppppppp ppp ii i p",
     "ka_relu_bn_bwd_reduce": "pppppp ppp ii i p",
-    "ka_block_dx": "ppppp p ii i p",
+    "ka_block_dx": "pppppp p ii i p",
     "ka_gemm": "pppp iii iii ii iii i i i p",
     "ka_reduce_slabs": "pp i q i p",
     "ka_colsum": "pppp ii i p",

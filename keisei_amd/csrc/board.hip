@@ -100,44 +100,38 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
 }
 
 // ---------------------------------------------------------------- BatchNorm statistics
-// sums[0:C] = sum_b bsum[b,c]; sums[C:2C] = sum_r sqpart[r,c]   (fp64, fixed order)
-__global__ void bn_reduce_kernel(const float* __restrict__ bsum, int B, const float* __restrict__ sqpart, int R,
-                                 int C, double* __restrict__ sums) {
+// Two-stage, fixed-order fp64 column sums of two fp32 planes (A: rowsA x C, B: rowsB x C):
+//   stage 1: grid (C/64, kRedSlices) -> part[slice][2C];  stage 2: sums[0:C] = sum_s part[s][c], sums[C:2C] likewise.
+// Used for BN forward statistics (per-board sums + per-workgroup squares from the conv epilogue) and for the BN
+// backward sums (two per-board planes).
+constexpr int kRedSlices = 64;
+__global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __restrict__ A, int rowsA,
+                                                             const float* __restrict__ Bp, int rowsB, int C,
+                                                             double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;           // 4 row-slices
+    const int sub = threadIdx.x >> 6;
+    const int slice = blockIdx.y * 4 + sub, nsl = kRedSlices * 4;
     __shared__ double red[2][4][64];
     double s = 0.0, ss = 0.0;
     if (c < C) {
-        for (int b = part; b < B; b += 4) s += (double)bsum[(size_t)b * C + c];
-        for (int r = part; r < R; r += 4) ss += (double)sqpart[(size_t)r * C + c];
+        for (int r = slice; r < rowsA; r += nsl) s += (double)A[(size_t)r * C + c];
+        for (int r = slice; r < rowsB; r += nsl) ss += (double)Bp[(size_t)r * C + c];
     }
-    red[0][part][threadIdx.x & 63] = s;
-    red[1][part][threadIdx.x & 63] = ss;
+    red[0][sub][threadIdx.x & 63] = s;
+    red[1][sub][threadIdx.x & 63] = ss;
     __syncthreads();
-    if (part == 0 && c < C) {
+    if (sub == 0 && c < C) {
         const int l = threadIdx.x;
-        sums[c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-        sums[C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+        part[(size_t)blockIdx.y * 2 * C + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        part[(size_t)blockIdx.y * 2 * C + C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
     }
 }
-
-// two (B,C) partial planes -> sums[2C] fp64 (BN backward)
-__global__ void pair_reduce_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int B, int C,
-                                   double* __restrict__ sums) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
-    __shared__ double red[2][4][64];
-    double s = 0.0, ss = 0.0;
-    if (c < C)
-        for (int b = part; b < B; b += 4) { s += (double)p1[(size_t)b * C + c]; ss += (double)p2[(size_t)b * C + c]; }
-    red[0][part][threadIdx.x & 63] = s;
-    red[1][part][threadIdx.x & 63] = ss;
-    __syncthreads();
-    if (part == 0 && c < C) {
-        const int l = threadIdx.x;
-        sums[c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-        sums[C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
-    }
+__global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* __restrict__ sums, int C2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C2) return;
+    double s = 0.0;
+    for (int k = 0; k < kRedSlices; ++k) s += part[(size_t)k * C2 + c];
+    sums[c] = s;
 }
 
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
@@ -219,7 +213,63 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
 }
 
 // ---------------------------------------------------------------- forward tail
-// out = relu( (scale*y+shift) [* sigmoid(se[b,c]) + se[b,C+c]] [+ res] ),  pool = [mean|max|std] of out
+// One-pass running statistics of a thread's squares for 2 adjacent channels: Welford mean/M2 (exactly 0 for
+// a constant plane), running max and the number of squares that attain it (autograd's amax backward shares the
+// gradient between ties).  Slices are merged in a fixed order with Chan's formula.
+struct PoolStat {
+    f32x2 mean = {0.f, 0.f}, m2 = {0.f, 0.f}, mx = {-INFINITY, -INFINITY}, cnt = {0.f, 0.f};
+    float n = 0.f;
+    __device__ __forceinline__ void push(const f32x2 x) {
+        n += 1.f;
+        const float inv = 1.f / n;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float d = x[e] - mean[e];
+            mean[e] += d * inv;
+            m2[e] += d * (x[e] - mean[e]);
+            if (x[e] > mx[e]) { mx[e] = x[e]; cnt[e] = 1.f; }
+            else if (x[e] == mx[e]) cnt[e] += 1.f;
+        }
+    }
+};
+// red: [slice][cpw][9]; the slice-0 thread of every channel pair merges and writes pool[b] = [mean|max|std|ties] (4C)
+__device__ __forceinline__ void pool_merge_store(float* red, const BoardMap& m, const PoolStat& st, float* pool_row,
+                                                 int c, int C) {
+    __syncthreads();
+    if (m.active) {
+        float* r = red + (m.slice * m.cpw + m.cp) * 9;
+        r[0] = st.n; r[1] = st.mean[0]; r[2] = st.mean[1]; r[3] = st.m2[0]; r[4] = st.m2[1];
+        r[5] = st.mx[0]; r[6] = st.mx[1]; r[7] = st.cnt[0]; r[8] = st.cnt[1];
+    }
+    __syncthreads();
+    if (m.active && m.slice == 0 && pool_row) {
+        float n = 0.f, mean[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f}, mx[2] = {-INFINITY, -INFINITY}, cnt[2] = {0.f, 0.f};
+        for (int s = 0; s < m.ph; ++s) {
+            const float* r = red + (s * m.cpw + m.cp) * 9;
+            const float nb = r[0];
+            if (nb == 0.f) continue;
+            const float nn = n + nb;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float d = r[1 + e] - mean[e];
+                mean[e] += d * (nb / nn);
+                m2[e] += r[3 + e] + d * d * (n * nb / nn);
+                if (r[5 + e] > mx[e]) { mx[e] = r[5 + e]; cnt[e] = r[7 + e]; }
+                else if (r[5 + e] == mx[e]) cnt[e] += r[7 + e];
+            }
+            n = nn;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            pool_row[c + e] = mean[e];
+            pool_row[C + c + e] = mx[e];
+            pool_row[2 * C + c + e] = sqrtf(fmaxf(m2[e], 0.f) / KA_BOARD);
+            pool_row[3 * C + c + e] = cnt[e];
+        }
+    }
+}
+
+// out = relu( (scale*y+shift) [* sigmoid(se[b,c]) + se[b,C+c]] [+ res] ),  pool[b] = [mean|max|std|ties] of out (4C)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void block_tail_fwd_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -230,8 +280,7 @@ __global__ __launch_bounds__(kThreads) void block_tail_fwd_kernel(
     const size_t base = (size_t)b * KA_BOARD * C;
     for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
         const int c = (cb + m.cp) * 2;
-        f32x2 v[kMaxPPT];
-        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
+        PoolStat st;
         if (m.active) {
             const f32x2 sc = {scale[c], scale[c + 1]}, sh = {shift[c], shift[c + 1]};
             f32x2 gate = {1.f, 1.f}, bias = {0.f, 0.f};
@@ -239,49 +288,23 @@ __global__ __launch_bounds__(kThreads) void block_tail_fwd_kernel(
                 gate = f32x2{sigmoidf_(se[(size_t)b * 2 * C + c]), sigmoidf_(se[(size_t)b * 2 * C + c + 1])};
                 bias = f32x2{se[(size_t)b * 2 * C + C + c], se[(size_t)b * 2 * C + C + c + 1]};
             }
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    const size_t off = base + (size_t)p * C + c;
-                    f32x2 u = ld2(y + off);
-                    u[0] = (u[0] * sc[0] + sh[0]) * gate[0] + bias[0];
-                    u[1] = (u[1] * sc[1] + sh[1]) * gate[1] + bias[1];
-                    if (res) { const f32x2 rr = ld2(res + off); u[0] += rr[0]; u[1] += rr[1]; }
-                    u[0] = rnd<T>(fmaxf(u[0], 0.f));
-                    u[1] = rnd<T>(fmaxf(u[1], 0.f));
-                    st2(out + off, u);
-                    v[i] = u;
-                    sum[0] += u[0]; sum[1] += u[1];
-                    mx[0] = fmaxf(mx[0], u[0]); mx[1] = fmaxf(mx[1], u[1]);
-                }
+            for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+                const size_t off = base + (size_t)p * C + c;
+                f32x2 u = ld2(y + off);
+                u[0] = (u[0] * sc[0] + sh[0]) * gate[0] + bias[0];
+                u[1] = (u[1] * sc[1] + sh[1]) * gate[1] + bias[1];
+                if (res) { const f32x2 rr = ld2(res + off); u[0] += rr[0]; u[1] += rr[1]; }
+                u[0] = rnd<T>(fmaxf(u[0], 0.f));
+                u[1] = rnd<T>(fmaxf(u[1], 0.f));
+                st2(out + off, u);
+                st.push(u);
             }
         }
-        const f32x2 tot = combine_sum(red, m, sum);
-        const f32x2 mxx = combine_max(red, m, mx);
-        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
-        f32x2 sq = {0.f, 0.f};
-        if (m.active) {
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
-                    sq[0] += d0 * d0; sq[1] += d1 * d1;
-                }
-            }
-        }
-        const f32x2 var = combine_sum(red, m, sq);
-        if (m.active && m.slice == 0 && pool) {
-            float* pr = pool + (size_t)b * 3 * C;
-            pr[c] = mean[0]; pr[c + 1] = mean[1];
-            pr[C + c] = mxx[0]; pr[C + c + 1] = mxx[1];
-            pr[2 * C + c] = sqrtf(var[0] / KA_BOARD); pr[2 * C + c + 1] = sqrtf(var[1] / KA_BOARD);
-        }
+        pool_merge_store(red, m, st, pool ? pool + (size_t)b * 4 * C : nullptr, c, C);
     }
 }
 
-// pool = [mean|max|std] of an arbitrary (B,81,C) tensor (se_resnet.py:93-98)
+// pool[b] = [mean|max|std|ties] of an arbitrary (B,81,C) tensor (se_resnet.py:93-98)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pool, int C) {
     extern __shared__ float red[];
@@ -290,40 +313,10 @@ __global__ __launch_bounds__(kThreads) void pool_fwd_kernel(const T* __restrict_
     const size_t base = (size_t)b * KA_BOARD * C;
     for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
         const int c = (cb + m.cp) * 2;
-        f32x2 v[kMaxPPT];
-        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
-        if (m.active) {
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    v[i] = ld2(x + base + (size_t)p * C + c);
-                    sum[0] += v[i][0]; sum[1] += v[i][1];
-                    mx[0] = fmaxf(mx[0], v[i][0]); mx[1] = fmaxf(mx[1], v[i][1]);
-                }
-            }
-        }
-        const f32x2 tot = combine_sum(red, m, sum);
-        const f32x2 mxx = combine_max(red, m, mx);
-        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
-        f32x2 sq = {0.f, 0.f};
-        if (m.active) {
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
-                    sq[0] += d0 * d0; sq[1] += d1 * d1;
-                }
-            }
-        }
-        const f32x2 var = combine_sum(red, m, sq);
-        if (m.active && m.slice == 0) {
-            float* pr = pool + (size_t)b * 3 * C;
-            pr[c] = mean[0]; pr[c + 1] = mean[1];
-            pr[C + c] = mxx[0]; pr[C + c + 1] = mxx[1];
-            pr[2 * C + c] = sqrtf(var[0] / KA_BOARD); pr[2 * C + c + 1] = sqrtf(var[1] / KA_BOARD);
-        }
+        PoolStat st;
+        if (m.active)
+            for (int p = m.slice; p < KA_BOARD; p += m.ph) st.push(ld2(x + base + (size_t)p * C + c));
+        pool_merge_store(red, m, st, pool + (size_t)b * 4 * C, c, C);
     }
 }
 
@@ -433,71 +426,42 @@ __global__ __launch_bounds__(kThreads) void relu_bn_bwd_reduce_kernel(
 }
 
 // ---------------------------------------------------------------- block input gradient
-// dx = [dxc] + [dout*[out>0]] + pool_bwd(dpool; x)
+// dx = [dxc] + [dout*[out>0]] + pool_bwd(dpool; x), single streaming pass using the statistics the forward tail
+// saved (xpool[b] = [mean|max|std|ties]):
 //   mean: dpool_mean/81 ; max: dpool_max/ties on every square equal to the max ;
 //   std : dpool_std*(x-mean)/(81*std), 0 where std == 0
 template <typename T>
 __global__ __launch_bounds__(kThreads) void block_dx_kernel(
     const T* __restrict__ dxc, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
-    const float* __restrict__ dpool, T* __restrict__ dx, int C) {
-    extern __shared__ float red[];
+    const float* __restrict__ xpool, const float* __restrict__ dpool, T* __restrict__ dx, int C) {
     const BoardMap m(C);
     const int b = blockIdx.x;
     const size_t base = (size_t)b * KA_BOARD * C;
+    if (!m.active) return;
     for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
         const int c = (cb + m.cp) * 2;
-        f32x2 v[kMaxPPT];
-        f32x2 sum = {0.f, 0.f}, mx = {-INFINITY, -INFINITY};
-        if (m.active) {
+        const float* xp = xpool + (size_t)b * 4 * C;
+        const float* dp = dpool + (size_t)b * 3 * C;
+        f32x2 mean, mxx, gm, gx, gs;
 #pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    v[i] = ld2(x + base + (size_t)p * C + c);
-                    sum[0] += v[i][0]; sum[1] += v[i][1];
-                    mx[0] = fmaxf(mx[0], v[i][0]); mx[1] = fmaxf(mx[1], v[i][1]);
-                }
-            }
+        for (int e = 0; e < 2; ++e) {
+            mean[e] = xp[c + e]; mxx[e] = xp[C + c + e];
+            const float sd = xp[2 * C + c + e];
+            gm[e] = dp[c + e] / KA_BOARD;
+            gx[e] = dp[C + c + e] / xp[3 * C + c + e];
+            gs[e] = sd > 0.f ? dp[2 * C + c + e] / (KA_BOARD * sd) : 0.f;
         }
-        const f32x2 tot = combine_sum(red, m, sum);
-        const f32x2 mxx = combine_max(red, m, mx);
-        const f32x2 mean = {tot[0] / KA_BOARD, tot[1] / KA_BOARD};
-        f32x2 sq = {0.f, 0.f}, ties = {0.f, 0.f};
-        if (m.active) {
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    const float d0 = v[i][0] - mean[0], d1 = v[i][1] - mean[1];
-                    sq[0] += d0 * d0; sq[1] += d1 * d1;
-                    ties[0] += (v[i][0] == mxx[0]) ? 1.f : 0.f; ties[1] += (v[i][1] == mxx[1]) ? 1.f : 0.f;
-                }
+        for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+            const size_t off = base + (size_t)p * C + c;
+            const f32x2 v = ld2(x + off);
+            f32x2 g = {gm[0] + gs[0] * (v[0] - mean[0]) + (v[0] == mxx[0] ? gx[0] : 0.f),
+                       gm[1] + gs[1] * (v[1] - mean[1]) + (v[1] == mxx[1] ? gx[1] : 0.f)};
+            if (dxc) { const f32x2 t = ld2(dxc + off); g[0] += t[0]; g[1] += t[1]; }
+            if (dout) {
+                const f32x2 t = ld2(dout + off), o = ld2(out + off);
+                g[0] += o[0] > 0.f ? t[0] : 0.f; g[1] += o[1] > 0.f ? t[1] : 0.f;
             }
-        }
-        const f32x2 var = combine_sum(red, m, sq);
-        const f32x2 nt = combine_sum(red, m, ties);
-        if (m.active) {
-            const float* dp = dpool + (size_t)b * 3 * C;
-            const f32x2 gm = {dp[c] / KA_BOARD, dp[c + 1] / KA_BOARD};
-            const f32x2 gx = {dp[C + c] / nt[0], dp[C + c + 1] / nt[1]};
-            const float sd0 = sqrtf(var[0] / KA_BOARD), sd1 = sqrtf(var[1] / KA_BOARD);
-            const f32x2 gs = {sd0 > 0.f ? dp[2 * C + c] / (KA_BOARD * sd0) : 0.f,
-                              sd1 > 0.f ? dp[2 * C + c + 1] / (KA_BOARD * sd1) : 0.f};
-#pragma unroll
-            for (int i = 0; i < kMaxPPT; ++i) {
-                const int p = m.slice + i * m.ph;
-                if (p < KA_BOARD) {
-                    const size_t off = base + (size_t)p * C + c;
-                    f32x2 g = {gm[0] + gs[0] * (v[i][0] - mean[0]) + (v[i][0] == mxx[0] ? gx[0] : 0.f),
-                               gm[1] + gs[1] * (v[i][1] - mean[1]) + (v[i][1] == mxx[1] ? gx[1] : 0.f)};
-                    if (dxc) { const f32x2 t = ld2(dxc + off); g[0] += t[0]; g[1] += t[1]; }
-                    if (dout) {
-                        const f32x2 t = ld2(dout + off), o = ld2(out + off);
-                        g[0] += o[0] > 0.f ? t[0] : 0.f; g[1] += o[1] > 0.f ? t[1] : 0.f;
-                    }
-                    st2(dx + off, g);
-                }
-            }
+            st2(dx + off, g);
         }
     }
 }
@@ -505,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void block_dx_kernel(
 template <typename T> size_t red_bytes(int C) {
     const int pairs = C >> 1, cpw = pairs < 128 ? pairs : 128;
     int ph = kThreads / cpw; if (ph > KA_BOARD) ph = KA_BOARD;
-    return (size_t)ph * cpw * 2 * sizeof(float);
+    return (size_t)ph * cpw * 9 * sizeof(float);      // PoolStat merge needs 9 floats per (slice, pair)
 }
 
 }  // namespace
@@ -533,18 +497,25 @@ extern "C" int ka_nhwc_to_nchw(const void* in, float* out, int B, int C, int dty
     return ka_check_launch("nhwc_to_nchw");
 }
 
-extern "C" int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R, int C, double* sums, void* stream) {
-    KA_REQUIRE(bsum && sqpart && sums, "bn_reduce: null tensor");
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), bsum, B,
-                       sqpart, R, C, sums);
-    return ka_check_launch("bn_reduce");
+static int colsum2(const float* A, int rowsA, const float* Bp, int rowsB, int C, double* sums, double* part,
+                   hipStream_t st, const char* what) {
+    hipLaunchKernelGGL(colsum2_stage1_kernel, dim3((C + 63) / 64, kRedSlices), dim3(256), 0, st, A, rowsA, Bp, rowsB, C, part);
+    hipLaunchKernelGGL(colsum2_stage2_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, st, part, sums, 2 * C);
+    return ka_check_launch(what);
 }
 
-extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, void* stream) {
-    KA_REQUIRE(p1 && p2 && sums, "pair_reduce: null tensor");
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), p1, p2,
-                       B, C, sums);
-    return ka_check_launch("pair_reduce");
+// part: workspace of ka_reduce_workspace_doubles(C) doubles
+extern "C" int ka_reduce_workspace_doubles(int C) { return kRedSlices * 2 * C; }
+
+extern "C" int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R, int C, double* sums, double* part,
+                            void* stream) {
+    KA_REQUIRE(bsum && sqpart && sums && part, "bn_reduce: null tensor");
+    return colsum2(bsum, B, sqpart, R, C, sums, part, static_cast<hipStream_t>(stream), "bn_reduce");
+}
+
+extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, double* part, void* stream) {
+    KA_REQUIRE(p1 && p2 && sums && part, "pair_reduce: null tensor");
+    return colsum2(p1, B, p2, B, C, sums, part, static_cast<hipStream_t>(stream), "pair_reduce");
 }
 
 extern "C" int ka_bn_coeffs(const double* sums, double count, const double* count_dev, const float* gamma,
@@ -649,12 +620,12 @@ extern "C" int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float*
     return ka_check_launch("relu_bn_bwd_reduce");
 }
 
-extern "C" int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* dpool,
-                           void* dx, int B, int C, int dtype, void* stream) {
-    KA_REQUIRE(x && dpool && dx && ((dout == nullptr) == (out == nullptr)), "block_dx: bad arguments");
+extern "C" int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* xpool,
+                           const float* dpool, void* dx, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(x && xpool && dpool && dx && ((dout == nullptr) == (out == nullptr)), "block_dx: bad arguments");
     KA_BOARD_CHECK("block_dx");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_dx_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
-                                            (const T*)dxc, (const T*)dout, (const T*)out, (const T*)x, dpool, (T*)dx, C));
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_dx_kernel<T>, dim3(B), dim3(kThreads), 0, st, (const T*)dxc,
+                                            (const T*)dout, (const T*)out, (const T*)x, xpool, dpool, (T*)dx, C));
     return ka_check_launch("block_dx");
 }

@@ -25,26 +25,27 @@ __device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
 }
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[16][64 + 4];
-    __shared__ float Bs[16][64 + 4];
+    constexpr int BK = 32;
+    __shared__ __attribute__((aligned(16))) float As[BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
     float acc[4][4] = {};
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // A tile: 64 rows x 16 k
-        for (int i = tid; i < 64 * 16; i += 256) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // A tile: 64 rows x BK k  (index so that consecutive lanes walk the contiguous axis of the operand)
+        for (int i = tid; i < 64 * BK; i += 256) {
             int m, k;
-            if (g.transA) { m = i & 63; k = i >> 6; } else { k = i & 15; m = i >> 4; }
+            if (g.transA) { m = i & 63; k = i >> 6; } else { k = i & (BK - 1); m = i / BK; }
             const int gm = m0 + m, gk = k0 + k;
             float v = 0.f;
             if (gm < g.M && gk < kend)
                 v = ldx(g.A, g.transA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk, g.a_bf16);
             As[k][m] = v;
         }
-        for (int i = tid; i < 64 * 16; i += 256) {
+        for (int i = tid; i < 64 * BK; i += 256) {
             int n, k;
-            if (g.transB) { k = i & 15; n = i >> 4; } else { n = i & 63; k = i >> 6; }
+            if (g.transB) { k = i & (BK - 1); n = i / BK; } else { n = i & 63; k = i >> 6; }
             const int gn = n0 + n, gk = k0 + k;
             float v = 0.f;
             if (gn < g.N && gk < kend)
@@ -53,10 +54,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+        for (int k = 0; k < BK; ++k) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -196,7 +196,7 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
     KA_REQUIRE(nsplit == 1 || (!bias && !relu && !c_bf16 && !accumulate), "gemm: split-K output must be raw fp32 slabs");
     KA_REQUIRE(!(accumulate && c_bf16), "gemm: accumulate needs an fp32 output");
     int len = (K + nsplit - 1) / nsplit;
-    len = (len + 15) / 16 * 16;
+    len = (len + 31) / 32 * 32;
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, a_bf16, b_bf16, c_bf16, relu, len, accumulate};
     dim3 grid((N + 63) / 64, (M + 63) / 64, nsplit);
     KA_REQUIRE(grid.y <= 65535, "gemm: M too large for grid.y (%d rows)", M);

@@ -43,7 +43,7 @@ def run_block(block: nn.Module, x: torch.Tensor) -> torch.Tensor:
     train = block.training
     xin = torch.empty(B, 81, C, dtype=T, device=dev)
     _call("ka_obs_to_nhwc", x.float().contiguous(), None, xin, B, C, C, code, st)
-    pool = torch.empty(B, 3 * C, device=dev)
+    pool = torch.empty(B, 4 * C, device=dev)
     _call("ka_pool_fwd", xin, pool, B, C, code, st)
     rows = _lib.query("ka_conv3x3_sqpart_rows", B)
     y1 = torch.empty_like(xin); bs = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)

@@ -43,6 +43,7 @@ class SEResNetEngine:
         self._packs: Dict[tuple, tuple] = {}
         self._pack_key = None
         self._scratch: Optional[torch.Tensor] = None
+        self._redws: Optional[torch.Tensor] = None
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
 
@@ -62,6 +63,12 @@ class SEResNetEngine:
 
     def notify_weights_updated(self) -> None:
         self.weights_epoch += 1
+
+    def _red_ws(self, C: int, device) -> torch.Tensor:
+        n = _lib.query("ka_reduce_workspace_doubles", C)
+        if self._redws is None or self._redws.numel() < n or self._redws.device != device:
+            self._redws = torch.empty(n, dtype=torch.float64, device=device)
+        return self._redws
 
     def _scratch_f32(self, n: int, device) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < n or self._scratch.device != device:
@@ -111,7 +118,7 @@ class SEResNetEngine:
             _call("ka_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C, st)
             return scale, shift, None, None
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
-        _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, st)
+        _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, self._red_ws(C, device), st)
         if self._sync_group(bn):
             sums[2 * C] = float(count)
             dist.all_reduce(sums)
@@ -133,10 +140,11 @@ class SEResNetEngine:
         _call("ka_gemm", A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, abf, bbf, cbf, relu, acc, ns, st)
 
     def _linear(self, x, lin: nn.Linear, relu: int, st):
-        M, K = x.shape
-        N = lin.weight.shape[0]
+        """y = act(x[:, :K] W^T + b); x may be wider than K (pooled statistics carry a 4th, non-feature plane)."""
+        M, lda = x.shape
+        N, K = lin.weight.shape
         y = torch.empty(M, N, device=x.device)
-        self._gemm(x, lin.weight, y, lin.bias, M, N, K, K, K, N, 0, 1, st, relu=relu)
+        self._gemm(x, lin.weight, y, lin.bias, M, N, K, lda, K, N, 0, 1, st, relu=relu)
         return y
 
     def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0):
@@ -145,16 +153,17 @@ class SEResNetEngine:
         K = lin.weight.shape[1] if lin.weight.ndim == 2 else lin.weight.shape[1]
         dev = dy.device
         ns = max(1, min(64, (M + 511) // 512))
+        ldx = x.shape[1]
         dW = torch.empty(N, K, device=dev)
         if ns == 1:
-            self._gemm(dy, x, dW, None, N, K, M, N, K, K, 1, 0, st, bbf=x_bf16)
+            self._gemm(dy, x, dW, None, N, K, M, N, ldx, K, 1, 0, st, bbf=x_bf16)
         else:
             slab = self._scratch_f32(ns * N * K, dev)
-            self._gemm(dy, x, slab, None, N, K, M, N, K, K, 1, 0, st, bbf=x_bf16, ns=ns)
+            self._gemm(dy, x, slab, None, N, K, M, N, ldx, K, 1, 0, st, bbf=x_bf16, ns=ns)
             _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
         grads[wname] = dW.view_as(lin.weight)
         if bname is not None:
-            nsb = max(1, min(256, (M + 2047) // 2048))
+            nsb = max(1, min(64, (M + 127) // 128))
             db = torch.empty(N, device=dev)
             if nsb == 1:
                 _call("ka_colsum", dy, None, db, None, M, N, 1, st)
@@ -199,7 +208,7 @@ class SEResNetEngine:
               bsum if train else None, sq if train else None, B, cin_pad, C, code, st)
         sc0, sh0, mu0, is0 = self._bn_forward(m.input_bn, bsum, B, sq, rows, C, count, train, dev, st)
         x = new_act(C)
-        pool = torch.empty(B, 3 * C, device=dev)
+        pool = torch.empty(B, 4 * C, device=dev)        # [mean|max|std|ties]
         _call("ka_block_tail_fwd", y0, sc0, sh0, None, None, x, pool, B, C, code, st)
         sv.xin = xin
         sv.stem = (y0, sc0, sh0, mu0, is0)
@@ -224,7 +233,7 @@ class SEResNetEngine:
             se1 = self._linear(sqz, blk.se_fc1, 1, st)
             se = self._linear(se1, blk.se_fc2, 0, st)
             out = new_act(C)
-            pool_out = torch.empty(B, 3 * C, device=dev)
+            pool_out = torch.empty(B, 4 * C, device=dev)
             _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
             if keep:
                 sv.blocks.append((x, pool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out))
@@ -260,7 +269,7 @@ class SEResNetEngine:
     # ------------------------------------------------------------------ backward
     def _bn_backward(self, bn, s1p, s2p, rows, C, count, mu, istd, train, grads, prefix, dev, st):
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-        _call("ka_pair_reduce", s1p, s2p, rows, C, sums, st)
+        _call("ka_pair_reduce", s1p, s2p, rows, C, sums, self._red_ws(C, dev), st)
         gsums, count_t = sums, None
         if train and self._sync_group(bn):
             gsums = sums.clone()
@@ -332,7 +341,7 @@ class SEResNetEngine:
                          ("policy_conv1.weight", m.policy_conv1.weight)):
                 grads[n] = torch.zeros_like(t)
         dout = new_act()
-        _call("ka_block_dx", dxc, None, None, x, dpool, dout, B, C, code, st)
+        _call("ka_block_dx", dxc, None, None, x, pool, dpool, dout, B, C, code, st)
 
         s1p = torch.empty(B, C, device=dev); s2p = torch.empty(B, C, device=dev)
         nsplit = _lib.query("ka_wgrad_splits", B, C, C)
@@ -373,7 +382,7 @@ class SEResNetEngine:
             self._timed("wgrad", "ka_conv3x3_wgrad", dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, code, st)
             grads[pre + "conv1.weight"] = dW1
             dx = dh                                                                           # reuse buffer
-            _call("ka_block_dx", dxc, dout, out, bx, dpool_x, dx, B, C, code, st)
+            _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
             dout = dx
 
         # ---- stem

@@ -185,7 +185,8 @@ def test_bn_stats_and_tail_forward(dtn, C):
     bsum = yq.sum(dim=(2, 3)).to(DEV)
     sq = (yq ** 2).sum(dim=(0, 2, 3))[None].to(DEV)
     sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
-    _lib.call("ka_bn_reduce", bsum, B, sq, 1, C, sums, st())
+    ws = torch.empty(_lib.query("ka_reduce_workspace_doubles", C), dtype=torch.float64, device=DEV)
+    _lib.call("ka_bn_reduce", bsum, B, sq, 1, C, sums, ws, st())
     scale, shift, mean, invstd = (torch.empty(C, device=DEV) for _ in range(4))
     rmd, rvd = rm.to(DEV), rv.to(DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
@@ -200,12 +201,17 @@ def test_bn_stats_and_tail_forward(dtn, C):
     # tail
     ref = torch.relu(z * torch.sigmoid(se[:, :C])[:, :, None, None] + se[:, C:, None, None] + xq)
     out = torch.empty(B, 81, C, dtype=dt, device=DEV)
-    pool = torch.empty(B, 3 * C, device=DEV)
+    pool = torch.empty(B, 4 * C, device=DEV)
     _lib.call("ka_block_tail_fwd", to_nhwc(y, dt), scale, shift, se.to(DEV), to_nhwc(x, dt), out, pool, B, C,
               _lib.dtype_code(dt), st())
     got = from_nhwc(out)
     close(got, ref, dt, k=2)
-    assert torch.allclose(pool.cpu(), orc.global_pool(got), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(pool.cpu()[:, :3 * C], orc.global_pool(got), rtol=1e-5, atol=1e-5)
+    ties = (got == got.amax(dim=(2, 3), keepdim=True)).sum(dim=(2, 3)).float()
+    assert torch.equal(pool.cpu()[:, 3 * C:], ties)
+    pool2 = torch.empty(B, 4 * C, device=DEV)
+    _lib.call("ka_pool_fwd", out, pool2, B, C, _lib.dtype_code(dt), st())
+    assert torch.equal(pool2, pool)
     # eval coefficients
     es, eh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     _lib.call("ka_bn_eval_coeffs", gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, es, eh, C, st())
@@ -245,7 +251,8 @@ def test_block_tail_backward_chain(dtn, C):
     _lib.call("ka_tail_bwd_dz", doutd, outd, yd, se.detach().to(DEV), dsq.to(DEV), mu.to(DEV), invstd.to(DEV), dz, s1, s2,
               B, C, _lib.dtype_code(dt), st())
     sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
-    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
+    ws = torch.empty(_lib.query("ka_reduce_workspace_doubles", C), dtype=torch.float64, device=DEV)
+    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, ws, st())
     dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
     _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), None, gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam,
               dbet, k, C, 1, st())
@@ -274,7 +281,8 @@ def test_relu_bn_backward_and_block_dx(dtn):
     _lib.call("ka_relu_bn_bwd_reduce", to_nhwc(dh, dt), yd, scale, shift, mu.to(DEV), invstd.to(DEV), da, s1, s2, B, C,
               _lib.dtype_code(dt), st())
     sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
-    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, st())
+    ws = torch.empty(_lib.query("ka_reduce_workspace_doubles", C), dtype=torch.float64, device=DEV)
+    _lib.call("ka_pair_reduce", s1, s2, B, C, sums, ws, st())
     dgam, dbet, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
     _lib.call("ka_bn_bwd_coeffs", sums, sums, float(B * 81), None, gamma.detach().to(DEV), mu.to(DEV), invstd.to(DEV), dgam,
               dbet, k, C, 1, st())
@@ -292,11 +300,13 @@ def test_relu_bn_backward_and_block_dx(dtn):
     outv = rnd(torch.randn(B, C, 9, 9, generator=g), dt)
     ref = torch.autograd.grad((orc.global_pool(xr) * dpool).sum(), xr)[0] + dxc + dout * (outv > 0)
     dx = torch.empty(B, 81, C, dtype=dt, device=DEV)
-    _lib.call("ka_block_dx", to_nhwc(dxc, dt), to_nhwc(dout, dt), to_nhwc(outv, dt), to_nhwc(x, dt), dpool.to(DEV), dx, B, C,
-              _lib.dtype_code(dt), st())
+    xpool = torch.empty(B, 4 * C, device=DEV)
+    _lib.call("ka_pool_fwd", to_nhwc(x, dt), xpool, B, C, _lib.dtype_code(dt), st())
+    _lib.call("ka_block_dx", to_nhwc(dxc, dt), to_nhwc(dout, dt), to_nhwc(outv, dt), to_nhwc(x, dt), xpool, dpool.to(DEV), dx,
+              B, C, _lib.dtype_code(dt), st())
     close(from_nhwc(dx), ref, dt, k=2)
     dx2 = torch.empty(B, 81, C, dtype=dt, device=DEV)
-    _lib.call("ka_block_dx", None, None, None, to_nhwc(x, dt), dpool.to(DEV), dx2, B, C, _lib.dtype_code(dt), st())
+    _lib.call("ka_block_dx", None, None, None, to_nhwc(x, dt), xpool, dpool.to(DEV), dx2, B, C, _lib.dtype_code(dt), st())
     close(from_nhwc(dx2), ref - dxc - dout * (outv > 0), dt, k=2)
 
 

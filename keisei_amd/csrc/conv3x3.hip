@@ -114,15 +114,37 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + e]; sh[e] = a.in_shift[c0 + e]; }
             }
-            for (int pos = spos0; pos < kRows; pos += sstep) {
-                const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
-                vec16 v;
-                if (bb < a.B) {
-                    v = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) +
-                                                        ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ);
-                    if (has_aff || a.relu || a.in_bias) {
+            float gbv[kNB][P16];                 // per-board bias of this thread's channel piece, fetched once
+            if (a.in_bias) {
+#pragma unroll
+                for (int b = 0; b < kNB; ++b)
+#pragma unroll
+                    for (int e = 0; e < P16; ++e)
+                        gbv[b][e] = (b0 + b < a.B) ? a.in_bias[(size_t)(b0 + b) * a.Cin + c0 + e] : 0.f;
+            }
+            // loads are issued in batches of kUnr before any is consumed: the staging phase is otherwise a
+            // chain of dependent HBM round trips (one per 16-byte piece per thread)
+            constexpr int kUnr = 8;
+            for (int pos0 = spos0; pos0 < kRows; pos0 += sstep * kUnr) {
+                vec16 v[kUnr];
+#pragma unroll
+                for (int u = 0; u < kUnr; ++u) {
+                    const int pos = pos0 + u * sstep;
+                    const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
+                    if (pos < kRows && bb < a.B)
+                        v[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) +
+                                                               ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ);
+                    else
+                        v[u] = vec16{};
+                }
+#pragma unroll
+                for (int u = 0; u < kUnr; ++u) {
+                    const int pos = pos0 + u * sstep;
+                    if (pos >= kRows) continue;
+                    const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
+                    if (bb < a.B && (has_aff || a.relu || a.in_bias)) {
                         float f[P16];
-                        E::unpack(v, f);
+                        E::unpack(v[u], f);
                         if (has_aff) {
 #pragma unroll
                             for (int e = 0; e < P16; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
@@ -132,53 +154,66 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                             for (int e = 0; e < P16; ++e) f[e] = fmaxf(f[e], 0.f);
                         }
                         if (a.in_bias) {
-                            const float* gb = a.in_bias + (size_t)bb * a.Cin + c0;
 #pragma unroll
-                            for (int e = 0; e < P16; ++e) f[e] += gb[e];
+                            for (int e = 0; e < P16; ++e) f[e] += (b == 0 ? gbv[0][e] : gbv[1][e]);
                         }
-                        v = E::pack(f);
+                        v[u] = E::pack(f);
                     }
-                } else {
-                    float z[P16];
-#pragma unroll
-                    for (int e = 0; e < P16; ++e) z[e] = 0.f;
-                    v = E::pack(z);
+                    *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v[u];
                 }
-                *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v;
             }
         }
         __syncthreads();
 
-        // ---- MFMA phase: 9 taps x KS k-steps; weights prefetched one step ahead
+        // ---- MFMA phase: 9 taps x KS k-steps.  Weight fragments stream from L2 straight into registers,
+        // ping-ponged between two named register sets (no conditional loads, no register copies) so the
+        // compiler's vmcnt bookkeeping leaves the next step's loads in flight under this step's MFMAs.
         if (wave_active) {
             const int nsteps = 9 * KS;
-            vec16 bcur[NTW], bnext[NTW];
-            {
-                const char* wp = wbase + (size_t)(kc * KS) * ks_stride;
+            const char* wchunk = wbase + (size_t)(kc * KS) * ks_stride;
+            // tile indices beyond NT (partial last wave) are clamped: they load valid bytes that are never stored
+            int jofs[NTW];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    bcur[j] = (nt0 + j < NT) ? *reinterpret_cast<const vec16*>(wp + j * 1024) : vec16{};
-            }
-            int tap = 0, ks = 0;
-            for (int it = 0; it < nsteps; ++it) {
-                int ntap = tap, nks = ks + 1;
-                if (nks == KS) { nks = 0; ntap = tap + 1; }
-                if (it + 1 < nsteps) {
-                    const char* wp = wbase + (size_t)ntap * tap_stride + (size_t)(kc * KS + nks) * ks_stride;
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-                        bnext[j] = (nt0 + j < NT) ? *reinterpret_cast<const vec16*>(wp + j * 1024) : vec16{};
-                }
-                const int toff = ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * stride + ks * 64;
+            for (int j = 0; j < NTW; ++j) jofs[j] = (min(nt0 + j, NT - 1) - nt0) * 1024;
+            auto wptr = [&](int step) {
+                step = min(step, nsteps - 1);
+                const int tap = step / KS, ks = step - tap * KS;
+                return wchunk + (size_t)tap * tap_stride + (size_t)ks * ks_stride;
+            };
+            auto lds_off = [&](int step) {
+                const int tap = step / KS, ks = step - tap * KS;
+                return ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * stride + ks * 64;
+            };
+            auto compute = [&](const vec16 (&bw)[NTW], int toff) {
 #pragma unroll
                 for (int mt = 0; mt < kMT; ++mt) {
                     const vec16 av = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av, bcur[j], acc[mt][j]);
+                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av, bw[j], acc[mt][j]);
                 }
+            };
+            vec16 b0[NTW], b1[NTW];
+            {
+                const char* wp = wptr(0);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bcur[j] = bnext[j];
-                tap = ntap; ks = nks;
+                for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
+            }
+            for (int it = 0; it < nsteps; it += 2) {
+                {
+                    const char* wp = wptr(it + 1);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) b1[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA block it overlaps
+                compute(b0, lds_off(it));
+                {
+                    const char* wp = wptr(it + 2);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nsteps) compute(b1, lds_off(it + 1));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

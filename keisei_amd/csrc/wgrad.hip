@@ -85,12 +85,17 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + xj * P16 + e]; sh[e] = a.in_shift[c0 + xj * P16 + e]; }
     }
     vec16 ry[NY], rx[NX];
+    float rb[P16];                          // per-board bias of this thread's X channel piece
     auto zero16 = [&] { float z[P16];
 #pragma unroll
         for (int e = 0; e < P16; ++e) z[e] = 0.f;
         return E::pack(z); };
 
     auto load_board = [&](int b) {
+        if (a.in_bias && xcol_ok) {
+#pragma unroll
+            for (int e = 0; e < P16; ++e) rb[e] = a.in_bias[(size_t)b * a.Cin + c0 + xj * P16 + e];
+        }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int row = (tid + i * 512) / PY;
@@ -131,9 +136,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
                         for (int e = 0; e < P16; ++e) f[e] = fmaxf(f[e], 0.f);
                     }
                     if (a.in_bias) {
-                        const float* gb = a.in_bias + (size_t)b * a.Cin + c0 + xj * P16;
 #pragma unroll
-                        for (int e = 0; e < P16; ++e) f[e] += gb[e];
+                        for (int e = 0; e < P16; ++e) f[e] += rb[e];
                     }
                     v = E::pack(f);
                 }

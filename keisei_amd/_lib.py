@@ -18,6 +18,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libkeisei_amd.so"
 _SIGS = {
     "ka_conv3x3_fwd": "pppppp i pp iii i p",
     "ka_conv3x3_sqpart_rows": "i",
+    "ka_debug_conv_stamps": "p",
     "ka_pack_conv3x3": "pp iiii i i p",
     "ka_wgrad_splits": "iii",
     "ka_conv3x3_wgrad": "ppppp i pp iiii i i p",

@@ -21,6 +21,7 @@
 //
 // Reference semantics replaced: nn.Conv2d(C, C, 3, padding=1, bias=False) at
 // keisei/training/models/se_resnet.py:50,52,110 and its autograd backward.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -39,7 +40,10 @@ struct ConvArgs {
     float* bsum;             // [B,Cout] or null
     float* sqpart;           // [gridDim.x, Cout] or null
     int B, Cin, Cout, KC, relu;
+    unsigned long long* stamps;   // diagnostic only: [workgroup][4] s_memtime at phase boundaries (null in production)
 };
+
+unsigned long long* g_stamps = nullptr;
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -58,14 +62,20 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int NTW>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+// WM = waves along M: 1 -> 4 waves, each owns all 11 row tiles of its output-channel slice;
+//                     2 -> 8 waves (2 per SIMD), each owns 6 row tiles: half the accumulators per wave, and a
+//                          second wave per SIMD whose MFMAs fill the first one's LDS/L2 stalls
+template <typename T, int NTW, int WM>
+__global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
+    constexpr int kThreads = 256 * WM;
+    constexpr int kMTW = (kMT + WM - 1) / WM;        // row tiles per wave
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int ESZ = E::kSize, P16 = E::kPer16, CPK = 4 * P16;   // channels per k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mhalf = tid >> 8;
+    const int mt_base = mhalf * kMTW;
     const int r = lane & 15, q = lane >> 4;
     const int b0 = blockIdx.x * kNB;
     const int NT = a.Cout >> 4;
@@ -75,33 +85,35 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     const int KSG = a.Cin / CPK;                 // k-steps over all input channels
     const int KS = a.KC / CPK;                   // k-steps per LDS chunk
 
-    f32x4 acc[kMT][NTW];
+    f32x4 acc[kMTW][NTW];
 #pragma unroll
-    for (int mt = 0; mt < kMT; ++mt)
+    for (int mt = 0; mt < kMTW; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int rowoff[kMT];
+    int rowoff[kMTW];
 #pragma unroll
-    for (int mt = 0; mt < kMT; ++mt) {
-        int m = mt * 16 + r;
+    for (int mt = 0; mt < kMTW; ++mt) {
+        int m = (mt_base + mt) * 16 + r;
         if (m >= kRows) m = 0;                   // dummy rows read valid LDS; never stored
         rowoff[mt] = ((m / KA_BOARD) * KA_PADBOARD + pad_index(m % KA_BOARD)) * stride + q * 16;
     }
 
     // zero the halo once (staging only ever writes interior squares)
-    for (int i = tid; i < kNB * KA_PADBOARD * cpr; i += 256) {
+    for (int i = tid; i < kNB * KA_PADBOARD * cpr; i += kThreads) {
         int idx = i / cpr, j = i - idx * cpr;
         int pp = idx % KA_PADBOARD, yy = pp / 11, xx = pp - yy * 11;
         if (yy == 0 || yy == 10 || xx == 0 || xx == 10)
             *reinterpret_cast<uint4*>(smem + idx * stride + j * 16) = uint4{0, 0, 0, 0};
     }
 
-    const int sj = tid % cpr, spos0 = tid / cpr, sstep = 256 / cpr;   // staging role of this thread
+    const int sj = tid % cpr, spos0 = tid / cpr, sstep = kThreads / cpr;   // staging role of this thread
     const char* wbase = static_cast<const char*>(a.wpack) + ((size_t)nt0 * 64 + lane) * 16;
     const size_t tap_stride = (size_t)KSG * NT * 1024, ks_stride = (size_t)NT * 1024;
     const bool wave_active = nt0 < NT;
 
+    const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 0] = __builtin_amdgcn_s_memtime();
     const int nchunks = a.Cin / a.KC;
     for (int kc = 0; kc < nchunks; ++kc) {
         if (kc > 0) __syncthreads();
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             }
             // loads are issued in batches of kUnr before any is consumed: the staging phase is otherwise a
             // chain of dependent HBM round trips (one per 16-byte piece per thread)
-            constexpr int kUnr = 8;
+            constexpr int kUnr = (WM == 2) ? 6 : 11;
             for (int pos0 = spos0; pos0 < kRows; pos0 += sstep * kUnr) {
                 vec16 v[kUnr];
 #pragma unroll
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
+        if (a.stamps && tid == 0 && kc == 0) a.stamps[wg_lin * 4 + 1] = __builtin_amdgcn_s_memtime();
 
         // ---- MFMA phase: 9 taps x KS k-steps.  Weight fragments stream from L2 straight into registers,
         // ping-ponged between two named register sets (no conditional loads, no register copies) so the
@@ -184,92 +197,139 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
                 const int tap = step / KS, ks = step - tap * KS;
                 return ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * stride + ks * 64;
             };
-            auto compute = [&](const vec16 (&bw)[NTW], int toff) {
+            // A fragments are double-buffered in registers across steps: while step s multiplies from `ac`, the
+            // 11 LDS reads of step s+1 land in `an` (a whole step of MFMA time to hide LDS latency/conflicts).
+            auto load_a = [&](vec16 (&av)[kMTW], int toff) {
 #pragma unroll
-                for (int mt = 0; mt < kMT; ++mt) {
-                    const vec16 av = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
+                for (int mt = 0; mt < kMTW; ++mt) av[mt] = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
+            };
+            auto compute = [&](const vec16 (&bw)[NTW], const vec16 (&av)[kMTW], vec16 (&anext)[kMTW], int toff_next) {
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av, bw[j], acc[mt][j]);
+                for (int mt = 0; mt < kMTW; ++mt) {
+#ifndef KA_DIAG_NO_A
+                    anext[mt] = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff_next);
+#else
+                    anext[mt] = av[mt];
+#endif
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av[mt], bw[j], acc[mt][j]);
+                }
+                // pin the issue order: one LDS read ahead of every group of MFMAs (the scheduler otherwise
+                // sinks all 11 reads behind the MFMA block and the next step starts by waiting for them)
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NTW * (sizeof(T) == 2 ? 1 : 4), 0);
                 }
             };
-            vec16 b0[NTW], b1[NTW];
+            vec16 b0[NTW], b1[NTW], a0[kMTW], a1[kMTW];
             {
                 const char* wp = wptr(0);
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
             }
+            load_a(a0, lds_off(0));
             for (int it = 0; it < nsteps; it += 2) {
+#ifndef KA_DIAG_NO_W
                 {
                     const char* wp = wptr(it + 1);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) b1[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
                 }
+#else
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) b1[j] = b0[j];
+#endif
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA block it overlaps
-                compute(b0, lds_off(it));
+                compute(b0, a0, a1, lds_off(min(it + 1, nsteps - 1)));
+#ifndef KA_DIAG_NO_W
                 {
                     const char* wp = wptr(it + 2);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + 1 < nsteps) compute(b1, lds_off(it + 1));
+                if (it + 1 < nsteps) compute(b1, a1, a0, lds_off(min(it + 2, nsteps - 1)));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: statistics from the fp32 accumulators, then the output tile
     const bool v0 = b0 < a.B, v1 = b0 + 1 < a.B;
-    if (wave_active && (a.bsum || a.sqpart)) {
+    constexpr int BN = 4 * NTW * 16;                 // output channels of this workgroup
+    constexpr int ostride = BN * 2 + 16;
+    float* stat_lds = reinterpret_cast<float*>(smem + (sizeof(T) == 2 ? kMT * 16 * ostride : 0));   // [WM][BN][3]
+    const bool want_stats = a.bsum || a.sqpart;
+    float s0[NTW], s1[NTW], ss[NTW];
+    if (wave_active && want_stats) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            float s0 = 0.f, s1 = 0.f, ss = 0.f;
+            s0[j] = s1[j] = ss[j] = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt)
+            for (int mt = 0; mt < kMTW; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int m = mt * 16 + q * 4 + i;
+                    const int m = (mt_base + mt) * 16 + q * 4 + i;
                     const float v = acc[mt][j][i];
-                    if (m < KA_BOARD) { s0 += v; ss += v * v; }
-                    else if (m < kRows) { s1 += v; ss += v * v; }
+                    if (m < KA_BOARD) { s0[j] += v; ss[j] += v * v; }
+                    else if (m < kRows) { s1[j] += v; ss[j] += v * v; }
                 }
-            s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
-            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-            const int n = (nt0 + j) * 16 + r;
-            if (q == 0 && nt0 + j < NT) {
-                if (a.bsum) {
-                    if (v0) a.bsum[(size_t)b0 * a.Cout + n] = s0;
-                    if (v1) a.bsum[(size_t)(b0 + 1) * a.Cout + n] = s1;
-                }
-                if (a.sqpart) a.sqpart[(size_t)blockIdx.x * a.Cout + n] = ss;
-            }
+            s0[j] += __shfl_xor(s0[j], 16); s0[j] += __shfl_xor(s0[j], 32);
+            s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
+            ss[j] += __shfl_xor(ss[j], 16); ss[j] += __shfl_xor(ss[j], 32);
         }
     }
-
+    if (WM > 1 || sizeof(T) == 2) __syncthreads();   // all waves done reading the input tile
+    if (WM > 1 && wave_active && want_stats && mhalf == 1 && q == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            float* d = stat_lds + ((wave * NTW + j) * 16 + r) * 3;
+            d[0] = s0[j]; d[1] = s1[j]; d[2] = ss[j];
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         // transpose through LDS so HBM sees whole 16-byte pieces of contiguous rows
-        const int BN = 4 * NTW * 16;                 // output channels of this workgroup
-        const int ostride = BN * 2 + 16;
-        __syncthreads();                             // all waves done reading the input tile
         if (wave_active) {
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt)
+            for (int mt = 0; mt < kMTW; ++mt)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int m = mt * 16 + q * 4 + i;
-                        *reinterpret_cast<uint16_t*>(smem + m * ostride + ((wave * NTW + j) * 16 + r) * 2) =
-                            f2bf(acc[mt][j][i]);
+                        const int m = (mt_base + mt) * 16 + q * 4 + i;
+                        if (m < kMT * 16)
+                            *reinterpret_cast<uint16_t*>(smem + m * ostride + ((wave * NTW + j) * 16 + r) * 2) =
+                                f2bf(acc[mt][j][i]);
                     }
         }
-        __syncthreads();
+    }
+    if (WM > 1 || sizeof(T) == 2) __syncthreads();
+    if (wave_active && want_stats && mhalf == 0 && q == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (nt0 + j >= NT) continue;
+            float t0 = s0[j], t1 = s1[j], t2 = ss[j];
+            if (WM > 1) {
+                const float* d = stat_lds + ((wave * NTW + j) * 16 + r) * 3;
+                t0 += d[0]; t1 += d[1]; t2 += d[2];
+            }
+            const int n = (nt0 + j) * 16 + r;
+            if (a.bsum) {
+                if (v0) a.bsum[(size_t)b0 * a.Cout + n] = t0;
+                if (v1) a.bsum[(size_t)(b0 + 1) * a.Cout + n] = t1;
+            }
+            if (a.sqpart) a.sqpart[(size_t)blockIdx.x * a.Cout + n] = t2;
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
         const int n_wg0 = blockIdx.y * BN;
         const int ncols = min(BN, a.Cout - n_wg0);   // multiple of 16
         const int ppr = ncols / 8;                   // 16-byte pieces per row
         const int rows = v1 ? kRows : (v0 ? KA_BOARD : 0);
-        for (int i = tid; i < rows * ppr; i += 256) {
+        for (int i = tid; i < rows * ppr; i += kThreads) {
             const int m = i / ppr, pc = i - m * ppr;
             const uint4 v = *reinterpret_cast<const uint4*>(smem + m * ostride + pc * 16);
             *reinterpret_cast<uint4*>(static_cast<char*>(a.out) +
@@ -279,19 +339,20 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         if (wave_active) {
             float* out = static_cast<float*>(a.out);
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt)
+            for (int mt = 0; mt < kMTW; ++mt)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     if (nt0 + j >= NT) continue;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int m = mt * 16 + q * 4 + i;
+                        const int m = (mt_base + mt) * 16 + q * 4 + i;
                         const bool ok = (m < KA_BOARD) ? v0 : (m < kRows && v1);
                         if (ok) out[(size_t)(b0 * KA_BOARD + m) * a.Cout + (nt0 + j) * 16 + r] = acc[mt][j][i];
                     }
                 }
         }
     }
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 // Pack (Co,Ci,3,3) fp32 weights into MFMA B-fragment order.
@@ -324,17 +385,17 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, void* __restric
     }
 }
 
-template <typename T, int NTW>
+template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
     const size_t lds_in = (size_t)kNB * KA_PADBOARD * (a.KC * E::kSize + 16);
-    const size_t lds_out = (E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0;
+    const size_t lds_out = ((E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0) + (size_t)WM * BN * 3 * sizeof(float);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             ka_set_error("conv3x3: hipFuncSetAttribute failed");
             return KA_ERR_HIP;
@@ -342,7 +403,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid((a.B + kNB - 1) / kNB, (a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv3x3_kernel<T, NTW>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM>), grid, dim3(256 * WM), lds, st, a);
     return ka_check_launch("conv3x3");
 }
 
@@ -358,11 +419,23 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         KA_REQUIRE(kc % 2 == 0 && (kc / 2) % CPK == 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
         kc /= 2;
     }
-    KA_REQUIRE(256 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile 256 threads", kc);
+    if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;   // measured: 2 chunks of 128 beat one of 256
+    int ntw = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
+    int wm = 2;
+    // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave, waves along M
+    if (const char* e = getenv("KA_CONV_KC")) { const int v = atoi(e); if (v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v; }
+    if (const char* e = getenv("KA_CONV_NTW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ntw = v; }
+    if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }
+    KA_REQUIRE((256 * wm) % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
-    if (a.Cout > 128) return launch_conv<T, 4>(a, st);
-    if (a.Cout > 64) return launch_conv<T, 2>(a, st);
-    return launch_conv<T, 1>(a, st);
+    if (wm == 2) {
+        if (ntw == 4) return launch_conv<T, 4, 2>(a, st);
+        if (ntw == 2) return launch_conv<T, 2, 2>(a, st);
+        return launch_conv<T, 1, 2>(a, st);
+    }
+    if (ntw == 4) return launch_conv<T, 4, 1>(a, st);
+    if (ntw == 2) return launch_conv<T, 2, 1>(a, st);
+    return launch_conv<T, 1, 1>(a, st);
 }
 
 }  // namespace
@@ -371,7 +444,7 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
 extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale,
                               const float* in_shift, const float* in_bias, int relu, float* bsum, float* sqpart,
                               int B, int Cin, int Cout, int dtype, void* stream) {
-    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu};
+    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu, g_stamps};
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -380,6 +453,10 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
     ka_set_error("conv3x3: unknown dtype %d", dtype);
     return KA_ERR_ARG;
 }
+
+// diagnostic: stamps != null makes every conv3x3 workgroup record 4 s_memtime values (100 MHz ticks are NOT used:
+// s_memtime counts shader clocks); pass null to switch off
+extern "C" int ka_debug_conv_stamps(unsigned long long* stamps) { g_stamps = stamps; return KA_OK; }
 
 extern "C" int ka_conv3x3_sqpart_rows(int B) { return (B + kNB - 1) / kNB; }
 

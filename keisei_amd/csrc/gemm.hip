@@ -83,6 +83,107 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+
+// Fast path: fp32 operands, 16-byte aligned rows (lda/ldb % 4 == 0, K-range % 4 == 0).  float4 global loads
+// along the operand's contiguous axis, next K-tile prefetched into registers while the current one is multiplied.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
+    constexpr int BK = 32;
+    __shared__ __attribute__((aligned(16))) float As[BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 4];
+    const float* __restrict__ A = static_cast<const float*>(g.A);
+    const float* __restrict__ Bp = static_cast<const float*>(g.B);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
+    // per-thread load roles: two float4 per operand per tile
+    //   contiguous-K operand (A not transposed / B transposed): row = t>>3 (+32), k4 = t&7
+    //   contiguous-M/N operand: k = t>>4 (+16), col4 = t&15
+    f32x4 ra[2], rb[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!TA) {
+                const int m = min(m0 + (tid >> 3) + 32 * h, g.M - 1), k = k0 + (tid & 7) * 4;
+                ra[h] = (k < kend) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * g.lda + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int k = k0 + (tid >> 4) + 16 * h, m = m0 + (tid & 15) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < kend) {
+                    if (m + 3 < g.M) v = *reinterpret_cast<const f32x4*>(A + (size_t)k * g.lda + m);
+                    else for (int e = 0; e < 4; ++e) if (m + e < g.M) v[e] = A[(size_t)k * g.lda + m + e];
+                }
+                ra[h] = v;
+            }
+            if (TB) {
+                const int n = min(n0 + (tid >> 3) + 32 * h, g.N - 1), k = k0 + (tid & 7) * 4;
+                rb[h] = (k < kend) ? *reinterpret_cast<const f32x4*>(Bp + (size_t)n * g.ldb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int k = k0 + (tid >> 4) + 16 * h, n = n0 + (tid & 15) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < kend) {
+                    if (n + 3 < g.N) v = *reinterpret_cast<const f32x4*>(Bp + (size_t)k * g.ldb + n);
+                    else for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] = Bp[(size_t)k * g.ldb + n + e];
+                }
+                rb[h] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!TA) {
+                const int m = (tid >> 3) + 32 * h, k = (tid & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[k + e][m] = ra[h][e];
+            } else {
+                *reinterpret_cast<f32x4*>(&As[(tid >> 4) + 16 * h][(tid & 15) * 4]) = ra[h];
+            }
+            if (TB) {
+                const int n = (tid >> 3) + 32 * h, k = (tid & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[k + e][n] = rb[h][e];
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[(tid >> 4) + 16 * h][(tid & 15) * 4]) = rb[h];
+            }
+        }
+    };
+    float acc[4][4] = {};
+    load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (k0 + BK < kend) load_tile(k0 + BK);          // in flight during the FMA block
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+    }
+    const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
+    float* C = static_cast<float*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= g.N) continue;
+            float v = acc[i][j];
+            if (g.bias) v += g.bias[n];
+            if (g.relu) v = fmaxf(v, 0.f);
+            const size_t o = slab + (size_t)m * g.ldc + n;
+            C[o] = g.accumulate ? C[o] + v : v;
+        }
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s*n + i]
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, size_t n,
                                     int accumulate) {
@@ -200,7 +301,18 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, a_bf16, b_bf16, c_bf16, relu, len, accumulate};
     dim3 grid((N + 63) / 64, (M + 63) / 64, nsplit);
     KA_REQUIRE(grid.y <= 65535, "gemm: M too large for grid.y (%d rows)", M);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool aligned = !a_bf16 && !b_bf16 && !c_bf16 && lda % 4 == 0 && ldb % 4 == 0 && len % 4 == 0 &&
+                         (transA || K % 4 == 0) && (!transB || K % 4 == 0) &&
+                         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    if (aligned) {
+        if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false>), grid, dim3(256), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
+    }
     return ka_check_launch("gemm");
 }
 

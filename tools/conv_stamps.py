@@ -1,0 +1,28 @@
+"""Diagnostic: where does a conv3x3 workgroup spend its cycles? (s_memtime stamps at phase boundaries)"""
+import os, sys
+sys.path.insert(0, '.')
+import torch
+from keisei_amd import _lib
+B, C = 4096, 256
+dt = torch.bfloat16; code = 1; dev = 'cuda'
+x = torch.randn(B, 81, C, device=dev).to(dt)
+w = torch.randn(C, C, 3, 3, device=dev) / 48
+wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=dev)
+_lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, code, _lib.stream_ptr())
+out = torch.empty_like(x); rows = _lib.query("ka_conv3x3_sqpart_rows", B)
+bsum = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)
+for kc, ntw in [(256, 4), (128, 2), (64, 2)]:
+    os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw)
+    nwg = rows * (4 // ntw if ntw < 4 else 1)
+    for _ in range(3):
+        _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())
+    stamps = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+    _lib.call("ka_debug_conv_stamps", stamps)
+    _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    _lib.call("ka_debug_conv_stamps", None)
+    s = stamps.cpu().view(nwg, 4).double()
+    d = s[:, 1:] - s[:, :-1]
+    tot = s[:, 3] - s[:, 0]
+    span = float(s[:, 3].max() - s[:, 0].min())
+    print(f"KC={kc} NTW={ntw}: per-WG cycles  stage(first chunk) {d[:,0].mean():.0f}  main(incl later chunks) {d[:,1].mean():.0f}  epilogue {d[:,2].mean():.0f}  total {tot.mean():.0f}; kernel span {span:.0f} cycles; nWG {nwg}")

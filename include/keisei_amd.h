@@ -1,0 +1,168 @@
+/* keisei_amd.h -- C ABI of libkeisei_amd.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * Keisei KataGo-PPO training hot path.
+ *
+ * The reference (tachyon-beep/keisei) has NO native boundary on this path: every operator below is a
+ * PyTorch op call site inside keisei/training/{models/se_resnet,katago_ppo,gae,value_adapter}.py
+ * (SURVEY.md 2.3 K1-K23).  This header therefore defines the boundary a binding would add *underneath*
+ * the reference's Python API; each entry point cites the reference statement(s) it replaces
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *     the library never allocates, frees or retains memory -- workspaces are caller-provided;
+ *   - every launch goes to `stream` (a hipStream_t passed as void*); nothing synchronises;
+ *   - return value: 0 = launched, <0 = error (KA_ERR_*), message via ka_last_error() (thread-local);
+ *   - `dtype`: activation storage type of (B,81,C) NHWC tensors, KA_DTYPE_F32 (exact-fp32 MFMA / FMA,
+ *     parity mode) or KA_DTYPE_BF16 (bf16 MFMA with fp32 accumulate, throughput mode);
+ *   - "board" = one 9x9 position = 81 squares; activations are NHWC: element (b, p, c) at
+ *     ((b*81 + p)*C + c); per-channel / per-board vectors are fp32.
+ */
+#ifndef KEISEI_AMD_H
+#define KEISEI_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KA_OK 0
+#define KA_ERR_ARG (-1)
+#define KA_ERR_HIP (-2)
+#define KA_ERR_UNSUPPORTED (-3)
+#define KA_DTYPE_F32 0
+#define KA_DTYPE_BF16 1
+
+/* ---- library identity / errors ------------------------------------------------------------ */
+int ka_version(void);
+const char* ka_target_arch(void);          /* "gfx950" */
+const char* ka_last_error(void);           /* message of the last failing call on this thread */
+
+/* ---- 3x3 convolution (implicit GEMM on MFMA) ----------------------------------------------------
+ * Replaces nn.Conv2d(Cin, Cout, 3, padding=1, bias=False): input_conv / conv1 / conv2
+ * (models/se_resnet.py:50,52,110,140) and, with a mode-1 weight pack, autograd's data gradient.
+ * Optional fused input transform x' = relu?(x*in_scale[c] + in_shift[c]) + in_bias[b,c] reproduces
+ * `F.relu(self.bn1(...)) + g.unsqueeze(-1).unsqueeze(-1)` (se_resnet.py:71,78) on the fly.
+ * Epilogue outputs (optional): bsum[b,n] = sum over the 81 squares of the fp32 result (SE squeeze,
+ * se_resnet.py:83, and the BatchNorm mean), sqpart[r,n] = per-workgroup sum of squares
+ * (r < ka_conv3x3_sqpart_rows(B)).  Requires Cin % 32 == 0 (bf16) / 16 (f32), Cout % 16 == 0. */
+int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale, const float* in_shift,
+                   const float* in_bias, int relu, float* bsum, float* sqpart, int B, int Cin, int Cout, int dtype,
+                   void* stream);
+int ka_conv3x3_sqpart_rows(int B);
+/* (Co,Ci,3,3) fp32 torch-layout weights -> MFMA B-fragment order (a derived cache; the stored parameter keeps
+ * the reference's shape).  mode 0: forward, Nout = Co, Kin = Ci rounded up (zero channels); mode 1: data
+ * gradient (in/out swapped, taps flipped), Nout = Ci, Kin = Co.  dst bytes = 9*(Kin/cpk)*(Nout/16)*1024. */
+int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int Nout, int Kin, int mode, int dtype, void* stream);
+/* Weight gradient dW[n,c,ky,kx] = sum_{b,p} dY[b,p,n] * X'[b,p+tap,c] (autograd conv2d weight backward);
+ * X' uses the same fused input transform as the forward.  slab: ka_wgrad_splits(B,Cin,Cout)*9*Cout*Cin floats. */
+int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift, const float* in_bias,
+                     int relu, float* slab, float* dw, int B, int Cin, int Cin_real, int Cout, int accumulate, int dtype,
+                     void* stream);
+int ka_wgrad_splits(int B, int Cin, int Cout);
+int ka_debug_conv_stamps(unsigned long long* stamps);   /* diagnostics only (tools/conv_stamps.py); null = off */
+
+/* ---- layout at the model boundary ----------------------------------------------------------------
+ * obs (S,Cobs,9,9) fp32 NCHW -> (B,81,Cpad) NHWC; row b is obs[idx[b]] when idx != NULL, which fuses the
+ * minibatch gather `gpu_obs[idx]` (katago_ppo.py:835) into the first kernel. */
+int ka_obs_to_nhwc(const float* obs, const long long* idx, void* out, int B, int Cobs, int Cpad, int dtype, void* stream);
+int ka_nhwc_to_nchw(const void* in, float* out, int B, int C, int dtype, void* stream);
+
+/* ---- BatchNorm2d, training and eval (se_resnet.py:51,53,111,121; torch defaults eps 1e-5, momentum 0.1) --
+ * ka_bn_reduce: sums[0:C] = sum_b bsum[b,c], sums[C:2C] = sum_r sqpart[r,c] in fp64, fixed order
+ *   (part: workspace of ka_reduce_workspace_doubles(C) doubles).  Between reduce and coeffs a caller may
+ *   all-reduce `sums` across ranks (SyncBatchNorm, katago_loop.py:495-496) and pass the global element count
+ *   through count_dev (device double) instead of `count`.
+ * ka_bn_coeffs: scale = gamma*invstd, shift = beta - mean*scale; updates running_mean / running_var (unbiased)
+ *   / num_batches_tracked exactly like nn.BatchNorm2d when the pointers are non-NULL. */
+int ka_reduce_workspace_doubles(int C);
+int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R, int C, double* sums, double* part, void* stream);
+int ka_bn_coeffs(const double* sums, double count, const double* count_dev, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                 float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+int ka_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float* scale, float* shift, int C, void* stream);
+/* backward: sums = [sum dz | sum dz*yhat]; dgamma/dbeta from the LOCAL sums, dy = k[0:C]*dz + k[C:2C] + k[2C:3C]*y
+ * from the (all-reduced) global sums; train = 0 gives the eval-mode derivative. */
+int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, double* part, void* stream);
+int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const double* count_dev,
+                     const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k,
+                     int C, int train, void* stream);
+int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, void* dy, int B, int C, int dtype, void* stream);
+int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C, void* stream);
+
+/* ---- GlobalPoolBiasBlock tail and global pooling (se_resnet.py:74-77,83-98) ----------------------------
+ * out = relu((scale*y+shift) * sigmoid(se[b,c]) + se[b,C+c] + res); pool[b] = [mean | max | std(correction=0) |
+ * number of squares attaining the max] of `out` (4C floats; the 4th plane serves amax's tie-splitting backward).
+ * se == NULL and res == NULL give relu(bn(y)) (stem, se_resnet.py:140). */
+int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se, const void* res, void* out,
+                      float* pool, int B, int C, int dtype, void* stream);
+int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, void* stream);
+/* backward of the tail: dse = [sigmoid'(a)*sum_p du*z | sum_p du] with du = dout*[out>0]; then
+ * dz = du*sigmoid(a) + dsq/81 plus the per-board BatchNorm partial sums s1p = sum dz, s2p = sum dz*yhat. */
+int ka_tail_bwd_reduce(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
+                       const float* se, float* dse, int B, int C, int dtype, void* stream);
+int ka_tail_bwd_dz(const void* dout, const void* out, const void* y, const float* se, const float* dsq, const float* mean,
+                   const float* invstd, void* dz, float* s1p, float* s2p, int B, int C, int dtype, void* stream);
+/* da = dh*[scale*y+shift > 0] (ReLU after BatchNorm) + the same partial sums */
+int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, void* da, float* s1p, float* s2p, int B, int C, int dtype, void* stream);
+/* dx = [dxc] + [dout*[out>0]] + backward of [mean|max|std] pooling of x (ties of amax share the gradient, std
+ * gradient is 0 where sigma == 0), using xpool = ka_block_tail_fwd's pool of x; dpool is (B,3C). */
+int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* xpool, const float* dpool,
+                void* dx, int B, int C, int dtype, void* stream);
+
+/* ---- small dense layers: nn.Linear / 1x1 nn.Conv2d forward and backward (se_resnet.py:57-61,65-66,120-130) --
+ * C[M,N] (+)= act(opA(A)[M,K] * opB(B)[K,N] + bias); opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k], likewise opB.
+ * *_bf16 flags mark bf16 operands/outputs; nsplit > 1 writes raw fp32 partial slabs (reduce with ka_reduce_slabs). */
+int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
+            int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int accumulate, int nsplit, void* stream);
+int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream);
+int ka_colsum(const float* A, const float* Bm, float* part, float* part2, int M, int N, int nsplit, void* stream);
+int ka_relu_mask(float* g, const float* h, long long n, void* stream);
+/* policy-head BatchNorm over fp32 rows (M = B*81, N = policy_channels; se_resnet.py:121,144) */
+int ka_rows_affine_relu(const float* in, const float* scale, const float* shift, float* out, long long M, int N, void* stream);
+int ka_rows_sq_sums(const float* A, float* part, float* part2, int M, int N, int nsplit, void* stream);
+int ka_rows_bn_sums(const float* da, const float* in, const float* mean, const float* invstd, float* part, float* part2,
+                    int M, int N, int nsplit, void* stream);
+int ka_rows_bn_bwd(float* dr, const float* in, const float* p0, const float* p1, long long M, int N, int mode, void* stream);
+
+/* ---- fused KataGo-PPO minibatch loss (katago_ppo.py:857-924, :33-57; value_adapter.py:98-126) -----------
+ * ka_policy_loss: masked log-softmax over A = 11259 actions, log-prob gather, clipped surrogate, entropy over
+ *   legal actions -- per-sample terms AND dL/dlogits in one pass over the logits.  Per-sample inputs (legal,
+ *   actions, old_lp, adv) are rows of the epoch dataset addressed through idx (NULL = identity).
+ *   w_policy = lambda_policy/B, w_entropy = entropy_coeff/B; gscale = optional device loss scale (GradScaler).
+ *   flags[0] |= NaN in raw logits, flags[1] |= a sample without legal action (the reference's two guards).
+ * ka_value_loss: W/D/L cross-entropy (ignore_index -1, all-ignored -> 0), score MSE, their gradients, the mean
+ *   reductions of the per-sample policy terms, and the value metrics of compute_value_metrics (katago_ppo.py:60-78).
+ *   out[9] = {policy_loss, value_ce, score_mse, entropy, total, n_valid, value_accuracy, frac_win, frac_draw};
+ *   acc[4] += {policy, value (combined lambda-weighted when combined_value_metric), score, entropy}. */
+int ka_policy_loss(const float* logits, const void* legal, const long long* actions, const float* old_lp, const float* adv,
+                   const long long* idx, float* dlogits, float* new_lp, float* rowloss, float* rowent, int* flags,
+                   const float* gscale, float clip_eps, float w_policy, float w_entropy, int B, int A, void* stream);
+int ka_value_loss(const float* vlogits, const float* score, const long long* cats, const float* targets,
+                  const long long* idx, const float* rowloss, const float* rowent, float* dvlogits, float* dscore,
+                  float* out, float* acc, const float* gscale, float lambda_policy, float lambda_value, float lambda_score,
+                  float entropy_coeff, int combined_value_metric, int B, void* stream);
+/* P(W) - P(L), optionally blended with clamp(score,-1,1) (katago_ppo.py:533-541, value_adapter.py:76-96) */
+int ka_scalar_value(const float* vlogits, const float* score, float alpha, float* out, int B, void* stream);
+
+/* ---- GradScaler.unscale_ + clip_grad_norm_ + torch.optim.Adam.step + GradScaler.update (katago_ppo.py:926-933) --
+ * tab: nt records {float* p, const float* g, float* m, float* v, long long n}; blk_tensor / blk_off map each of the
+ * nblocks chunks (ka_adam_chunk() elements) to (record, element offset).  ctl[0] = unscaled global grad norm,
+ * ctl[2] = 1 when the step was vetoed (inf/NaN gradients or a guard flag); step_state[0] = applied steps;
+ * scaler = {scale, growth_tracker} or NULL. */
+int ka_adam_chunk(void);
+int ka_clip_adam_step(const void* tab, const int* blk_tensor, const long long* blk_off, int nblocks, double* partial,
+                      float* ctl, float* step_state, float* scaler, const int* guard_flags, float* acc_gnorm,
+                      float max_norm, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* ---- Generalised Advantage Estimation (gae.py:8-296) and advantage normalisation (katago_ppo.py:797-798) --
+ * (T,N) grids, one launch; override: NaN = default bootstrap; lengths (N) selects the padded variants;
+ * f64 != 0: rewards/values/next_value/override/adv are double.  Bit-identical to compute_gae_gpu's op order. */
+int ka_gae(const void* rewards, const void* values, const float* term, const void* next_value, const void* override_,
+           const long long* lengths, void* adv, int T, int N, double gamma, double lam, int f64, void* stream);
+int ka_normalize_advantages(const float* x, float* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEISEI_AMD_H */

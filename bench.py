@@ -72,29 +72,41 @@ def synth_dataset(total, seed, device):
 
 
 def cpu_baseline(shape, seconds_budget=25.0):
-    """Times the oracle's PPO minibatch step (fp32 CPU PyTorch restatement of the reference) on this host."""
+    """Times the oracle's PPO minibatch step (fp32 CPU PyTorch restatement of the reference) on this host.
+    Bounded: threads = the CPUs this process may use (<= 16, the box's share per GPU), minibatch sized from a
+    probe step so that warm-up + timed steps stay within ~seconds_budget."""
     from oracle import keisei_oracle as orc
 
     nb, C, Rr, G, P, V, S = shape
     ns = orc.NetShape(nb, C, Rr, G, P, V, S)
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
     sd = orc.synth_state_dict(ns)
-    Bc = 32 if C >= 256 and nb >= 20 else 256
-    mb = orc.synth_minibatch(Bc, seed=1234)
     w = orc.LossWeights(1.0, 1.5, 0.1, 0.01, 0.2)
+    t0 = time.perf_counter()
+    orc.ppo_minibatch_step(sd, nb, orc.synth_minibatch(4, seed=1), w, None)          # probe (also warms the allocator)
+    probe = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline probe: minibatch 4 took {probe:.1f} s on {threads} threads", file=sys.stderr, flush=True)
+    Bc = 4
+    while Bc < 256 and probe * (2 * Bc / 4) * 3 < seconds_budget:                 # ~linear in the minibatch
+        Bc *= 2
+    mb = orc.synth_minibatch(Bc, seed=1234)
     state = None
-    _, state, _ = orc.ppo_minibatch_step(sd, nb, mb, w, state)       # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
+    while len(times) < 3 or ((time.perf_counter() - t_all) < 10.0 and len(times) < 9):
         t0 = time.perf_counter()
         _, state, _ = orc.ppo_minibatch_step(sd, nb, mb, w, state)
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.1f} s (minibatch {Bc})", file=sys.stderr, flush=True)
     med = sorted(times)[len(times) // 2]
     return {"value": round(Bc / med, 2), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"oracle ppo_minibatch_step (fp32 CPU PyTorch), se_resnet {nb}x{C}, minibatch {Bc}, "
-                      f"median of {len(times)} steps after 1 warm-up"}
+            "sample": f"oracle ppo_minibatch_step (fp32 CPU PyTorch restatement of the reference), se_resnet {nb}x{C}, "
+                      f"minibatch {Bc}, median of {len(times)} step(s) (~{sum(times):.0f} s of CPU work) after a probe step"}
 
 
 def main() -> None:
@@ -154,6 +166,7 @@ def main() -> None:
         lo = (i % nmb) * B
         algo._fused_step(fs, perm[lo:lo + B], device)
 
+    print(f"[bench] rank {rank}: model + dataset ready, running {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()

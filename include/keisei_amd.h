@@ -53,11 +53,11 @@ int ka_conv3x3_sqpart_rows(int B);
  * gradient (in/out swapped, taps flipped), Nout = Ci, Kin = Co.  dst bytes = 9*(Kin/cpk)*(Nout/16)*1024. */
 int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int Nout, int Kin, int mode, int dtype, void* stream);
 /* Weight gradient dW[n,c,ky,kx] = sum_{b,p} dY[b,p,n] * X'[b,p+tap,c] (autograd conv2d weight backward);
- * X' uses the same fused input transform as the forward.  slab: ka_wgrad_splits(B,Cin,Cout)*9*Cout*Cin floats. */
+ * X' uses the same fused input transform as the forward.  slab: ka_wgrad_splits(B,Cin,Cout,target_wgs)*9*Cout*Cin floats. */
 int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift, const float* in_bias,
-                     int relu, float* slab, float* dw, int B, int Cin, int Cin_real, int Cout, int accumulate, int dtype,
-                     void* stream);
-int ka_wgrad_splits(int B, int Cin, int Cout);
+                     int relu, float* slab, float* dw, int B, int Cin, int Cin_real, int Cout, int accumulate,
+                     int target_wgs, int dtype, void* stream);
+int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs);   /* target_wgs: 0 = 256 (one workgroup per CU) */
 int ka_debug_conv_stamps(unsigned long long* stamps);   /* diagnostics only (tools/conv_stamps.py); null = off */
 
 /* ---- layout at the model boundary ----------------------------------------------------------------

@@ -20,8 +20,8 @@ _SIGS = {
     "ka_conv3x3_sqpart_rows": "i",
     "ka_debug_conv_stamps": "p",
     "ka_pack_conv3x3": "pp iiii i i p",
-    "ka_wgrad_splits": "iii",
-    "ka_conv3x3_wgrad": "ppppp i pp iiii i i p",
+    "ka_wgrad_splits": "iiii",
+    "ka_conv3x3_wgrad": "ppppp i pp iiii i i i p",
     "ka_obs_to_nhwc": "ppp iii i p",
     "ka_nhwc_to_nchw": "pp ii i p",
     "ka_bn_reduce": "p i p i i pp p",

@@ -199,16 +199,22 @@ __global__ void affine_rows_kernel(const float* __restrict__ in, const float* __
     }
 }
 
-// dy = k1[c]*dz + k2[c] + k3[c]*y   (BatchNorm backward, elementwise part)
+// dy = k1[c]*dz + k2[c] + k3[c]*y   (BatchNorm backward, elementwise part).  One workgroup per board, a thread keeps
+// its two channels' coefficients in registers and walks its squares (no per-element index arithmetic).
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ k,
-                                    T* __restrict__ dy, size_t npairs, int C) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 2) % C);
-        const f32x2 g = ld2(dz + i * 2), v = ld2(y + i * 2);
-        f32x2 o = {k[c] * g[0] + k[C + c] + k[2 * C + c] * v[0],
-                   k[c + 1] * g[1] + k[C + c + 1] + k[2 * C + c + 1] * v[1]};
-        st2(dy + i * 2, o);
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                                const float* __restrict__ k, T* __restrict__ dy, int C) {
+    const BoardMap m(C);
+    if (!m.active) return;
+    const size_t base = (size_t)blockIdx.x * KA_BOARD * C;
+    for (int cb = 0; cb < (C >> 1); cb += m.cpw) {
+        const int c = (cb + m.cp) * 2;
+        const f32x2 k1 = {k[c], k[c + 1]}, k2 = {k[C + c], k[C + c + 1]}, k3 = {k[2 * C + c], k[2 * C + c + 1]};
+        for (int p = m.slice; p < KA_BOARD; p += m.ph) {
+            const size_t off = base + (size_t)p * C + c;
+            const f32x2 g = ld2(dz + off), v = ld2(y + off);
+            st2(dy + off, f32x2{k1[0] * g[0] + k2[0] + k3[0] * v[0], k1[1] * g[1] + k2[1] + k3[1] * v[1]});
+        }
     }
 }
 
@@ -558,12 +564,11 @@ extern "C" int ka_affine_rows(const float* in, const float* a, const float* s, f
 
 extern "C" int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, void* dy, int B, int C, int dtype,
                                void* stream) {
-    KA_REQUIRE(dz && y && k && dy && C % 2 == 0, "bn_bwd_apply: bad arguments");
-    const size_t npairs = (size_t)B * KA_BOARD * C / 2;
-    const int blocks = (int)((npairs + 255) / 256 < 4096 ? (npairs + 255) / 256 : 4096);
+    KA_REQUIRE(dz && y && k && dy, "bn_bwd_apply: bad arguments");
+    KA_BOARD_CHECK("bn_bwd_apply");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dz,
-                                            (const T*)y, k, (T*)dy, npairs, C));
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(B), dim3(kThreads), 0, st, (const T*)dz,
+                                            (const T*)y, k, (T*)dy, C));
     return ka_check_launch("bn_bwd_apply");
 }
 

@@ -14,6 +14,7 @@
 // summed by wgrad_reduce_kernel in a fixed order, so the result is run-to-run deterministic.
 //
 // Replaces: autograd's conv2d weight backward for se_resnet.py:50,52,110.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -53,6 +54,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     constexpr int PY = kTN * ESZ / 16, PX = kTC * ESZ / 16;      // 16-byte pieces per tile row
     constexpr int NY = (KA_BOARD * PY + 511) / 512, NX = (KA_BOARD * PX + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // bf16: two tile sets (double buffer) -- a wave writes board b+1 into the other set while slower waves still
+    // multiply board b, one barrier per board.  f32 tiles are twice as large: single set, two barriers per board.
+    constexpr int NBUF = (sizeof(T) == 2) ? 2 : 1;
+    constexpr int TILE_BYTES = KROWS * SY + KA_PADBOARD * SX;
     char* ytile = smem;
     char* xtile = smem + KROWS * SY;
 
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // zero both tiles once: dY pad rows (81..KROWS) and the X halo stay zero forever
-    for (int i = tid; i < (KROWS * SY + KA_PADBOARD * SX) / 16; i += 512)
+    for (int i = tid; i < NBUF * TILE_BYTES / 16; i += 512)
         reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
 
     // staging roles
@@ -151,17 +156,51 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     const bool c_ok = c0 + cq * 16 < a.Cin;
 
     if (bbeg < bend) load_board(bbeg);
-    for (int b = bbeg; b < bend; ++b) {
-        __syncthreads();                 // previous board fully consumed
-        store_board(b);
+    if (NBUF == 2) {
+        __syncthreads();                 // zero fill complete
+        if (bbeg < bend) { store_board(bbeg); if (bbeg + 1 < bend) load_board(bbeg + 1); }
         __syncthreads();
-        if (b + 1 < bend) load_board(b + 1);      // in flight during the MFMA phase
-        if (!c_ok || ntn_valid == 0) continue;    // wave-uniform; barriers are above
+    }
+    for (int b = bbeg; b < bend; ++b) {
+        if (NBUF == 1) {
+            __syncthreads();                 // previous board fully consumed
+            store_board(b);
+            __syncthreads();
+            if (b + 1 < bend) load_board(b + 1);      // in flight during the MFMA phase
+        } else {
+            // stage board b+1 into the other tile set (its registers were loaded one iteration ago), then start
+            // the loads of board b+2; the single barrier at the bottom closes both hazards
+            const int cur = (b - bbeg) & 1;
+            if (b + 1 < bend) {
+                ytile = smem + (cur ^ 1) * TILE_BYTES; xtile = ytile + KROWS * SY;
+                store_board(b + 1);
+                if (b + 2 < bend) load_board(b + 2);
+            }
+            ytile = smem + cur * TILE_BYTES; xtile = ytile + KROWS * SY;
+        }
+        const bool skip = !c_ok || ntn_valid == 0;    // wave-uniform
+        if (!skip) {
 
         if constexpr (sizeof(T) == 2) {
+            // branch-free MFMA stream: tiles beyond Cout multiply zero-filled LDS columns and are never stored.
+            // B fragments (the tap-shifted X rows) are fetched one tap ahead; the issue order is pinned so each
+            // pair of transpose reads sits in front of the 4 MFMAs of the previous tap.
+            auto load_b = [&](int ks, int tap) {
+                const int k1 = ks * 32 + 4 * q + (r >> 2), k2 = k1 + 16;   // k-slot permutation, see below
+                const int i1 = (k1 < KA_BOARD) ? pad_index(k1) : 12, i2 = (k2 < KA_BOARD) ? pad_index(k2) : 12;
+                const int colx = (cq * 16 + 4 * (r & 3)) * 2;
+                const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i1 + toff) * SX + colx));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i2 + toff) * SX + colx));
+                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
 #pragma unroll 1
             for (int ks = 0; ks < 3; ++ks) {
-                const int k1 = ks * 32 + 8 * q + (r >> 2), k2 = k1 + 4;
+                // MFMA k-slot (q, j) is mapped to tile row 4q+j (j<4) / 16+4q+(j-4) (j>=4) for BOTH operands (any
+                // common permutation of k is legal): each 32-lane half of a transpose read then covers 8 CONSECUTIVE
+                // rows, which the 32*odd-byte row strides spread over all 64 banks (the natural 8q+j map makes a half
+                // read rows {k..k+3, k+8..k+11}: a guaranteed 2-way conflict)
+                const int k1 = ks * 32 + 4 * q + (r >> 2), k2 = k1 + 16;
                 bf16x8 af[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -170,18 +209,24 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ytile + k2 * SY + colb));
                     af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                const int i1 = (k1 < KA_BOARD) ? pad_index(k1) : 12, i2 = (k2 < KA_BOARD) ? pad_index(k2) : 12;
-                const int colx = (cq * 16 + 4 * (r & 3)) * 2;
+                bf16x8 bcur = load_b(ks, 0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i1 + toff) * SX + colx));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i2 + toff) * SX + colx));
-                    const bf16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8 bnext = bcur;
+                    if (tap < 8) bnext = load_b(ks, tap + 1);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        if (t < ntn_valid) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bv, acc[tap][t], 0, 0, 0);
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bcur, acc[tap][t], 0, 0, 0);
+                    bcur = bnext;
                 }
+                // issue order: [8 A reads + 2 B reads] then 8 x { 2 B reads of the next tap, 4 MFMAs of this tap }, 4 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+                for (int tap = 0; tap < 8; ++tap) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         } else {
 #pragma unroll 1
@@ -198,10 +243,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
                     const float bv = *reinterpret_cast<const float*>(xtile + (ik + toff) * SX + (cq * 16 + r) * 4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        if (t < ntn_valid) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv, acc[tap][t], 0, 0, 0);
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bv, acc[tap][t], 0, 0, 0);
                 }
             }
         }
+        }
+        if (NBUF == 2) __syncthreads();
     }
 
     // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
@@ -237,9 +284,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 }  // namespace
 
-extern "C" int ka_wgrad_splits(int B, int Cin, int Cout) {
+// target_wgs: workgroups to aim for (0 = one per CU, 256).  Fewer leaves CUs free for kernels that run concurrently
+// on another stream (the engine overlaps wgrad with the HBM-bound backward kernels and asks for 192).
+extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
     const int tiles = ((Cout + kTN - 1) / kTN) * ((Cin + kTC - 1) / kTC);
-    int s = 256 / tiles;
+    if (const char* e = getenv("KA_WGRAD_WGS")) { const int v = atoi(e); if (v > 0) target_wgs = v; }   // experiments
+    int s = (target_wgs > 0 ? target_wgs : 256) / tiles;
     if (s < 1) s = 1;
     if (s > B) s = B;
     const int bps = (B + s - 1) / s;
@@ -248,17 +298,26 @@ extern "C" int ka_wgrad_splits(int B, int Cin, int Cout) {
 
 extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift,
                                 const float* in_bias, int relu, float* slab, float* dw, int B, int Cin, int Cin_real,
-                                int Cout, int accumulate, int dtype, void* stream) {
+                                int Cout, int accumulate, int target_wgs, int dtype, void* stream) {
     KA_REQUIRE(dy && x && slab && dw && B > 0, "wgrad: null tensor");
     KA_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin_real <= Cin, "wgrad: need Cin,Cout %% 16 == 0");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nsplit = ka_wgrad_splits(B, Cin, Cout);
+    const int nsplit = ka_wgrad_splits(B, Cin, Cout, target_wgs);
     const int bps = (B + nsplit - 1) / nsplit;
     WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, (Cout + kTN - 1) / kTN};
     dim3 grid(a.ntn * ((Cin + kTC - 1) / kTC), nsplit);
     if (dtype == KA_DTYPE_BF16) {
-        const size_t lds = WG<bf16_t>::KROWS * WG<bf16_t>::SY + KA_PADBOARD * WG<bf16_t>::SX;
+        const size_t lds = 2 * (WG<bf16_t>::KROWS * WG<bf16_t>::SY + KA_PADBOARD * WG<bf16_t>::SX);
+        static bool attr_bf = false;
+        if (!attr_bf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                ka_set_error("wgrad: hipFuncSetAttribute failed");
+                return KA_ERR_HIP;
+            }
+            attr_bf = true;
+        }
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(512), lds, st, a);
     } else if (dtype == KA_DTYPE_F32) {
         const size_t lds = WG<float>::KROWS * WG<float>::SY + KA_PADBOARD * WG<float>::SX;

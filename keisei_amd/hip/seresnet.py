@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -44,6 +46,9 @@ class SEResNetEngine:
         self._pack_key = None
         self._scratch: Optional[torch.Tensor] = None
         self._redws: Optional[torch.Tensor] = None
+        self._side = None
+        self._wslab: Optional[torch.Tensor] = None
+        self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
 
@@ -69,6 +74,29 @@ class SEResNetEngine:
         if self._redws is None or self._redws.numel() < n or self._redws.device != device:
             self._redws = torch.empty(n, dtype=torch.float64, device=device)
         return self._redws
+
+    def _wgrad_side(self, n: int, device):
+        """(side stream, partial-slab buffer) of the weight-gradient GEMMs.  In backward they are issued on a second
+        HIP stream right after the data-gradient conv that shares their input, so the MFMA-bound wgrad overlaps the
+        HBM-bound BatchNorm / pooling / FC kernels of the main stream instead of serialising with them."""
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device)
+        if self._wslab is None or self._wslab.numel() < n or self._wslab.device != device:
+            self._wslab = torch.empty(n, dtype=torch.float32, device=device)
+        return self._side, self._wslab
+
+    def _wgrad_launch(self, side, main, inputs, *args) -> None:
+        """ka_conv3x3_wgrad on the side stream, ordered after everything already queued on the main stream."""
+        if side is None:
+            self._timed("wgrad", "ka_conv3x3_wgrad", *args, _lib.stream_ptr(main.device))
+            return
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            self._timed("wgrad", "ka_conv3x3_wgrad", *args, _lib.stream_ptr(main.device))
+        for t in inputs:                 # main-stream allocations read by the side stream: defer their reuse
+            t.record_stream(side)
 
     def _scratch_f32(self, n: int, device) -> torch.Tensor:
         if self._scratch is None or self._scratch.numel() < n or self._scratch.device != device:
@@ -344,8 +372,14 @@ class SEResNetEngine:
         _call("ka_block_dx", dxc, None, None, x, pool, dpool, dout, B, C, code, st)
 
         s1p = torch.empty(B, C, device=dev); s2p = torch.empty(B, C, device=dev)
-        nsplit = _lib.query("ka_wgrad_splits", B, C, C)
-        slab = self._scratch_f32(max(nsplit * 9 * C * C, _lib.query("ka_wgrad_splits", B, 64, C) * 9 * C * 64), dev)
+        # overlapped wgrad leaves a quarter of the CUs to the concurrent main-stream kernels (measured best: 192 of 256)
+        twg = 192 if self.overlap_wgrad else 0
+        nsplit = _lib.query("ka_wgrad_splits", B, C, C, twg)
+        nslab = max(nsplit * 9 * C * C, _lib.query("ka_wgrad_splits", B, 64, C, 0) * 9 * C * 64)
+        main = torch.cuda.current_stream(dev)
+        side, slab = self._wgrad_side(nslab, dev)
+        if not self.overlap_wgrad:
+            side = None
 
         # ---- tower, last block first
         for i in range(len(sv.blocks) - 1, -1, -1):
@@ -367,7 +401,7 @@ class SEResNetEngine:
             dg = torch.empty(B, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
             dW2 = torch.empty_like(blk.conv2.weight)
-            self._timed("wgrad", "ka_conv3x3_wgrad", dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, code, st)
+            self._wgrad_launch(side, main, (dz, dW2), dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
             grads[pre + "conv2.weight"] = dW2
             dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
             _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
@@ -376,12 +410,12 @@ class SEResNetEngine:
             _call("ka_relu_bn_bwd_reduce", dh, y1, sc1, sh1, mu1, is1, dh, s1p, s2p, B, C, code, st)   # dh -> da1 in place
             k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
             _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
-            dxc = dz                                                                          # reuse buffer
+            dxc = new_act() if side is not None else dz       # dz / dh may still be read by the side stream
             self._timed("conv3x3", "ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
             dW1 = torch.empty_like(blk.conv1.weight)
-            self._timed("wgrad", "ka_conv3x3_wgrad", dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, code, st)
+            self._wgrad_launch(side, main, (dh, dW1), dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
             grads[pre + "conv1.weight"] = dW1
-            dx = dh                                                                           # reuse buffer
+            dx = new_act() if side is not None else dh
             _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
             dout = dx
 
@@ -394,8 +428,10 @@ class SEResNetEngine:
         _call("ka_bn_bwd_apply", dout, y0, k0, dout, B, C, code, st)
         dW0 = torch.empty_like(m.input_conv.weight)
         cin_pad = sv.xin.shape[2]
-        _call("ka_conv3x3_wgrad", dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad, p.obs_channels, C, 0, code, st)
+        _call("ka_conv3x3_wgrad", dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad, p.obs_channels, C, 0, 0, code, st)
         grads["input_conv.weight"] = dW0
+        if side is not None:
+            main.wait_stream(side)          # every dW is complete before autograd hands the gradients on
         return grads
 
     def _linear_bwd_act(self, dy, x_act, lin, grads, wname, dx_act, bf, st):

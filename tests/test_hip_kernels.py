@@ -130,11 +130,11 @@ def test_conv3x3_wgrad(dtn, B, cin, cin_real, cout):
     x[:, cin_real:] = 0
     dy = torch.randn(B, cout, 9, 9, generator=g) / 9.0
     ref = torch.nn.grad.conv2d_weight(rnd(x, dt), (cout, cin, 3, 3), rnd(dy, dt), padding=1)[:, :cin_real]
-    ns = _lib.query("ka_wgrad_splits", B, cin, cout)
+    ns = _lib.query("ka_wgrad_splits", B, cin, cout, 0)
     slab = torch.empty(ns * 9 * cout * cin, device=DEV)
     dw = torch.full((cout, cin_real, 3, 3), float("nan"), device=DEV)
     _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(x, dt), None, None, None, 0, slab, dw, B, cin, cin_real, cout,
-              0, _lib.dtype_code(dt), st())
+              0, 0, _lib.dtype_code(dt), st())
     torch.cuda.synchronize()
     tol_dt = torch.float32 if dt == torch.float32 else torch.bfloat16
     scale = float(ref.abs().max())
@@ -142,7 +142,7 @@ def test_conv3x3_wgrad(dtn, B, cin, cin_real, cout):
     assert err <= (3e-5 if tol_dt == torch.float32 else 2e-3) * scale, (err, scale)
     # accumulate flag
     _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(x, dt), None, None, None, 0, slab, dw, B, cin, cin_real, cout,
-              1, _lib.dtype_code(dt), st())
+              1, 0, _lib.dtype_code(dt), st())
     assert float((dw.cpu() - 2 * ref).abs().max()) <= (6e-5 if tol_dt == torch.float32 else 4e-3) * scale
 
 
@@ -157,11 +157,11 @@ def test_wgrad_fused_input_transform(dtn):
     gb = 0.5 * torch.randn(B, C, generator=g)
     h = rnd(torch.relu(rnd(y, dt) * sc[None, :, None, None] + sh[None, :, None, None]) + gb[:, :, None, None], dt)
     ref = torch.nn.grad.conv2d_weight(h, (C, C, 3, 3), rnd(dy, dt), padding=1)
-    ns = _lib.query("ka_wgrad_splits", B, C, C)
+    ns = _lib.query("ka_wgrad_splits", B, C, C, 0)
     slab = torch.empty(ns * 9 * C * C, device=DEV)
     dw = torch.empty(C, C, 3, 3, device=DEV)
     _lib.call("ka_conv3x3_wgrad", to_nhwc(dy, dt), to_nhwc(y, dt), sc.to(DEV), sh.to(DEV), gb.to(DEV), 1, slab, dw, B, C, C, C,
-              0, _lib.dtype_code(dt), st())
+              0, 0, _lib.dtype_code(dt), st())
     scale = float(ref.abs().max())
     assert float((dw.cpu() - ref).abs().max()) <= (3e-5 if dt == torch.float32 else 3e-3) * scale
 

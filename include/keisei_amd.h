@@ -48,6 +48,15 @@ int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in
                    const float* in_bias, int relu, float* bsum, float* sqpart, int B, int Cin, int Cout, int dtype,
                    void* stream);
 int ka_conv3x3_sqpart_rows(int B);
+/* Data-gradient convolution with the surrounding BatchNorm-backward passes fused in (bf16): the input is
+ * dy = in*k[0:C] + k[C:2C] + in2*k[2C:3C] (= ka_bn_bwd_apply on the fly, also written to dy_out for the weight-gradient
+ * kernel); with ep_y the output is masked by the ReLU of the preceding BatchNorm, out = conv(dy)*[ep_scale*ep_y+ep_shift>0],
+ * and ep_s1/ep_s2 [ka_conv3x3_sqpart_rows(B)][Cout] receive the partial sums of ka_relu_bn_bwd_reduce.  bsum = per-board
+ * sums of the unmasked conv(dy) (gradient of the global-pool bias, se_resnet.py:78). */
+int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const float* k, void* dy_out, const void* wpack, void* out,
+                           float* bsum, const void* ep_y, const float* ep_scale, const float* ep_shift,
+                           const float* ep_mean, const float* ep_invstd, float* ep_s1, float* ep_s2, int B, int Cin,
+                           int Cout, int dtype, void* stream);
 /* (Co,Ci,3,3) fp32 torch-layout weights -> MFMA B-fragment order (a derived cache; the stored parameter keeps
  * the reference's shape).  mode 0: forward, Nout = Co, Kin = Ci rounded up (zero channels); mode 1: data
  * gradient (in/out swapped, taps flipped), Nout = Ci, Kin = Co.  dst bytes = 9*(Kin/cpk)*(Nout/16)*1024. */

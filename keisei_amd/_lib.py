@@ -17,6 +17,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libkeisei_amd.so"
 # signature strings: p = pointer (torch tensor | int | None), i = int, f = float, d = double, q = long long
 _SIGS = {
     "ka_conv3x3_fwd": "pppppp i pp iii i p",
+    "ka_conv3x3_dgrad_fused": "ppppp pp ppppp pp iii i p",
     "ka_conv3x3_sqpart_rows": "i",
     "ka_debug_conv_stamps": "p",
     "ka_pack_conv3x3": "pp iiii i i p",

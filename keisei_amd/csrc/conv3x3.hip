@@ -40,7 +40,17 @@ struct ConvArgs {
     float* bsum;             // [B,Cout] or null
     float* sqpart;           // [gridDim.x, Cout] or null
     int B, Cin, Cout, KC, relu;
-    unsigned long long* stamps;   // diagnostic only: [workgroup][4] s_memtime at phase boundaries (null in production)
+    // fused BatchNorm-backward input (data-gradient convs): x' = in*in_scale + in_shift + in2*in_k3, optionally
+    // written back to in_out (the materialised dy the weight-gradient kernel reads)
+    const void* in2;
+    const float* in_k3;
+    void* in_out;
+    // fused ReLU+BatchNorm-backward epilogue (bf16): out = acc * [ep_scale*ep_y + ep_shift > 0]; per-workgroup partial
+    // sums ep_s1[wg][n] = sum out, ep_s2[wg][n] = sum out*(ep_y-ep_mean)*ep_invstd
+    const void* ep_y;
+    const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_invstd;
+    float* ep_s1; float* ep_s2;
+    unsigned long long* stamps;   // diagnostic only: [workgroup][8] s_memtime at phase boundaries (null in production)
 };
 
 unsigned long long* g_stamps = nullptr;
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     const bool wave_active = nt0 < NT;
 
     const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 0] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 0] = __builtin_amdgcn_s_memtime();
     const int nchunks = a.Cin / a.KC;
     for (int kc = 0; kc < nchunks; ++kc) {
         if (kc > 0) __syncthreads();
@@ -134,6 +144,44 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                     for (int e = 0; e < P16; ++e)
                         gbv[b][e] = (b0 + b < a.B) ? a.in_bias[(size_t)(b0 + b) * a.Cin + c0 + e] : 0.f;
             }
+            if (a.in2) {
+                // two-tensor transform (BatchNorm backward applied on the fly), 3 + 3 loads in flight
+                float k3[P16];
+#pragma unroll
+                for (int e = 0; e < P16; ++e) k3[e] = a.in_k3[c0 + e];
+                constexpr int kU2 = (WM == 2) ? 6 : 4;
+                for (int pos0 = spos0; pos0 < kRows; pos0 += sstep * kU2) {
+                    vec16 v[kU2], w[kU2];
+#pragma unroll
+                    for (int u = 0; u < kU2; ++u) {
+                        const int pos = pos0 + u * sstep;
+                        const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
+                        const size_t off = ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ;
+                        if (pos < kRows && bb < a.B) {
+                            v[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) + off);
+                            w[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in2) + off);
+                        } else { v[u] = vec16{}; w[u] = vec16{}; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU2; ++u) {
+                        const int pos = pos0 + u * sstep;
+                        if (pos >= kRows) continue;
+                        const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
+                        if (bb < a.B) {
+                            float f[P16], g2[P16];
+                            E::unpack(v[u], f);
+                            E::unpack(w[u], g2);
+#pragma unroll
+                            for (int e = 0; e < P16; ++e) f[e] = fmaf(g2[e], k3[e], fmaf(f[e], sc[e], sh[e]));
+                            v[u] = E::pack(f);
+                            if (a.in_out && blockIdx.y == 0)
+                                *reinterpret_cast<vec16*>(static_cast<char*>(a.in_out) +
+                                                          ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ) = v[u];
+                        }
+                        *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v[u];
+                    }
+                }
+            } else {
             // loads are issued in batches of kUnr before any is consumed: the staging phase is otherwise a
             // chain of dependent HBM round trips (one per 16-byte piece per thread)
             constexpr int kUnr = (WM == 2) ? 6 : 11;
@@ -174,9 +222,10 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                     *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v[u];
                 }
             }
+                    }
         }
         __syncthreads();
-        if (a.stamps && tid == 0 && kc == 0) a.stamps[wg_lin * 4 + 1] = __builtin_amdgcn_s_memtime();
+        if (a.stamps && tid == 0 && kc == 0) a.stamps[wg_lin * 8 + 1] = __builtin_amdgcn_s_memtime();
 
         // ---- MFMA phase: 9 taps x KS k-steps.  Weight fragments stream from L2 straight into registers,
         // ping-ponged between two named register sets (no conditional loads, no register copies) so the
@@ -256,7 +305,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
         }
     }
 
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 2] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: statistics from the fp32 accumulators, then the output tile
     const bool v0 = b0 < a.B, v1 = b0 + 1 < a.B;
     constexpr int BN = 4 * NTW * 16;                 // output channels of this workgroup
@@ -282,7 +331,9 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
             ss[j] += __shfl_xor(ss[j], 16); ss[j] += __shfl_xor(ss[j], 32);
         }
     }
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 3] = __builtin_amdgcn_s_memtime();
     if (WM > 1 || sizeof(T) == 2) __syncthreads();   // all waves done reading the input tile
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 4] = __builtin_amdgcn_s_memtime();
     if (WM > 1 && wave_active && want_stats && mhalf == 1 && q == 0) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -307,6 +358,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
         }
     }
     if (WM > 1 || sizeof(T) == 2) __syncthreads();
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 5] = __builtin_amdgcn_s_memtime();
     if (wave_active && want_stats && mhalf == 0 && q == 0) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -324,16 +376,71 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
             if (a.sqpart) a.sqpart[(size_t)blockIdx.x * a.Cout + n] = t2;
         }
     }
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 6] = __builtin_amdgcn_s_memtime();
     if constexpr (sizeof(T) == 2) {
         const int n_wg0 = blockIdx.y * BN;
         const int ncols = min(BN, a.Cout - n_wg0);   // multiple of 16
         const int ppr = ncols / 8;                   // 16-byte pieces per row
         const int rows = v1 ? kRows : (v0 ? KA_BOARD : 0);
-        for (int i = tid; i < rows * ppr; i += kThreads) {
-            const int m = i / ppr, pc = i - m * ppr;
-            const uint4 v = *reinterpret_cast<const uint4*>(smem + m * ostride + pc * 16);
-            *reinterpret_cast<uint4*>(static_cast<char*>(a.out) +
-                                      ((size_t)(b0 * KA_BOARD + m) * a.Cout + n_wg0 + pc * 8) * 2) = v;
+        if (!a.ep_y) {
+            for (int i = tid; i < rows * ppr; i += kThreads) {
+                const int m = i / ppr, pc = i - m * ppr;
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + m * ostride + pc * 16);
+                *reinterpret_cast<uint4*>(static_cast<char*>(a.out) +
+                                          ((size_t)(b0 * KA_BOARD + m) * a.Cout + n_wg0 + pc * 8) * 2) = v;
+            }
+        } else {
+            // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da (this thread always
+            // handles the same 8 channels: kThreads % ppr == 0)
+            const int pc = tid % ppr, n8 = n_wg0 + pc * 8;
+            float esc[8], esh[8], emu[8], eis[8], s1[8], s2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                esc[e] = a.ep_scale[n8 + e]; esh[e] = a.ep_shift[n8 + e];
+                emu[e] = a.ep_mean[n8 + e]; eis[e] = a.ep_invstd[n8 + e];
+                s1[e] = 0.f; s2[e] = 0.f;
+            }
+            // all y pieces of this thread are requested up front (one HBM round trip instead of one per row)
+            // (rows per thread = 162 / (kThreads/ppr) <= kMaxIt because ppr <= 32)
+            constexpr int kMaxIt = (kRows + (kThreads / 32) - 1) / (kThreads / 32);
+            const int mstep = kThreads / ppr, m_first = tid / ppr;
+            bf16x8 yv[kMaxIt];
+#pragma unroll
+            for (int it = 0; it < kMaxIt; ++it) {
+                const int m = m_first + it * mstep;
+                yv[it] = (m < rows) ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) +
+                                          ((size_t)(b0 * KA_BOARD + m) * a.Cout + n8) * 2) : bf16x8{};
+            }
+#pragma unroll
+            for (int it = 0; it < kMaxIt; ++it) {
+                const int m = m_first + it * mstep;
+                if (m >= rows) continue;
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(smem + m * ostride + pc * 16);
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = (float)yv[it][e];
+                    const float d = (y * esc[e] + esh[e] > 0.f) ? (float)dv[e] : 0.f;
+                    s1[e] += d; s2[e] += d * ((y - emu[e]) * eis[e]);
+                    ov[e] = (__bf16)d;
+                }
+                *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + ((size_t)(b0 * KA_BOARD + m) * a.Cout + n8) * 2) = ov;
+            }
+            // combine the kThreads/ppr row-slices of every channel octet (region after the output tile + stats)
+            float* red = stat_lds + WM * BN * 3;                      // [slice][ppr*8][2]
+            const int slice = tid / ppr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[((slice * ppr + pc) * 8 + e) * 2] = s1[e];
+                red[((slice * ppr + pc) * 8 + e) * 2 + 1] = s2[e];
+            }
+            __syncthreads();
+            if (tid < ncols) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int sl = 0; sl < kThreads / ppr; ++sl) { t1 += red[(sl * ncols + tid) * 2]; t2 += red[(sl * ncols + tid) * 2 + 1]; }
+                a.ep_s1[(size_t)blockIdx.x * a.Cout + n_wg0 + tid] = t1;
+                a.ep_s2[(size_t)blockIdx.x * a.Cout + n_wg0 + tid] = t2;
+            }
         }
     } else {
         if (wave_active) {
@@ -352,7 +459,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                 }
         }
     }
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 4 + 3] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 
 // Pack (Co,Ci,3,3) fp32 weights into MFMA B-fragment order.
@@ -390,7 +497,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
     const size_t lds_in = (size_t)kNB * KA_PADBOARD * (a.KC * E::kSize + 16);
-    const size_t lds_out = ((E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0) + (size_t)WM * BN * 3 * sizeof(float);
+    const size_t lds_out = ((E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0) + (size_t)WM * BN * 3 * sizeof(float) +
+                           (a.ep_y ? (size_t)256 * WM * 16 * sizeof(float) : 0);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
     static bool attr_done = false;   // per instantiation
@@ -444,7 +552,8 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
 extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale,
                               const float* in_shift, const float* in_bias, int relu, float* bsum, float* sqpart,
                               int B, int Cin, int Cout, int dtype, void* stream) {
-    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu, g_stamps};
+    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g_stamps};
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -452,6 +561,22 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
     if (dtype == KA_DTYPE_F32) return conv_dispatch<float>(a, st);
     ka_set_error("conv3x3: unknown dtype %d", dtype);
     return KA_ERR_ARG;
+}
+
+// Data-gradient convolution with the surrounding BatchNorm-backward passes fused in (bf16 only):
+//   input  : dy = in*k[0:C] + k[C:2C] + in2*k[2C:3C]   (ka_bn_bwd_apply on the fly; written to dy_out when non-NULL)
+//   output : out = conv(dy) [* [ep_scale*ep_y + ep_shift > 0]]  and, with ep_y, the per-workgroup partial sums
+//            ep_s1/ep_s2 [ka_conv3x3_sqpart_rows(B)][Cout] of ka_relu_bn_bwd_reduce; bsum = per-board sums of conv(dy)
+extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const float* k, void* dy_out, const void* wpack,
+                                      void* out, float* bsum, const void* ep_y, const float* ep_scale,
+                                      const float* ep_shift, const float* ep_mean, const float* ep_invstd, float* ep_s1,
+                                      float* ep_s2, int B, int Cin, int Cout, int dtype, void* stream) {
+    KA_REQUIRE(in && in2 && k && wpack && out, "conv3x3_dgrad_fused: null tensor");
+    KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused: bf16 only");
+    KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused: epilogue tensors");
+    ConvArgs a{in, wpack, out, k, k + Cin, nullptr, bsum, nullptr, B, Cin, Cout, 0, 0,
+               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, g_stamps};
+    return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
 }
 
 // diagnostic: stamps != null makes every conv3x3 workgroup record 4 s_memtime values (100 MHz ticks are NOT used:

@@ -396,26 +396,50 @@ class SEResNetEngine:
             dz = new_act()
             _call("ka_tail_bwd_dz", dout, out, y2, se, dsq, mu2, is2, dz, s1p, s2p, B, C, code, st)
             k2 = self._bn_backward(blk.bn2, s1p, s2p, B, C, count, mu2, is2, train, grads, pre + "bn2", dev, st)
-            _call("ka_bn_bwd_apply", dz, y2, k2, dz, B, C, code, st)                         # dz -> dy2 in place
-            dh = new_act()
             dg = torch.empty(B, C, device=dev)
-            self._timed("conv3x3", "ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
-            dW2 = torch.empty_like(blk.conv2.weight)
-            self._wgrad_launch(side, main, (dz, dW2), dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
-            grads[pre + "conv2.weight"] = dW2
-            dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
-            _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
-            dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
-                                       pre + "global_fc.0.bias", st)
-            _call("ka_relu_bn_bwd_reduce", dh, y1, sc1, sh1, mu1, is1, dh, s1p, s2p, B, C, code, st)   # dh -> da1 in place
-            k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
-            _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
-            dxc = new_act() if side is not None else dz       # dz / dh may still be read by the side stream
-            self._timed("conv3x3", "ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
-            dW1 = torch.empty_like(blk.conv1.weight)
-            self._wgrad_launch(side, main, (dh, dW1), dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
-            grads[pre + "conv1.weight"] = dW1
-            dx = new_act() if side is not None else dh
+            if T == torch.bfloat16:
+                # bf16: both BatchNorm-backward "apply" passes and the ReLU/BN1-backward reduce pass are fused into the
+                # two data-gradient convolutions (input transform / epilogue); dy2 / dy1 are written for the wgrads
+                rows = _lib.query("ka_conv3x3_sqpart_rows", B)
+                dy2, dh = new_act(), new_act()
+                ep1 = torch.empty(rows, C, device=dev); ep2 = torch.empty(rows, C, device=dev)
+                self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dz, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
+                            y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
+                dW2 = torch.empty_like(blk.conv2.weight)
+                self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
+                grads[pre + "conv2.weight"] = dW2
+                dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
+                _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
+                dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
+                                           pre + "global_fc.0.bias", st)
+                k1 = self._bn_backward(blk.bn1, ep1, ep2, rows, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
+                dy1, dxc = new_act(), new_act()
+                self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dh, y1, k1, dy1, packs[pre + "conv1"][1], dxc, None,
+                            None, None, None, None, None, None, None, B, C, C, code, st)
+                dW1 = torch.empty_like(blk.conv1.weight)
+                self._wgrad_launch(side, main, (dy1, dW1), dy1, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
+                grads[pre + "conv1.weight"] = dW1
+                dx = new_act()
+            else:
+                _call("ka_bn_bwd_apply", dz, y2, k2, dz, B, C, code, st)                         # dz -> dy2 in place
+                dh = new_act()
+                self._timed("conv3x3", "ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
+                dW2 = torch.empty_like(blk.conv2.weight)
+                self._wgrad_launch(side, main, (dz, dW2), dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
+                grads[pre + "conv2.weight"] = dW2
+                dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
+                _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
+                dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
+                                           pre + "global_fc.0.bias", st)
+                _call("ka_relu_bn_bwd_reduce", dh, y1, sc1, sh1, mu1, is1, dh, s1p, s2p, B, C, code, st)   # dh -> da1 in place
+                k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
+                _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
+                dxc = new_act() if side is not None else dz       # dz / dh may still be read by the side stream
+                self._timed("conv3x3", "ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
+                dW1 = torch.empty_like(blk.conv1.weight)
+                self._wgrad_launch(side, main, (dh, dW1), dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
+                grads[pre + "conv1.weight"] = dW1
+                dx = new_act() if side is not None else dh
             _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
             dout = dx
 

@@ -484,3 +484,39 @@ def test_clip_adam_matches_reference(golden):
     _lib.call("ka_clip_adam_step", tab, btd, bod, len(bt), partial, ctl, step, scaler, flags, None, 1.0, 2e-4, 0.9, 0.999, 1e-8, st())
     assert float(step) == 3.0 and all(torch.equal(a, b) for a, b in zip(before, params))
     assert scaler.cpu().tolist() == [32768.0, 1.0]
+
+
+def test_conv3x3_dgrad_fused_matches_unfused_sequence():
+    """ka_conv3x3_dgrad_fused == bn_bwd_apply -> conv (dgrad pack) -> relu_bn_bwd_reduce, incl. the dy side output."""
+    dt, code = torch.bfloat16, 1
+    B, C = 5, 128
+    g = torch.Generator().manual_seed(71)
+    dz = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    y = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    yprev = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    k = torch.cat([torch.rand(C, generator=g) + 0.5, 0.1 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)]).to(DEV)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    wp = pack(w, dt, 1, C, C)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    mu, istd = (0.1 * torch.randn(C, generator=g)).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    rows = _lib.query("ka_conv3x3_sqpart_rows", B)
+    # unfused reference sequence
+    dy_ref = torch.empty_like(dz)
+    _lib.call("ka_bn_bwd_apply", dz, y, k, dy_ref, B, C, code, st())
+    dh_ref, dg_ref, _ = run_conv(dy_ref, wp, B, C, C, dt)
+    da_ref = torch.empty_like(dz); s1, s2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.call("ka_relu_bn_bwd_reduce", dh_ref, yprev, sc, sh, mu, istd, da_ref, s1, s2, B, C, code, st())
+    # fused
+    dy, da, dg = torch.empty_like(dz), torch.empty_like(dz), torch.empty(B, C, device=DEV)
+    e1, e2 = torch.empty(rows, C, device=DEV), torch.empty(rows, C, device=DEV)
+    _lib.call("ka_conv3x3_dgrad_fused", dz, y, k, dy, wp, da, dg, yprev, sc, sh, mu, istd, e1, e2, B, C, C, code, st())
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy_ref)
+    assert torch.allclose(dg, dg_ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(da, da_ref)
+    # partial sums are taken from the bf16-rounded dh in both paths
+    assert torch.allclose(e1.sum(0), s1.sum(0), rtol=1e-4, atol=1e-3) and torch.allclose(e2.sum(0), s2.sum(0), rtol=1e-4, atol=1e-3)
+    # without the epilogue and without dy side output
+    out2 = torch.empty_like(dz)
+    _lib.call("ka_conv3x3_dgrad_fused", dz, y, k, None, wp, out2, None, None, None, None, None, None, None, None, B, C, C, code, st())
+    assert torch.equal(out2, dh_ref)

@@ -174,7 +174,7 @@ def main() -> None:
         dist.barrier()
     engine = model._hip_engine
     if not args.no_kernel_events:
-        engine.kernel_events = {"conv3x3": [], "wgrad": []}
+        engine.kernel_events = {"conv3x3": [], "wgrad": [], "conv3x3_fwd": []}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -204,10 +204,21 @@ def main() -> None:
             conv_flop = 2.0 * B * 81 * 9 * C * C
             avg = sum(conv_ms) / len(conv_ms)
             ach = conv_flop / (avg * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv, forward + dgrad launches)",
+            traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
+            pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
+            if pmc.exists() and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
+                rec = json.loads(pmc.read_text())["kernels"].get("conv3x3_kernel<bf16_t, 4, 2>")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv; forward + data-gradient launches, the "
+                                               "latter with fused BatchNorm-backward passes and concurrent with wgrad on a 2nd stream)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
+                    "traffic": traffic, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
                     "flop_per_launch": conv_flop}
+            fwd_ms = [a.elapsed_time(b) for a, b in ev.get("conv3x3_fwd", [])]
+            if fwd_ms:
+                favg = sum(fwd_ms) / len(fwd_ms)
+                extra["conv3x3_forward_launches_only"] = {"avg_launch_ms": round(favg, 4), "launches_timed": len(fwd_ms),
+                                                          "achieved_tflops": round(conv_flop / (favg * 1e-3) / 1e12, 1)}
             if ev["wgrad"]:
                 w_ms = [a.elapsed_time(b) for a, b in ev["wgrad"]]
                 wavg = sum(w_ms) / len(w_ms)

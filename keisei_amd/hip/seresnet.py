@@ -49,6 +49,7 @@ class SEResNetEngine:
         self._side = None
         self._wslab: Optional[torch.Tensor] = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
+        self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
 
@@ -65,6 +66,8 @@ class SEResNetEngine:
         _call(name, *args)
         b.record(stream)
         ev[kind].append((a, b))
+        if kind == "conv3x3" and name == "ka_conv3x3_fwd" and "conv3x3_fwd" in ev and self._in_forward:
+            ev["conv3x3_fwd"].append((a, b))
 
     def notify_weights_updated(self) -> None:
         self.weights_epoch += 1
@@ -208,6 +211,7 @@ class SEResNetEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, obs: torch.Tensor, train: bool, keep: bool, T: torch.dtype, idx: Optional[torch.Tensor] = None):
+        self._in_forward = True
         m = self.model
         p = m.params
         dev = obs.device
@@ -292,6 +296,7 @@ class SEResNetEngine:
         s = self._linear(s1, m.score_fc2, 0, st)
         if keep:
             sv.heads = (x, pool, p1, scp, shp, mup, isp, p1r, v1, s1)
+        self._in_forward = False
         return logits, v, s, (sv if keep else None)
 
     # ------------------------------------------------------------------ backward

@@ -6,7 +6,7 @@
 // coalesced run along the channel axis.  One workgroup (4 waves) owns NB=2 whole boards and a
 // slab of output channels: the boards are staged ONCE into LDS as zero-haloed 11x11 tiles
 // ([padded square][channel]), after which each of the 9 taps is just a constant LDS offset
-// ((dy*11+dx)*row_stride) on the MFMA A-operand read -- the input is read from HBM exactly
+// ((dy*17+dx)*row_stride) on the MFMA A-operand read -- the input is read from HBM exactly
 // once per output-channel slab.  Weights are pre-packed (pack_conv3x3_kernel) in MFMA
 // B-fragment order so a wave streams them from L2 with perfectly coalesced 1 KiB loads
 // straight into registers; waves split the N (output channel) dimension, so no weight goes
@@ -29,6 +29,15 @@ namespace {
 constexpr int kNB = 2;                       // boards per workgroup
 constexpr int kRows = kNB * KA_BOARD;        // 162 GEMM rows
 constexpr int kMT = (kRows + 15) / 16;       // 11 row tiles
+// LDS image of the input: zero-haloed boards, [square][channel].  A padded board row is 17 squares wide (9 + halo,
+// widened so that stepping to the next board row advances the square index by 8 more than a neighbour step) and the
+// second board starts 193 squares after the first; with a row stride of 32 bytes more than a multiple of 256 a
+// 16-lane MFMA fragment read (16 consecutive GEMM rows x 16 bytes) then lands on 16 different 16-byte bank slots for
+// every tap -- conflict-free ds_read_b128, where the natural 11-wide image costs a 2-way conflict on every read.
+constexpr int kPW = 17;                      // squares per padded board row
+constexpr int kBoardStride = 193;            // squares between the two boards
+constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380
+__device__ __forceinline__ int lds_square(int b, int p) { return b * kBoardStride + (p / 9 + 1) * kPW + (p % 9) + 1; }
 
 struct ConvArgs {
     const void* in;
@@ -50,6 +59,7 @@ struct ConvArgs {
     const void* ep_y;
     const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_invstd;
     float* ep_s1; float* ep_s2;
+    int tune_stagger, tune_prio;  // experiments: s_sleep count / static priority of the second wave of every SIMD
     unsigned long long* stamps;   // diagnostic only: [workgroup][8] s_memtime at phase boundaries (null in production)
 };
 
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     const int b0 = blockIdx.x * kNB;
     const int NT = a.Cout >> 4;
     const int nt0 = blockIdx.y * (4 * NTW) + wave * NTW;
-    const int stride = a.KC * ESZ + 16;          // bytes per padded square (+16: bank spread)
+    const int stride = a.KC * ESZ + 32;          // bytes per padded square (+32: bank spread, see kPW)
     const int cpr = a.KC * ESZ / 16;             // 16-byte pieces per square
     const int KSG = a.Cin / CPK;                 // k-steps over all input channels
     const int KS = a.KC / CPK;                   // k-steps per LDS chunk
@@ -106,15 +116,15 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     for (int mt = 0; mt < kMTW; ++mt) {
         int m = (mt_base + mt) * 16 + r;
         if (m >= kRows) m = 0;                   // dummy rows read valid LDS; never stored
-        rowoff[mt] = ((m / KA_BOARD) * KA_PADBOARD + pad_index(m % KA_BOARD)) * stride + q * 16;
+        rowoff[mt] = lds_square(m / KA_BOARD, m % KA_BOARD) * stride + q * 16;
     }
 
     // zero the halo once (staging only ever writes interior squares)
-    for (int i = tid; i < kNB * KA_PADBOARD * cpr; i += kThreads) {
-        int idx = i / cpr, j = i - idx * cpr;
-        int pp = idx % KA_PADBOARD, yy = pp / 11, xx = pp - yy * 11;
-        if (yy == 0 || yy == 10 || xx == 0 || xx == 10)
-            *reinterpret_cast<uint4*>(smem + idx * stride + j * 16) = uint4{0, 0, 0, 0};
+    for (int i = tid; i < kLdsSquares * cpr; i += kThreads) {
+        const int idx = i / cpr, j = i - idx * cpr;
+        const int pp = idx >= kBoardStride ? idx - kBoardStride : idx, yy = pp / kPW, xx = pp - yy * kPW;
+        const bool interior = yy >= 1 && yy <= 9 && xx >= 1 && xx <= 9 && pp < 11 * kPW;
+        if (!interior) *reinterpret_cast<uint4*>(smem + idx * stride + j * 16) = uint4{0, 0, 0, 0};
     }
 
     const int sj = tid % cpr, spos0 = tid / cpr, sstep = kThreads / cpr;   // staging role of this thread
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                                 *reinterpret_cast<vec16*>(static_cast<char*>(a.in_out) +
                                                           ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ) = v[u];
                         }
-                        *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v[u];
+                        *reinterpret_cast<vec16*>(smem + lds_square(b, p) * stride + sj * 16) = v[u];
                     }
                 }
             } else {
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                         }
                         v[u] = E::pack(f);
                     }
-                    *reinterpret_cast<vec16*>(smem + (b * KA_PADBOARD + pad_index(p)) * stride + sj * 16) = v[u];
+                    *reinterpret_cast<vec16*>(smem + lds_square(b, p) * stride + sj * 16) = v[u];
                 }
             }
                     }
@@ -231,6 +241,10 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
         // ping-ponged between two named register sets (no conditional loads, no register copies) so the
         // compiler's vmcnt bookkeeping leaves the next step's loads in flight under this step's MFMAs.
         if (wave_active) {
+            if (WM == 2 && kc == 0 && __builtin_amdgcn_readfirstlane(mhalf) == 1) {
+                if (a.tune_prio) __builtin_amdgcn_s_setprio(1);
+                for (int z = 0; z < a.tune_stagger; ++z) __builtin_amdgcn_s_sleep(2);
+            }
             const int nsteps = 9 * KS;
             const char* wchunk = wbase + (size_t)(kc * KS) * ks_stride;
             // tile indices beyond NT (partial last wave) are clamped: they load valid bytes that are never stored
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
             };
             auto lds_off = [&](int step) {
                 const int tap = step / KS, ks = step - tap * KS;
-                return ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * stride + ks * 64;
+                return ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * stride + ks * 64;
             };
             // A fragments are double-buffered in registers across steps: while step s multiplies from `ac`, the
             // 11 LDS reads of step s+1 land in `an` (a whole step of MFMA time to hide LDS latency/conflicts).
@@ -496,7 +510,7 @@ template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
-    const size_t lds_in = (size_t)kNB * KA_PADBOARD * (a.KC * E::kSize + 16);
+    const size_t lds_in = (size_t)kLdsSquares * (a.KC * E::kSize + 32);
     const size_t lds_out = ((E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0) + (size_t)WM * BN * 3 * sizeof(float) +
                            (a.ep_y ? (size_t)256 * WM * 16 * sizeof(float) : 0);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
@@ -523,17 +537,20 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
                "conv3x3: need Cin %% %d == 0 and Cout %% 16 == 0 (got Cin=%d Cout=%d)", CPK, a.Cin, a.Cout);
     // largest LDS chunk that fits: 2 boards x 121 squares x (KC*size+16) <= 160 KiB
     int kc = a.Cin;
-    while ((size_t)kNB * KA_PADBOARD * (kc * E::kSize + 16) > 150 * 1024) {
+    while ((size_t)kLdsSquares * (kc * E::kSize + 32) > 150 * 1024) {
         KA_REQUIRE(kc % 2 == 0 && (kc / 2) % CPK == 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
         kc /= 2;
     }
     if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;   // measured: 2 chunks of 128 beat one of 256
     int ntw = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
     int wm = 2;
+    a.tune_prio = 1;          // measured -3 %: static priority for the second wave of every SIMD
     // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave, waves along M
     if (const char* e = getenv("KA_CONV_KC")) { const int v = atoi(e); if (v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v; }
     if (const char* e = getenv("KA_CONV_NTW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ntw = v; }
     if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }
+    if (const char* e = getenv("KA_CONV_STAGGER")) a.tune_stagger = atoi(e);
+    if (const char* e = getenv("KA_CONV_PRIO")) a.tune_prio = atoi(e);
     KA_REQUIRE((256 * wm) % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
     if (wm == 2) {
@@ -553,7 +570,7 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
                               const float* in_shift, const float* in_bias, int relu, float* bsum, float* sqpart,
                               int B, int Cin, int Cout, int dtype, void* stream) {
     ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu,
-               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g_stamps};
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, g_stamps};
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -575,7 +592,7 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
     KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused: bf16 only");
     KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused: epilogue tensors");
     ConvArgs a{in, wpack, out, k, k + Cin, nullptr, bsum, nullptr, B, Cin, Cout, 0, 0,
-               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, g_stamps};
+               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps};
     return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
 }
 

@@ -247,14 +247,30 @@ class SEResNetEngine:
         sv.blocks = []
 
         # ---- tower
+        fside = self._wgrad_side(1, dev)[0] if self.overlap_wgrad else None
+        main_f = torch.cuda.current_stream(dev)
         for i, blk in enumerate(m.blocks):
+            # g = global_fc(pool(x)) is only needed by conv2: run its two small GEMMs on the side stream while conv1
+            # occupies the main stream
+            if fside is not None:
+                ev = torch.cuda.Event(); ev.record(main_f)
+                with torch.cuda.stream(fside):
+                    fside.wait_event(ev)
+                    sts = _lib.stream_ptr(dev)
+                    g1 = self._linear(pool, blk.global_fc[0], 1, sts)
+                    g = self._linear(g1, blk.global_fc[2], 0, sts)
+                    g_ready = torch.cuda.Event(); g_ready.record(fside)
+                g1.record_stream(main_f); g.record_stream(main_f)
+            else:
+                g1 = self._linear(pool, blk.global_fc[0], 1, st)
+                g = self._linear(g1, blk.global_fc[2], 0, st)
             y1 = new_act(C)
             bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
                   bsum1 if train else None, sq1 if train else None, B, C, C, code, st)
             sc1, sh1, mu1, is1 = self._bn_forward(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
-            g1 = self._linear(pool, blk.global_fc[0], 1, st)
-            g = self._linear(g1, blk.global_fc[2], 0, st)
+            if fside is not None:
+                main_f.wait_event(g_ready)               # global-pool FC chain ran on the side stream beside conv1
             y2 = new_act(C)
             bsum2 = torch.empty(B, C, device=dev); sq2 = torch.empty(rows, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
@@ -457,7 +473,9 @@ class SEResNetEngine:
         _call("ka_bn_bwd_apply", dout, y0, k0, dout, B, C, code, st)
         dW0 = torch.empty_like(m.input_conv.weight)
         cin_pad = sv.xin.shape[2]
-        _call("ka_conv3x3_wgrad", dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad, p.obs_channels, C, 0, 0, code, st)
+        # on the wgrad stream as well: the partial-slab buffer is shared with the tower wgrads still running there
+        self._wgrad_launch(side, main, (dout, dW0), dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad,
+                           p.obs_channels, C, 0, 0, code)
         grads["input_conv.weight"] = dW0
         if side is not None:
             main.wait_stream(side)          # every dW is complete before autograd hands the gradients on

@@ -25,7 +25,14 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
-if which == "conv":
+if which == "tune":
+    os.environ["KA_CONV_KC"] = "128"; os.environ["KA_CONV_NTW"] = "4"; os.environ["KA_CONV_WM"] = "2"
+    for rep in range(2):
+        for stg, prio in [(0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (0, 1), (2, 1), (3, 1)]:
+            os.environ["KA_CONV_STAGGER"] = str(stg); os.environ["KA_CONV_PRIO"] = str(prio)
+            ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr()), n=20)
+            print(f"stagger={stg} prio={prio}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
+elif which == "conv":
     for kc, ntw, wm in [(256, 4, 1), (128, 4, 1), (256, 4, 2), (128, 4, 2), (64, 4, 2), (128, 2, 2), (64, 2, 2)]:
         os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = str(wm)
         for name, args in (("plain", (None, None, None, 0)), ("fused", (sc, sh, g, 1))):

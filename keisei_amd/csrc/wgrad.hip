@@ -275,18 +275,29 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[n][c][tap] (Cout, Cin_real, 3, 3) = sum_s slab[s][tap][n][c]; optional accumulate into dW
+// dW[n][c][tap] (Cout, Cin_real, 3, 3) = sum_s slab[s][tap][n][c]; optional accumulate into dW.
+// One thread sums 4 consecutive c of one (tap, n) over the splits: the slab reads -- nsplit times the bytes of the
+// result -- are whole coalesced 16-byte pieces in slab order; only the 4-byte result stores are strided (by 9).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout,
                                     int Cin, int Cin_real, int accumulate) {
-    const size_t total = (size_t)Cout * Cin_real * 9;
+    const int c4n = Cin >> 2;                                      // Cin % 4 == 0 (checked by the launcher)
+    const size_t total = (size_t)9 * Cout * c4n, sstride = (size_t)9 * Cout * c4n;   // in 16-byte pieces
+    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(slab);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int tap = i % 9;
-        const size_t nc = i / 9;
-        const int c = nc % Cin_real, n = nc / Cin_real;
-        const size_t src = ((size_t)tap * Cout + n) * Cin + c, sstride = (size_t)9 * Cout * Cin;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[src + k * sstride];
-        dw[i] = accumulate ? dw[i] + s : s;
+        const int c4 = (int)(i % c4n);
+        const size_t tn = i / c4n;
+        const int n = (int)(tn % Cout), tap = (int)(tn / Cout);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k = 0; k < nsplit; ++k) acc += s4[i + k * sstride];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            if (c < Cin_real) {
+                const size_t o = ((size_t)n * Cin_real + c) * 9 + tap;
+                dw[o] = accumulate ? dw[o] + acc[e] : acc[e];
+            }
+        }
     }
 }
 
@@ -346,8 +357,8 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     }
     int rc = ka_check_launch("wgrad");
     if (rc) return rc;
-    const size_t total = (size_t)Cout * Cin_real * 9;
-    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    const size_t total = (size_t)9 * Cout * (Cin / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, dw, nsplit, Cout, Cin, Cin_real,
                        accumulate);
     return ka_check_launch("wgrad_reduce");

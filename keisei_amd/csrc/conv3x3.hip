@@ -3,19 +3,26 @@
 //   out[b,p,n] = sum_{tap,c} X'[b, p+tap, c] * W[n,c,tap]      X' = optional fused transform of the input
 //
 // Layout: activations are NHWC (B,81,C), channel-contiguous, so every HBM access is a
-// coalesced run along the channel axis.  One workgroup (4 waves) owns NB=2 whole boards and a
-// slab of output channels: the boards are staged ONCE into LDS as zero-haloed 11x11 tiles
-// ([padded square][channel]), after which each of the 9 taps is just a constant LDS offset
-// ((dy*17+dx)*row_stride) on the MFMA A-operand read -- the input is read from HBM exactly
-// once per output-channel slab.  Weights are pre-packed (pack_conv3x3_kernel) in MFMA
-// B-fragment order so a wave streams them from L2 with perfectly coalesced 1 KiB loads
-// straight into registers; waves split the N (output channel) dimension, so no weight goes
-// through LDS.  M = 162 rows is padded to 11 tiles of 16 (v_mfma_f32_16x16x32_bf16 /
-// 4x v_mfma_f32_16x16x4_f32); the f32 path is an exact fmaf chain (parity mode), the bf16
-// path is the throughput mode.
+// coalesced run along the channel axis.  One workgroup (8 waves, two per SIMD) owns NB=2 whole
+// boards and a slab of output channels: the boards are staged ONCE into LDS as zero-haloed
+// 17-wide tiles ([padded square][channel]), after which each of the 9 taps is just a constant
+// LDS offset ((dy*17+dx)*row_stride) on the MFMA operand read -- the input is read from HBM
+// exactly once per output-channel slab.  Weights are pre-packed (pack_conv3x3_kernel) in MFMA
+// fragment order so a wave streams them from L2 with perfectly coalesced 1 KiB loads straight
+// into registers; no weight goes through LDS.
 //
-// The epilogue fuses what the following BatchNorm / squeeze-excite need: per-board channel
-// sums (= SE squeeze, and summed over boards the BN mean) and per-workgroup sums of squares.
+// Wave tile: wave (h, w) owns board h of the pair -- its 81 squares padded to 6 row tiles of 16
+// -- and the w-th quarter of the channel slab.  The weights are the MFMA "A" operand and the
+// activations the "B" operand, i.e. the kernel computes out^T: an accumulator lane then holds
+// 4 CONSECUTIVE channel slots of one square, and the pack interleaves neighbouring 16-channel
+// tiles so that a lane owns runs of 8 consecutive channels.  The epilogue therefore works
+// entirely in registers: the per-board channel sums (= SE squeeze, and summed over boards the
+// BN mean) and sums of squares are DPP reductions over the 16 square lanes of a wave that owns
+// the whole board, and the output tile is stored straight from the accumulators in 16-byte
+// pieces -- no LDS transpose and no barrier after the main loop, so the wave of a SIMD that
+// finishes first (static priority) runs its epilogue under the other wave's MFMAs.
+// (v_mfma_f32_16x16x32_bf16 / 4x v_mfma_f32_16x16x4_f32; the f32 path is exact f32 (parity
+// mode), the bf16 path is the throughput mode.)
 //
 // The same kernel is the data-gradient conv: pack with flip+transpose (mode 1).
 //
@@ -38,6 +45,23 @@ constexpr int kPW = 17;                      // squares per padded board row
 constexpr int kBoardStride = 193;            // squares between the two boards
 constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380
 __device__ __forceinline__ int lds_square(int b, int p) { return b * kBoardStride + (p / 9 + 1) * kPW + (p % 9) + 1; }
+constexpr int kMTW = 6;                      // row tiles per wave: one board, 81 squares padded to 96 rows
+
+// output-channel slot permutation of the weight pack: MFMA row s of tile nt multiplies output channel chan_of(nt, s).
+// The two tiles of a pair are interleaved in groups of 4 so that accumulator lane q (rows 4q..4q+3 of both tiles)
+// owns the 8 consecutive channels pair*32 + 8q .. +7.  A lone last tile keeps the identity order.
+__host__ __device__ __forceinline__ int chan_of(int nt, int s, int NT) {
+    return ((nt | 1) < NT) ? (nt >> 1) * 32 + (s >> 2) * 8 + (nt & 1) * 4 + (s & 3) : nt * 16 + s;
+}
+
+// sum over the 16 lanes of a DPP row (lanes that share lane>>4); every lane ends up with the total
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm 1,0,3,2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm 2,3,0,1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 
 struct ConvArgs {
     const void* in;
@@ -47,15 +71,15 @@ struct ConvArgs {
     const float* in_shift;
     const float* in_bias;    // [B,Cin] or null: per-board bias added after the ReLU
     float* bsum;             // [B,Cout] or null
-    float* sqpart;           // [gridDim.x, Cout] or null
+    float* sqpart;           // [B, Cout] or null: per-board sums of squares
     int B, Cin, Cout, KC, relu;
     // fused BatchNorm-backward input (data-gradient convs): x' = in*in_scale + in_shift + in2*in_k3, optionally
     // written back to in_out (the materialised dy the weight-gradient kernel reads)
     const void* in2;
     const float* in_k3;
     void* in_out;
-    // fused ReLU+BatchNorm-backward epilogue (bf16): out = acc * [ep_scale*ep_y + ep_shift > 0]; per-workgroup partial
-    // sums ep_s1[wg][n] = sum out, ep_s2[wg][n] = sum out*(ep_y-ep_mean)*ep_invstd
+    // fused ReLU+BatchNorm-backward epilogue (bf16): out = acc * [ep_scale*ep_y + ep_shift > 0]; per-board partial
+    // sums ep_s1[b][n] = sum out, ep_s2[b][n] = sum out*(ep_y-ep_mean)*ep_invstd
     const void* ep_y;
     const float* ep_scale; const float* ep_shift; const float* ep_mean; const float* ep_invstd;
     float* ep_s1; float* ep_s2;
@@ -82,20 +106,18 @@ template <> struct Mma<float> {
     }
 };
 
-// WM = waves along M: 1 -> 4 waves, each owns all 11 row tiles of its output-channel slice;
-//                     2 -> 8 waves (2 per SIMD), each owns 6 row tiles: half the accumulators per wave, and a
-//                          second wave per SIMD whose MFMAs fill the first one's LDS/L2 stalls
+// NTW = 16-channel tiles per wave (the workgroup's slab is 4*NTW tiles wide); WM = waves along M, always 2: the
+// second wave of every SIMD owns the second board, and its MFMAs fill the first one's LDS/L2 stalls
 template <typename T, int NTW, int WM>
 __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
+    static_assert(WM == 2, "one wave group per board");
     constexpr int kThreads = 256 * WM;
-    constexpr int kMTW = (kMT + WM - 1) / WM;        // row tiles per wave
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int ESZ = E::kSize, P16 = E::kPer16, CPK = 4 * P16;   // channels per k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mhalf = tid >> 8;
-    const int mt_base = mhalf * kMTW;
     const int r = lane & 15, q = lane >> 4;
     const int b0 = blockIdx.x * kNB;
     const int NT = a.Cout >> 4;
@@ -114,9 +136,9 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     int rowoff[kMTW];
 #pragma unroll
     for (int mt = 0; mt < kMTW; ++mt) {
-        int m = (mt_base + mt) * 16 + r;
-        if (m >= kRows) m = 0;                   // dummy rows read valid LDS; never stored
-        rowoff[mt] = lds_square(m / KA_BOARD, m % KA_BOARD) * stride + q * 16;
+        int p = mt * 16 + r;                     // square of board `mhalf`
+        if (p >= KA_BOARD) p = 0;                // dummy rows read valid LDS; never stored
+        rowoff[mt] = lds_square(mhalf, p) * stride + q * 16;
     }
 
     // zero the halo once (staging only ever writes interior squares)
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                     anext[mt] = av[mt];
 #endif
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(av[mt], bw[j], acc[mt][j]);
+                    for (int j = 0; j < NTW; ++j) acc[mt][j] = Mma<T>::run(bw[j], av[mt], acc[mt][j]);
                 }
                 // pin the issue order: one LDS read ahead of every group of MFMAs (the scheduler otherwise
                 // sinks all 11 reads behind the MFMA block and the next step starts by waiting for them)
@@ -320,166 +342,119 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     }
 
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 2] = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: statistics from the fp32 accumulators, then the output tile
-    const bool v0 = b0 < a.B, v1 = b0 + 1 < a.B;
-    constexpr int BN = 4 * NTW * 16;                 // output channels of this workgroup
-    constexpr int ostride = BN * 2 + 16;
-    float* stat_lds = reinterpret_cast<float*>(smem + (sizeof(T) == 2 ? kMT * 16 * ostride : 0));   // [WM][BN][3]
-    const bool want_stats = a.bsum || a.sqpart;
-    float s0[NTW], s1[NTW], ss[NTW];
-    if (wave_active && want_stats) {
+    // ---- epilogue, all in registers: lane (r, q) holds square mt*16+r of board bb for every row tile mt, and for
+    // tile j the 4 consecutive channels cb[j] .. cb[j]+3 (tiles 2k and 2k+1 together: 8 consecutive channels)
+    const int bb = b0 + mhalf;
+    if (wave_active && bb < a.B) {
+        int cb[NTW];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            s0[j] = s1[j] = ss[j] = 0.f;
+        for (int j = 0; j < NTW; ++j) cb[j] = chan_of(min(nt0 + j, NT - 1), 4 * q, NT);
+        if (a.bsum || a.sqpart) {
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt)
+            for (int j = 0; j < NTW; ++j) {
+                float s0[4], ss[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = (mt_base + mt) * 16 + q * 4 + i;
-                    const float v = acc[mt][j][i];
-                    if (m < KA_BOARD) { s0[j] += v; ss[j] += v * v; }
-                    else if (m < kRows) { s1[j] += v; ss[j] += v * v; }
-                }
-            s0[j] += __shfl_xor(s0[j], 16); s0[j] += __shfl_xor(s0[j], 32);
-            s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
-            ss[j] += __shfl_xor(ss[j], 16); ss[j] += __shfl_xor(ss[j], 32);
-        }
-    }
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 3] = __builtin_amdgcn_s_memtime();
-    if (WM > 1 || sizeof(T) == 2) __syncthreads();   // all waves done reading the input tile
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 4] = __builtin_amdgcn_s_memtime();
-    if (WM > 1 && wave_active && want_stats && mhalf == 1 && q == 0) {
+                for (int i = 0; i < 4; ++i) { s0[i] = 0.f; ss[i] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            float* d = stat_lds + ((wave * NTW + j) * 16 + r) * 3;
-            d[0] = s0[j]; d[1] = s1[j]; d[2] = ss[j];
-        }
-    }
-    if constexpr (sizeof(T) == 2) {
-        // transpose through LDS so HBM sees whole 16-byte pieces of contiguous rows
-        if (wave_active) {
-#pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const bool in = mt * 16 + r < KA_BOARD;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int m = (mt_base + mt) * 16 + q * 4 + i;
-                        if (m < kMT * 16)
-                            *reinterpret_cast<uint16_t*>(smem + m * ostride + ((wave * NTW + j) * 16 + r) * 2) =
-                                f2bf(acc[mt][j][i]);
+                        const float v = in ? acc[mt][j][i] : 0.f;
+                        s0[i] += v; ss[i] += v * v;
                     }
-        }
-    }
-    if (WM > 1 || sizeof(T) == 2) __syncthreads();
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 5] = __builtin_amdgcn_s_memtime();
-    if (wave_active && want_stats && mhalf == 0 && q == 0) {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            if (nt0 + j >= NT) continue;
-            float t0 = s0[j], t1 = s1[j], t2 = ss[j];
-            if (WM > 1) {
-                const float* d = stat_lds + ((wave * NTW + j) * 16 + r) * 3;
-                t0 += d[0]; t1 += d[1]; t2 += d[2];
-            }
-            const int n = (nt0 + j) * 16 + r;
-            if (a.bsum) {
-                if (v0) a.bsum[(size_t)b0 * a.Cout + n] = t0;
-                if (v1) a.bsum[(size_t)(b0 + 1) * a.Cout + n] = t1;
-            }
-            if (a.sqpart) a.sqpart[(size_t)blockIdx.x * a.Cout + n] = t2;
-        }
-    }
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 6] = __builtin_amdgcn_s_memtime();
-    if constexpr (sizeof(T) == 2) {
-        const int n_wg0 = blockIdx.y * BN;
-        const int ncols = min(BN, a.Cout - n_wg0);   // multiple of 16
-        const int ppr = ncols / 8;                   // 16-byte pieces per row
-        const int rows = v1 ? kRows : (v0 ? KA_BOARD : 0);
-        if (!a.ep_y) {
-            for (int i = tid; i < rows * ppr; i += kThreads) {
-                const int m = i / ppr, pc = i - m * ppr;
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + m * ostride + pc * 16);
-                *reinterpret_cast<uint4*>(static_cast<char*>(a.out) +
-                                          ((size_t)(b0 * KA_BOARD + m) * a.Cout + n_wg0 + pc * 8) * 2) = v;
-            }
-        } else {
-            // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da (this thread always
-            // handles the same 8 channels: kThreads % ppr == 0)
-            const int pc = tid % ppr, n8 = n_wg0 + pc * 8;
-            float esc[8], esh[8], emu[8], eis[8], s1[8], s2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                esc[e] = a.ep_scale[n8 + e]; esh[e] = a.ep_shift[n8 + e];
-                emu[e] = a.ep_mean[n8 + e]; eis[e] = a.ep_invstd[n8 + e];
-                s1[e] = 0.f; s2[e] = 0.f;
-            }
-            // all y pieces of this thread are requested up front (one HBM round trip instead of one per row)
-            // (rows per thread = 162 / (kThreads/ppr) <= kMaxIt because ppr <= 32)
-            constexpr int kMaxIt = (kRows + (kThreads / 32) - 1) / (kThreads / 32);
-            const int mstep = kThreads / ppr, m_first = tid / ppr;
-            bf16x8 yv[kMaxIt];
-#pragma unroll
-            for (int it = 0; it < kMaxIt; ++it) {
-                const int m = m_first + it * mstep;
-                yv[it] = (m < rows) ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) +
-                                          ((size_t)(b0 * KA_BOARD + m) * a.Cout + n8) * 2) : bf16x8{};
-            }
-#pragma unroll
-            for (int it = 0; it < kMaxIt; ++it) {
-                const int m = m_first + it * mstep;
-                if (m >= rows) continue;
-                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(smem + m * ostride + pc * 16);
-                bf16x8 ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float y = (float)yv[it][e];
-                    const float d = (y * esc[e] + esh[e] > 0.f) ? (float)dv[e] : 0.f;
-                    s1[e] += d; s2[e] += d * ((y - emu[e]) * eis[e]);
-                    ov[e] = (__bf16)d;
                 }
-                *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + ((size_t)(b0 * KA_BOARD + m) * a.Cout + n8) * 2) = ov;
-            }
-            // combine the kThreads/ppr row-slices of every channel octet (region after the output tile + stats)
-            float* red = stat_lds + WM * BN * 3;                      // [slice][ppr*8][2]
-            const int slice = tid / ppr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[((slice * ppr + pc) * 8 + e) * 2] = s1[e];
-                red[((slice * ppr + pc) * 8 + e) * 2 + 1] = s2[e];
-            }
-            __syncthreads();
-            if (tid < ncols) {
-                float t1 = 0.f, t2 = 0.f;
-                for (int sl = 0; sl < kThreads / ppr; ++sl) { t1 += red[(sl * ncols + tid) * 2]; t2 += red[(sl * ncols + tid) * 2 + 1]; }
-                a.ep_s1[(size_t)blockIdx.x * a.Cout + n_wg0 + tid] = t1;
-                a.ep_s2[(size_t)blockIdx.x * a.Cout + n_wg0 + tid] = t2;
+                for (int i = 0; i < 4; ++i) { s0[i] = row_sum16(s0[i]); ss[i] = row_sum16(ss[i]); }
+                if (r == 0 && nt0 + j < NT) {
+                    if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+                    if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + (size_t)bb * a.Cout + cb[j]) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+                }
             }
         }
-    } else {
-        if (wave_active) {
-            float* out = static_cast<float*>(a.out);
+        if constexpr (sizeof(T) == 2) {
+            if (!a.ep_y) {
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt)
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const int p = mt * 16 + r;
+                    if (p >= KA_BOARD) continue;
+                    char* orow = static_cast<char*>(a.out) + (size_t)(bb * KA_BOARD + p) * a.Cout * 2;
+                    if constexpr (NTW >= 2) {
+#pragma unroll
+                        for (int j = 0; j < NTW; j += 2) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { o[i] = (__bf16)acc[mt][j][i]; o[4 + i] = (__bf16)acc[mt][j + 1][i]; }
+                            if (nt0 + j < NT) *reinterpret_cast<bf16x8*>(orow + cb[j] * 2) = o;
+                        }
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)acc[mt][0][i];
+                        *reinterpret_cast<bf16x4*>(orow + cb[0] * 2) = o;
+                    }
+                }
+            } else {
+                // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da, one tile at a time
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     if (nt0 + j >= NT) continue;
+                    bf16x4 yv[kMTW];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = (mt_base + mt) * 16 + q * 4 + i;
-                        const bool ok = (m < KA_BOARD) ? v0 : (m < kRows && v1);
-                        if (ok) out[(size_t)(b0 * KA_BOARD + m) * a.Cout + (nt0 + j) * 16 + r] = acc[mt][j][i];
+                    for (int mt = 0; mt < kMTW; ++mt) {
+                        const int p = mt * 16 + r;
+                        yv[mt] = bf16x4{};
+                        if (p < KA_BOARD)
+                            yv[mt] = *reinterpret_cast<const bf16x4*>(static_cast<const char*>(a.ep_y) +
+                                                                      ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2);
+                    }
+                    const f32x4 esc = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]);
+                    const f32x4 esh = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
+                    const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]);
+                    const f32x4 eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
+                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < kMTW; ++mt) {
+                        const int p = mt * 16 + r;
+                        const bool in = p < KA_BOARD;
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float y = (float)yv[mt][i];
+                            const __bf16 db = (__bf16)acc[mt][j][i];
+                            const float d = (in && y * esc[i] + esh[i] > 0.f) ? (float)db : 0.f;
+                            t1[i] += d; t2[i] += d * ((y - emu[i]) * eis[i]);
+                            o[i] = (__bf16)d;
+                        }
+                        if (in) *reinterpret_cast<bf16x4*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2) = o;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { t1[i] = row_sum16(t1[i]); t2[i] = row_sum16(t2[i]); }
+                    if (r == 0) {
+                        *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+                        *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
                     }
                 }
+            }
+        } else {
+            float* out = static_cast<float*>(a.out);
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                const int p = mt * 16 + r;
+                if (p >= KA_BOARD) continue;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    if (nt0 + j < NT) *reinterpret_cast<f32x4*>(out + (size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) = acc[mt][j];
+            }
         }
     }
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 
-// Pack (Co,Ci,3,3) fp32 weights into MFMA B-fragment order.
+// Pack (Co,Ci,3,3) fp32 weights into MFMA fragment order.
 //   mode 0 (forward): out-channel n = co, in-channel c = ci (zero-padded to Ci_pad), tap = ky*3+kx
 //   mode 1 (dgrad)  : out-channel n = ci, in-channel c = co, tap flipped (8 - tap)
-// dst[((tap*KSG + ks)*NT + nt)*64 + lane] (16 bytes) = W'[n = nt*16 + (lane&15)][c = ks*CPK + (lane>>4)*P16 + e][tap]
+// dst[((tap*KSG + ks)*NT + nt)*64 + lane] (16 bytes) = W'[n = chan_of(nt, lane&15)][c = ks*CPK + (lane>>4)*P16 + e][tap]
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, void* __restrict__ dst, int Co, int Ci,
                                     int Nout, int Kin, int mode) {
@@ -492,7 +467,7 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, void* __restric
         size_t t = i >> 6;
         const int nt = t % NT; t /= NT;
         const int ks = t % KSG; const int tap = t / KSG;
-        const int n = nt * 16 + (lane & 15);
+        const int n = chan_of(nt, lane & 15, NT);
         float f[P16];
 #pragma unroll
         for (int e = 0; e < P16; ++e) {
@@ -510,10 +485,7 @@ template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
-    const size_t lds_in = (size_t)kLdsSquares * (a.KC * E::kSize + 32);
-    const size_t lds_out = ((E::kSize == 2) ? (size_t)kMT * 16 * (BN * 2 + 16) : 0) + (size_t)WM * BN * 3 * sizeof(float) +
-                           (a.ep_y ? (size_t)256 * WM * 16 * sizeof(float) : 0);
-    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    const size_t lds = (size_t)kLdsSquares * (a.KC * E::kSize + 32);
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -543,24 +515,17 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     }
     if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;   // measured: 2 chunks of 128 beat one of 256
     int ntw = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
-    int wm = 2;
-    a.tune_prio = 1;          // measured -3 %: static priority for the second wave of every SIMD
-    // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave, waves along M
+    a.tune_prio = 1;          // static priority for the second wave of every SIMD: it reaches its epilogue first
+    // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave
     if (const char* e = getenv("KA_CONV_KC")) { const int v = atoi(e); if (v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v; }
     if (const char* e = getenv("KA_CONV_NTW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ntw = v; }
-    if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }
     if (const char* e = getenv("KA_CONV_STAGGER")) a.tune_stagger = atoi(e);
     if (const char* e = getenv("KA_CONV_PRIO")) a.tune_prio = atoi(e);
-    KA_REQUIRE((256 * wm) % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
+    KA_REQUIRE(512 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
-    if (wm == 2) {
-        if (ntw == 4) return launch_conv<T, 4, 2>(a, st);
-        if (ntw == 2) return launch_conv<T, 2, 2>(a, st);
-        return launch_conv<T, 1, 2>(a, st);
-    }
-    if (ntw == 4) return launch_conv<T, 4, 1>(a, st);
-    if (ntw == 2) return launch_conv<T, 2, 1>(a, st);
-    return launch_conv<T, 1, 1>(a, st);
+    if (ntw == 4) return launch_conv<T, 4, 2>(a, st);
+    if (ntw == 2) return launch_conv<T, 2, 2>(a, st);
+    return launch_conv<T, 1, 2>(a, st);
 }
 
 }  // namespace
@@ -600,7 +565,7 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
 // s_memtime counts shader clocks); pass null to switch off
 extern "C" int ka_debug_conv_stamps(unsigned long long* stamps) { g_stamps = stamps; return KA_OK; }
 
-extern "C" int ka_conv3x3_sqpart_rows(int B) { return (B + kNB - 1) / kNB; }
+extern "C" int ka_conv3x3_sqpart_rows(int B) { return B; }
 
 extern "C" int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int Nout, int Kin, int mode, int dtype,
                                void* stream) {

@@ -1,6 +1,6 @@
 """Diagnostic: where does a conv3x3 workgroup spend its cycles? (s_memtime stamps at phase boundaries)"""
 import os, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from keisei_amd import _lib
 B, C = 4096, 256
@@ -11,9 +11,9 @@ wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=dev
 _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, code, _lib.stream_ptr())
 out = torch.empty_like(x); rows = _lib.query("ka_conv3x3_sqpart_rows", B)
 bsum = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)
-for kc, ntw, wm in [(128, 4, 2), (256, 4, 2), (128, 4, 1)]:
+for kc, ntw, wm in [(128, 4, 2), (64, 4, 2)]:
     os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = str(wm)
-    nwg = rows * (4 // ntw if ntw < 4 else 1)
+    nwg = (B + 1) // 2
     for _ in range(3):
         _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())
     stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
@@ -22,6 +22,5 @@ for kc, ntw, wm in [(128, 4, 2), (256, 4, 2), (128, 4, 1)]:
     torch.cuda.synchronize()
     _lib.call("ka_debug_conv_stamps", None)
     s = stamps.cpu().view(nwg, 8).double()
-    d = (s[:, 1:] - s[:, :-1]).mean(0)
     tot = (s[:, 7] - s[:, 0]).mean()
-    print(f"KC={kc} NTW={ntw} WM={wm}: stage {d[0]:.0f} main {d[1]:.0f} | stats-shuffle {d[2]:.0f} sync1 {d[3]:.0f} lds-write+sync2 {d[4]:.0f} stats-store {d[5]:.0f} copy-out {d[6]:.0f} | total {tot:.0f}")
+    print(f"KC={kc} NTW={ntw}: stage0 {(s[:, 1] - s[:, 0]).mean():.0f}  chunks {(s[:, 2] - s[:, 1]).mean():.0f}  epilogue(wave 0) {(s[:, 7] - s[:, 2]).mean():.0f} | total {tot:.0f}")

@@ -42,7 +42,7 @@ const char* ka_last_error(void);           /* message of the last failing call o
  * Optional fused input transform x' = relu?(x*in_scale[c] + in_shift[c]) + in_bias[b,c] reproduces
  * `F.relu(self.bn1(...)) + g.unsqueeze(-1).unsqueeze(-1)` (se_resnet.py:71,78) on the fly.
  * Epilogue outputs (optional): bsum[b,n] = sum over the 81 squares of the fp32 result (SE squeeze,
- * se_resnet.py:83, and the BatchNorm mean), sqpart[r,n] = per-workgroup sum of squares
+ * se_resnet.py:83, and the BatchNorm mean), sqpart[r,n] = per-board sum of squares
  * (r < ka_conv3x3_sqpart_rows(B)).  Requires Cin % 32 == 0 (bf16) / 16 (f32), Cout % 16 == 0. */
 int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale, const float* in_shift,
                    const float* in_bias, int relu, float* bsum, float* sqpart, int B, int Cin, int Cout, int dtype,

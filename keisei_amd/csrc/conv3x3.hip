@@ -33,9 +33,7 @@
 
 namespace {
 
-constexpr int kNB = 2;                       // boards per workgroup
-constexpr int kRows = kNB * KA_BOARD;        // 162 GEMM rows
-constexpr int kMT = (kRows + 15) / 16;       // 11 row tiles
+constexpr int kNB = 2;                       // boards per workgroup in the paired layout
 // LDS image of the input: zero-haloed boards, [square][channel].  A padded board row is 17 squares wide (9 + halo,
 // widened so that stepping to the next board row advances the square index by 8 more than a neighbour step) and the
 // second board starts 193 squares after the first; with a row stride of 32 bytes more than a multiple of 256 a
@@ -43,7 +41,7 @@ constexpr int kMT = (kRows + 15) / 16;       // 11 row tiles
 // every tap -- conflict-free ds_read_b128, where the natural 11-wide image costs a 2-way conflict on every read.
 constexpr int kPW = 17;                      // squares per padded board row
 constexpr int kBoardStride = 193;            // squares between the two boards
-constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380
+constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380 (two boards); a single-board image is 11 * kPW = 187
 __device__ __forceinline__ int lds_square(int b, int p) { return b * kBoardStride + (p / 9 + 1) * kPW + (p % 9) + 1; }
 constexpr int kMTW = 6;                      // row tiles per wave: one board, 81 squares padded to 96 rows
 
@@ -106,12 +104,15 @@ template <> struct Mma<float> {
     }
 };
 
-// NTW = 16-channel tiles per wave (the workgroup's slab is 4*NTW tiles wide); WM = waves along M, always 2: the
-// second wave of every SIMD owns the second board, and its MFMAs fill the first one's LDS/L2 stalls
+// NTW = 16-channel tiles per wave (the workgroup's slab is 4*NTW tiles wide).  WM = boards (= groups of 4 waves) per
+// workgroup: 2 -> 512 threads, the second wave of every SIMD owns the second board and its MFMAs fill the first one's
+// LDS/L2 stalls; 1 -> 256 threads and two INDEPENDENT workgroups per CU (registers capped at 256 by the launch
+// bounds), so that the staging and epilogue of one overlap the MFMA loop of the other.
 template <typename T, int NTW, int WM>
-__global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
-    static_assert(WM == 2, "one wave group per board");
+__global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     constexpr int kThreads = 256 * WM;
+    constexpr int kRows = WM * KA_BOARD;         // staged squares
+    constexpr int kImgSquares = WM == 2 ? kLdsSquares : 11 * kPW;
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int ESZ = E::kSize, P16 = E::kPer16, CPK = 4 * P16;   // channels per k-step
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, mhalf = tid >> 8;
     const int r = lane & 15, q = lane >> 4;
-    const int b0 = blockIdx.x * kNB;
+    const int b0 = blockIdx.x * WM;
     const int NT = a.Cout >> 4;
     const int nt0 = blockIdx.y * (4 * NTW) + wave * NTW;
     const int stride = a.KC * ESZ + 32;          // bytes per padded square (+32: bank spread, see kPW)
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
     }
 
     // zero the halo once (staging only ever writes interior squares)
-    for (int i = tid; i < kLdsSquares * cpr; i += kThreads) {
+    for (int i = tid; i < kImgSquares * cpr; i += kThreads) {
         const int idx = i / cpr, j = i - idx * cpr;
         const int pp = idx >= kBoardStride ? idx - kBoardStride : idx, yy = pp / kPW, xx = pp - yy * kPW;
         const bool interior = yy >= 1 && yy <= 9 && xx >= 1 && xx <= 9 && pp < 11 * kPW;
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + e]; sh[e] = a.in_shift[c0 + e]; }
             }
-            float gbv[kNB][P16];                 // per-board bias of this thread's channel piece, fetched once
+            float gbv[WM][P16];                 // per-board bias of this thread's channel piece, fetched once
             if (a.in_bias) {
 #pragma unroll
-                for (int b = 0; b < kNB; ++b)
+                for (int b = 0; b < WM; ++b)
 #pragma unroll
                     for (int e = 0; e < P16; ++e)
                         gbv[b][e] = (b0 + b < a.B) ? a.in_bias[(size_t)(b0 + b) * a.Cin + c0 + e] : 0.f;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                 float k3[P16];
 #pragma unroll
                 for (int e = 0; e < P16; ++e) k3[e] = a.in_k3[c0 + e];
-                constexpr int kU2 = (WM == 2) ? 6 : 4;
+                constexpr int kU2 = 6;
                 for (int pos0 = spos0; pos0 < kRows; pos0 += sstep * kU2) {
                     vec16 v[kU2], w[kU2];
 #pragma unroll
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
             } else {
             // loads are issued in batches of kUnr before any is consumed: the staging phase is otherwise a
             // chain of dependent HBM round trips (one per 16-byte piece per thread)
-            constexpr int kUnr = (WM == 2) ? 6 : 11;
+            constexpr int kUnr = 6;
             for (int pos0 = spos0; pos0 < kRows; pos0 += sstep * kUnr) {
                 vec16 v[kUnr];
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256 * WM) void conv3x3_kernel(ConvArgs a) {
                         }
                         if (a.in_bias) {
 #pragma unroll
-                            for (int e = 0; e < P16; ++e) f[e] += (b == 0 ? gbv[0][e] : gbv[1][e]);
+                            for (int e = 0; e < P16; ++e) f[e] += (WM == 1 || b == 0) ? gbv[0][e] : gbv[WM - 1][e];
                         }
                         v[u] = E::pack(f);
                     }
@@ -485,7 +486,7 @@ template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
-    const size_t lds = (size_t)kLdsSquares * (a.KC * E::kSize + 32);
+    const size_t lds = (size_t)(WM == 2 ? kLdsSquares : 11 * kPW) * (a.KC * E::kSize + 32);
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -496,7 +497,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         }
         attr_done = true;
     }
-    dim3 grid((a.B + kNB - 1) / kNB, (a.Cout + BN - 1) / BN);
+    dim3 grid((a.B + WM - 1) / WM, (a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM>), grid, dim3(256 * WM), lds, st, a);
     return ka_check_launch("conv3x3");
 }
@@ -507,13 +508,19 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     constexpr int CPK = 4 * E::kPer16;
     KA_REQUIRE(a.B > 0 && a.Cin % CPK == 0 && a.Cout % 16 == 0,
                "conv3x3: need Cin %% %d == 0 and Cout %% 16 == 0 (got Cin=%d Cout=%d)", CPK, a.Cin, a.Cout);
-    // largest LDS chunk that fits: 2 boards x 121 squares x (KC*size+16) <= 160 KiB
+    // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
+    int wm = 1;
+    if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }   // experiments
+    const int img_squares = wm == 2 ? kLdsSquares : 11 * kPW;
+    // largest LDS chunk that fits: squares x (KC*size + 32) <= 150 KiB
     int kc = a.Cin;
-    while ((size_t)kLdsSquares * (kc * E::kSize + 32) > 150 * 1024) {
+    while ((size_t)img_squares * (kc * E::kSize + 32) > 150 * 1024) {
         KA_REQUIRE(kc % 2 == 0 && (kc / 2) % CPK == 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
         kc /= 2;
     }
-    if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;   // measured: 2 chunks of 128 beat one of 256
+    // measured (bf16, C=256): 2 chunks of 128 beat one of 256 -- with one board per workgroup the smaller tile lets two
+    // workgroups share a CU, and inside the training step that is worth 15 %
+    if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;
     int ntw = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
     a.tune_prio = 1;          // static priority for the second wave of every SIMD: it reaches its epilogue first
     // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave
@@ -521,8 +528,13 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     if (const char* e = getenv("KA_CONV_NTW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ntw = v; }
     if (const char* e = getenv("KA_CONV_STAGGER")) a.tune_stagger = atoi(e);
     if (const char* e = getenv("KA_CONV_PRIO")) a.tune_prio = atoi(e);
-    KA_REQUIRE(512 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
+    KA_REQUIRE(256 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
+    if (wm == 1) {
+        if (ntw == 4) return launch_conv<T, 4, 1>(a, st);
+        if (ntw == 2) return launch_conv<T, 2, 1>(a, st);
+        return launch_conv<T, 1, 1>(a, st);
+    }
     if (ntw == 4) return launch_conv<T, 4, 2>(a, st);
     if (ntw == 2) return launch_conv<T, 2, 2>(a, st);
     return launch_conv<T, 1, 2>(a, st);

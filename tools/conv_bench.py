@@ -33,7 +33,7 @@ if which == "tune":
             ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr()), n=20)
             print(f"stagger={stg} prio={prio}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
 elif which == "conv":
-    for kc, ntw, wm in [(256, 4, 1), (128, 4, 1), (256, 4, 2), (128, 4, 2), (64, 4, 2), (128, 2, 2), (64, 2, 2)]:
+    for kc, ntw, wm in [(128, 4, 2), (64, 4, 2), (128, 4, 1), (64, 4, 1), (256, 4, 1)]:
         os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = str(wm)
         for name, args in (("plain", (None, None, None, 0)), ("fused", (sc, sh, g, 1))):
             ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, args[0], args[1], args[2], args[3], bsum, sq, B, C, C, code, _lib.stream_ptr()))

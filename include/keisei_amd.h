@@ -111,6 +111,16 @@ int ka_tail_bwd_reduce(const void* dout, const void* out, const void* y, const f
                        const float* se, float* dse, int B, int C, int dtype, void* stream);
 int ka_tail_bwd_dz(const void* dout, const void* out, const void* y, const float* se, const float* dsq, const float* mean,
                    const float* invstd, void* dz, float* s1p, float* s2p, int B, int C, int dtype, void* stream);
+/* Single-pass form of the two calls above plus the squeeze-excite FC chain backward that sits between them
+ * (se_resnet.py:77-86: se_fc2 -> ReLU -> se_fc1): dse (B,2C) and dh = masked gradient of the hidden layer (B,H) are
+ * written for the FC weight-gradient GEMMs, dz / s1p / s2p as ka_tail_bwd_dz.  W2 = se_fc2.weight (2C,H),
+ * W1 = se_fc1.weight (H,C), se1 = the saved hidden activations (B,H).  ka_tail_bwd_fused_supported() says whether
+ * the shape fits the register-resident board tile. */
+int ka_tail_bwd_fused_supported(int C, int H, int dtype);
+int ka_tail_bwd_fused(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
+                      const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
+                      const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C, int H,
+                      int dtype, void* stream);
 /* da = dh*[scale*y+shift > 0] (ReLU after BatchNorm) + the same partial sums */
 int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, const float* shift, const float* mean,
                           const float* invstd, void* da, float* s1p, float* s2p, int B, int C, int dtype, void* stream);

@@ -37,6 +37,8 @@ _SIGS = {
     "ka_pool_fwd": "pp ii i p",
     "ka_tail_bwd_reduce": "pppppp p ii i p",
     "ka_tail_bwd_dz": "ppppppp ppp ii i p",
+    "ka_tail_bwd_fused_supported": "iii",
+    "ka_tail_bwd_fused": "ppppp pppppp p pppp iii i p",
     "ka_relu_bn_bwd_reduce": "pppppp ppp ii i p",
     "ka_block_dx": "pppppp p ii i p",
     "ka_gemm": "pppp iii iii ii iii i i i p",

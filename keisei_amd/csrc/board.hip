@@ -396,6 +396,127 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_dz_kernel(
     }
 }
 
+// ---------------------------------------------------------------- backward tail, single pass
+// tail_bwd_reduce + the per-board squeeze-excite FC chain backward + tail_bwd_dz in ONE read of dout/out/y:
+//   du = dout*[out>0]                                          (kept in registers, with y, between the two phases)
+//   dse[b,c] = sig'(a_c) * sum_p du*z, dse[b,C+c] = sum_p du   (z = scale*y+shift)                -> written out
+//   dh[b,j]  = [se1[b,j] > 0] * sum_k dse[b,k] * W2[k,j]       (se_fc2 backward + ReLU mask)      -> written out
+//   dsq[b,c] = sum_j dh[b,j] * W1[j,c]                         (se_fc1 backward)
+//   dz = du*sigmoid(a_c) + dsq[b,c]/81;   s1 = sum_p dz, s2 = sum_p dz*yhat
+// One workgroup per board; a thread owns one 16-byte channel piece (8 bf16 / 4 f32 channels) and every nsl-th square.
+// The FC weight gradients (dW2 = dse^T se1, dW1 = dh^T sqz) stay with the GEMM kernels, off the data-gradient chain.
+template <typename T, int MAXSQ>
+__global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
+    const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
+    const float* __restrict__ W2, const float* __restrict__ W1, const float* __restrict__ mean,
+    const float* __restrict__ invstd, T* __restrict__ dz, float* __restrict__ dse_out, float* __restrict__ dh_out,
+    float* __restrict__ s1p, float* __restrict__ s2p, int C, int H) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P16 = E::kPer16;
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int groups = C / P16, nsl = kThreads / groups;          // channel pieces per square, square slices
+    const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
+    float* red1 = lds;                       // [nsl][C]
+    float* red2 = red1 + nsl * C;            // [nsl][C]
+    float* v_dse = red2 + nsl * C;           // [2C]
+    float* v_part = v_dse + 2 * C;           // [kThreads]
+    float* v_dh = v_part + kThreads;         // [H]
+    float* v_dsq = v_dh + H;                 // [C]
+    const size_t base = (size_t)b * KA_BOARD * C + c0;
+
+    float sc[P16], sh[P16], r1[P16], r2[P16];
+#pragma unroll
+    for (int e = 0; e < P16; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; r1[e] = 0.f; r2[e] = 0.f; }
+    vec16 du[MAXSQ], yv[MAXSQ];
+#pragma unroll
+    for (int i = 0; i < MAXSQ; ++i) {
+        const int p = slice + i * nsl;
+        du[i] = vec16{}; yv[i] = vec16{};
+        if (p < KA_BOARD) {
+            const vec16 g = *reinterpret_cast<const vec16*>(dout + base + (size_t)p * C);
+            const vec16 o = *reinterpret_cast<const vec16*>(out + base + (size_t)p * C);
+            yv[i] = *reinterpret_cast<const vec16*>(y + base + (size_t)p * C);
+            float gf[P16], of[P16], yf[P16];
+            E::unpack(g, gf); E::unpack(o, of); E::unpack(yv[i], yf);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) {
+                gf[e] = of[e] > 0.f ? gf[e] : 0.f;
+                r1[e] += gf[e] * (yf[e] * sc[e] + sh[e]);
+                r2[e] += gf[e];
+            }
+            du[i] = E::pack(gf);             // exact: a masked copy of dout
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = r1[e]; red2[slice * C + c0 + e] = r2[e]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += kThreads) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
+        const float sg = sigmoidf_(se[(size_t)b * 2 * C + c]);
+        const float d1 = t1 * sg * (1.f - sg);
+        v_dse[c] = d1; v_dse[C + c] = t2;
+        dse_out[(size_t)b * 2 * C + c] = d1; dse_out[(size_t)b * 2 * C + C + c] = t2;
+    }
+    __syncthreads();
+    {   // dh[j] = sum_k dse[k] W2[k][j]: thread (j, part) sums every parts-th k
+        const int parts = kThreads / H, j = tid % H, part = tid / H;
+        float a = 0.f;
+        for (int k = part; k < 2 * C; k += parts) a += v_dse[k] * W2[(size_t)k * H + j];
+        v_part[tid] = a;
+    }
+    __syncthreads();
+    if (tid < H) {
+        const int parts = kThreads / H;
+        float a = 0.f;
+        for (int q = 0; q < parts; ++q) a += v_part[q * H + tid];
+        a = se1[(size_t)b * H + tid] > 0.f ? a : 0.f;
+        v_dh[tid] = a;
+        dh_out[(size_t)b * H + tid] = a;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += kThreads) {
+        float a = 0.f;
+        for (int j = 0; j < H; ++j) a += v_dh[j] * W1[(size_t)j * C + c];
+        v_dsq[c] = a;
+    }
+    __syncthreads();
+    float gate[P16], add[P16], mu[P16], is[P16], a1[P16], a2[P16];
+#pragma unroll
+    for (int e = 0; e < P16; ++e) {
+        gate[e] = sigmoidf_(se[(size_t)b * 2 * C + c0 + e]);
+        add[e] = v_dsq[c0 + e] / KA_BOARD;
+        mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
+        a1[e] = 0.f; a2[e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXSQ; ++i) {
+        const int p = slice + i * nsl;
+        if (p < KA_BOARD) {
+            float df[P16], yf[P16];
+            E::unpack(du[i], df); E::unpack(yv[i], yf);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) {
+                df[e] = df[e] * gate[e] + add[e];
+                a1[e] += df[e];
+                a2[e] += df[e] * ((yf[e] - mu[e]) * is[e]);
+            }
+            *reinterpret_cast<vec16*>(dz + base + (size_t)p * C) = E::pack(df);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = a1[e]; red2[slice * C + c0 + e] = a2[e]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += kThreads) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
+        s1p[(size_t)b * C + c] = t1; s2p[(size_t)b * C + c] = t2;
+    }
+}
+
 // ---------------------------------------------------------------- ReLU + BN backward, reduce pass
 // da = dh * [scale*y+shift > 0]  (written), partials s1 = sum da, s2 = sum da*yhat
 template <typename T>
@@ -612,6 +733,45 @@ extern "C" int ka_tail_bwd_dz(const void* dout, const void* out, const void* y, 
                                             (const T*)dout, (const T*)out, (const T*)y, se, dsq, mean, invstd, (T*)dz,
                                             s1p, s2p, C));
     return ka_check_launch("tail_bwd_dz");
+}
+
+// squares per thread of the single-pass tail backward: 81 / (256 / (C / channels-per-16-bytes)); the kernel keeps
+// them in registers, so it exists for <= 21 (C <= 512 bf16, C <= 256 f32) and power-of-two hidden sizes
+static int tail_fused_squares(int C, int H, int dtype) {
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+    if (C <= 0 || H <= 0 || C % p16 != 0) return 0;
+    const int groups = C / p16;
+    if (groups > kThreads || kThreads % groups != 0 || H > kThreads || kThreads % H != 0) return 0;
+    const int nsl = kThreads / groups;
+    return (KA_BOARD + nsl - 1) / nsl;
+}
+
+extern "C" int ka_tail_bwd_fused_supported(int C, int H, int dtype) {
+    const int n = tail_fused_squares(C, H, dtype);
+    return n > 0 && n <= 21;
+}
+
+extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
+                                 const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
+                                 const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                                 int H, int dtype, void* stream) {
+    KA_REQUIRE(dout && out && y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
+               "tail_bwd_fused: null tensor");
+    KA_REQUIRE(B > 0 && ka_tail_bwd_fused_supported(C, H, dtype), "tail_bwd_fused: unsupported shape C=%d H=%d", C, H);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, nsl = kThreads / (C / p16), nsq = tail_fused_squares(C, H, dtype);
+    const size_t lds = ((size_t)2 * nsl * C + 2 * C + kThreads + H + C) * sizeof(float);
+    KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
+    if (nsq <= 11) {
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, 11>), dim3(B), dim3(kThreads), lds, st, (const T*)dout,
+                                                (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, invstd, (T*)dz,
+                                                dse, dh, s1p, s2p, C, H));
+    } else {
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, 21>), dim3(B), dim3(kThreads), lds, st, (const T*)dout,
+                                                (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, invstd, (T*)dz,
+                                                dse, dh, s1p, s2p, C, H));
+    }
+    return ka_check_launch("tail_bwd_fused");
 }
 
 extern "C" int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, const float* shift,

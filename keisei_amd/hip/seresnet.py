@@ -410,12 +410,21 @@ class SEResNetEngine:
             if not train:
                 mu1, is1 = eval_stats(blk.bn1); mu2, is2 = eval_stats(blk.bn2)
             dse = torch.empty(B, 2 * C, device=dev)
-            _call("ka_tail_bwd_reduce", dout, out, y2, sc2, sh2, se, dse, B, C, code, st)
-            dse1 = self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st)
-            _call("ka_relu_mask", dse1, se1, dse1.numel(), st)
-            dsq = self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st)
             dz = new_act()
-            _call("ka_tail_bwd_dz", dout, out, y2, se, dsq, mu2, is2, dz, s1p, s2p, B, C, code, st)
+            H = blk.se_fc1.weight.shape[0]
+            if _lib.query("ka_tail_bwd_fused_supported", C, H, code):
+                # one read of dout / out / y2: SE-gate reductions, the per-board FC chain backward and dz in one kernel
+                dse1 = torch.empty(B, H, device=dev)
+                _call("ka_tail_bwd_fused", dout, out, y2, sc2, sh2, se, se1, blk.se_fc2.weight, blk.se_fc1.weight, mu2, is2,
+                      dz, dse, dse1, s1p, s2p, B, C, H, code, st)
+                self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
+                self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st, need_dx=False)
+            else:
+                _call("ka_tail_bwd_reduce", dout, out, y2, sc2, sh2, se, dse, B, C, code, st)
+                dse1 = self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st)
+                _call("ka_relu_mask", dse1, se1, dse1.numel(), st)
+                dsq = self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st)
+                _call("ka_tail_bwd_dz", dout, out, y2, se, dsq, mu2, is2, dz, s1p, s2p, B, C, code, st)
             k2 = self._bn_backward(blk.bn2, s1p, s2p, B, C, count, mu2, is2, train, grads, pre + "bn2", dev, st)
             dg = torch.empty(B, C, device=dev)
             if T == torch.bfloat16:

@@ -520,3 +520,40 @@ def test_conv3x3_dgrad_fused_matches_unfused_sequence():
     out2 = torch.empty_like(dz)
     _lib.call("ka_conv3x3_dgrad_fused", dz, y, k, None, wp, out2, None, None, None, None, None, None, None, None, B, C, C, code, st())
     assert torch.equal(out2, dh_ref)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,H", [(3, 32, 4), (5, 128, 8), (4, 256, 16)])
+def test_tail_bwd_fused_matches_unfused_sequence(dtn, B, C, H):
+    """ka_tail_bwd_fused == tail_bwd_reduce -> se_fc2 backward -> ReLU mask -> se_fc1 backward -> tail_bwd_dz."""
+    dt = DT[dtn]
+    code = _lib.dtype_code(dt)
+    assert _lib.query("ka_tail_bwd_fused_supported", C, H, code)
+    g = torch.Generator().manual_seed(900 + C)
+    dout = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    out = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    y = to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    mu, istd = (0.1 * torch.randn(C, generator=g)).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    se = torch.randn(B, 2 * C, generator=g).to(DEV)
+    se1 = torch.randn(B, H, generator=g).to(DEV)
+    W2 = (torch.randn(2 * C, H, generator=g) / H ** 0.5).to(DEV)
+    W1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(DEV)
+    # unfused reference sequence (the FC steps in fp64 torch)
+    dse_ref = torch.empty(B, 2 * C, device=DEV)
+    _lib.call("ka_tail_bwd_reduce", dout, out, y, sc, sh, se, dse_ref, B, C, code, st())
+    dh_ref = ((dse_ref.double() @ W2.double()) * (se1 > 0)).float()
+    dsq_ref = (dh_ref.double() @ W1.double()).float().contiguous()
+    dz_ref = torch.empty_like(dout); s1r, s2r = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.call("ka_tail_bwd_dz", dout, out, y, se, dsq_ref, mu, istd, dz_ref, s1r, s2r, B, C, code, st())
+    # fused
+    dz = torch.empty_like(dout); dse = torch.empty(B, 2 * C, device=DEV); dh = torch.empty(B, H, device=DEV)
+    s1, s2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    _lib.call("ka_tail_bwd_fused", dout, out, y, sc, sh, se, se1, W2, W1, mu, istd, dz, dse, dh, s1, s2, B, C, H, code, st())
+    torch.cuda.synchronize()
+    close(dse.cpu(), dse_ref.cpu(), torch.float32, k=5)
+    close(dh.cpu(), dh_ref.cpu(), torch.float32, k=5)
+    close(dz.float().cpu(), dz_ref.float().cpu(), dt, k=1 if dt == torch.float32 else 0.5)
+    close(s1.cpu(), s1r.cpu(), torch.float32, k=10)
+    close(s2.cpu(), s2r.cpu(), torch.float32, k=10)
+    assert not _lib.query("ka_tail_bwd_fused_supported", 48, 5, code)

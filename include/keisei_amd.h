@@ -61,6 +61,9 @@ int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const float* k, void
  * the reference's shape).  mode 0: forward, Nout = Co, Kin = Ci rounded up (zero channels); mode 1: data
  * gradient (in/out swapped, taps flipped), Nout = Ci, Kin = Co.  dst bytes = 9*(Kin/cpk)*(Nout/16)*1024. */
 int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int Nout, int Kin, int mode, int dtype, void* stream);
+/* Every layer of a network in one launch.  table = device int64 [n][8]: {src weights, dst pack, Co, Ci, Nout, Kin,
+ * mode, 0} per entry, as the arguments of ka_pack_conv3x3; max_pieces = max over entries of 9*(Kin/cpk)*(Nout/16)*64. */
+int ka_pack_conv3x3_multi(const long long* table, int n, long long max_pieces, int dtype, void* stream);
 /* Weight gradient dW[n,c,ky,kx] = sum_{b,p} dY[b,p,n] * X'[b,p+tap,c] (autograd conv2d weight backward);
  * X' uses the same fused input transform as the forward.  slab: ka_wgrad_splits(B,Cin,Cout,target_wgs)*9*Cout*Cin floats. */
 int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift, const float* in_bias,

@@ -21,6 +21,7 @@ _SIGS = {
     "ka_conv3x3_sqpart_rows": "i",
     "ka_debug_conv_stamps": "p",
     "ka_pack_conv3x3": "pp iiii i i p",
+    "ka_pack_conv3x3_multi": "p i q i p",
     "ka_wgrad_splits": "iiii",
     "ka_conv3x3_wgrad": "ppppp i pp iiii i i i p",
     "ka_obs_to_nhwc": "ppp iii i p",

@@ -405,8 +405,8 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_dz_kernel(
 //   dz = du*sigmoid(a_c) + dsq[b,c]/81;   s1 = sum_p dz, s2 = sum_p dz*yhat
 // One workgroup per board; a thread owns one 16-byte channel piece (8 bf16 / 4 f32 channels) and every nsl-th square.
 // The FC weight gradients (dW2 = dse^T se1, dW1 = dh^T sqz) stay with the GEMM kernels, off the data-gradient chain.
-template <typename T, int MAXSQ>
-__global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
+template <typename T, int MAXSQ, int NTHR>
+__global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
     const float* __restrict__ W2, const float* __restrict__ W1, const float* __restrict__ mean,
@@ -417,13 +417,13 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
     constexpr int P16 = E::kPer16;
     extern __shared__ float lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int groups = C / P16, nsl = kThreads / groups;          // channel pieces per square, square slices
+    const int groups = C / P16, nsl = NTHR / groups;          // channel pieces per square, square slices
     const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
     float* red1 = lds;                       // [nsl][C]
     float* red2 = red1 + nsl * C;            // [nsl][C]
     float* v_dse = red2 + nsl * C;           // [2C]
-    float* v_part = v_dse + 2 * C;           // [kThreads]
-    float* v_dh = v_part + kThreads;         // [H]
+    float* v_part = v_dse + 2 * C;           // [NTHR]
+    float* v_dh = v_part + NTHR;         // [H]
     float* v_dsq = v_dh + H;                 // [C]
     const size_t base = (size_t)b * KA_BOARD * C + c0;
 
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
 #pragma unroll
     for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = r1[e]; red2[slice * C + c0 + e] = r2[e]; }
     __syncthreads();
-    for (int c = tid; c < C; c += kThreads) {
+    for (int c = tid; c < C; c += NTHR) {
         float t1 = 0.f, t2 = 0.f;
         for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
         const float sg = sigmoidf_(se[(size_t)b * 2 * C + c]);
@@ -463,14 +463,14 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
     }
     __syncthreads();
     {   // dh[j] = sum_k dse[k] W2[k][j]: thread (j, part) sums every parts-th k
-        const int parts = kThreads / H, j = tid % H, part = tid / H;
+        const int parts = NTHR / H, j = tid % H, part = tid / H;
         float a = 0.f;
         for (int k = part; k < 2 * C; k += parts) a += v_dse[k] * W2[(size_t)k * H + j];
         v_part[tid] = a;
     }
     __syncthreads();
     if (tid < H) {
-        const int parts = kThreads / H;
+        const int parts = NTHR / H;
         float a = 0.f;
         for (int q = 0; q < parts; ++q) a += v_part[q * H + tid];
         a = se1[(size_t)b * H + tid] > 0.f ? a : 0.f;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
         dh_out[(size_t)b * H + tid] = a;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += kThreads) {
+    for (int c = tid; c < C; c += NTHR) {
         float a = 0.f;
         for (int j = 0; j < H; ++j) a += v_dh[j] * W1[(size_t)j * C + c];
         v_dsq[c] = a;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_fused_kernel(
 #pragma unroll
     for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = a1[e]; red2[slice * C + c0 + e] = a2[e]; }
     __syncthreads();
-    for (int c = tid; c < C; c += kThreads) {
+    for (int c = tid; c < C; c += NTHR) {
         float t1 = 0.f, t2 = 0.f;
         for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
         s1p[(size_t)b * C + c] = t1; s2p[(size_t)b * C + c] = t2;
@@ -735,20 +735,25 @@ extern "C" int ka_tail_bwd_dz(const void* dout, const void* out, const void* y, 
     return ka_check_launch("tail_bwd_dz");
 }
 
-// squares per thread of the single-pass tail backward: 81 / (256 / (C / channels-per-16-bytes)); the kernel keeps
-// them in registers, so it exists for <= 21 (C <= 512 bf16, C <= 256 f32) and power-of-two hidden sizes
-static int tail_fused_squares(int C, int H, int dtype) {
+// Single-pass tail backward: workgroup size and squares per thread.  A thread keeps its squares of du and y in
+// registers between the two phases, so the workgroup is sized (512 threads when the board has >= 32 channel pieces) to
+// leave <= 11 squares per thread; shapes that would need more, or hidden sizes that do not divide the workgroup,
+// fall back to the two-kernel path.
+static int tail_fused_plan(int C, int H, int dtype, int* nthr) {
     const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
     if (C <= 0 || H <= 0 || C % p16 != 0) return 0;
     const int groups = C / p16;
-    if (groups > kThreads || kThreads % groups != 0 || H > kThreads || kThreads % H != 0) return 0;
-    const int nsl = kThreads / groups;
+    const int nt = groups >= 32 ? 512 : 256;
+    if (groups > nt || nt % groups != 0 || H > nt || nt % H != 0) return 0;
+    const int nsl = nt / groups;
+    *nthr = nt;
     return (KA_BOARD + nsl - 1) / nsl;
 }
 
 extern "C" int ka_tail_bwd_fused_supported(int C, int H, int dtype) {
-    const int n = tail_fused_squares(C, H, dtype);
-    return n > 0 && n <= 21;
+    int nt = 0;
+    const int n = tail_fused_plan(C, H, dtype, &nt);
+    return n > 0 && n <= 11;
 }
 
 extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
@@ -759,18 +764,18 @@ extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* 
                "tail_bwd_fused: null tensor");
     KA_REQUIRE(B > 0 && ka_tail_bwd_fused_supported(C, H, dtype), "tail_bwd_fused: unsupported shape C=%d H=%d", C, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, nsl = kThreads / (C / p16), nsq = tail_fused_squares(C, H, dtype);
-    const size_t lds = ((size_t)2 * nsl * C + 2 * C + kThreads + H + C) * sizeof(float);
+    int nt = 0;
+    const int nsq = tail_fused_plan(C, H, dtype, &nt);
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, nsl = nt / (C / p16);
+    const size_t lds = ((size_t)2 * nsl * C + 2 * C + nt + H + C) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
-    if (nsq <= 11) {
-        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, 11>), dim3(B), dim3(kThreads), lds, st, (const T*)dout,
-                                                (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, invstd, (T*)dz,
-                                                dse, dh, s1p, s2p, C, H));
-    } else {
-        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, 21>), dim3(B), dim3(kThreads), lds, st, (const T*)dout,
-                                                (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, invstd, (T*)dz,
-                                                dse, dh, s1p, s2p, C, H));
-    }
+#define KA_TAIL_LAUNCH(MAXSQ, NTHR) \
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
+                                            (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, \
+                                            invstd, (T*)dz, dse, dh, s1p, s2p, C, H))
+    if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512); else KA_TAIL_LAUNCH(11, 512); }
+    else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256); else KA_TAIL_LAUNCH(11, 256); }
+#undef KA_TAIL_LAUNCH
     return ka_check_launch("tail_bwd_fused");
 }
 

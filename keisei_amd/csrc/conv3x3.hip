@@ -482,6 +482,38 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, void* __restric
     }
 }
 
+// All layers of a network in one launch: table[n][8] (int64) = {src, dst, Co, Ci, Nout, Kin, mode, unused}; blockIdx.y
+// picks the layer.  (80 tower convolutions x {forward, dgrad} packs after every optimiser step: as single launches
+// they are CPU-launch-bound and leave the GPU idle for ~2 ms at the start of a step.)
+template <typename T>
+__global__ void pack_conv3x3_multi_kernel(const long long* __restrict__ table) {
+    typedef Elem<T> E;
+    constexpr int P16 = E::kPer16, CPK = 4 * P16;
+    const long long* t = table + (size_t)blockIdx.y * 8;
+    const float* __restrict__ w = reinterpret_cast<const float*>(t[0]);
+    void* __restrict__ dst = reinterpret_cast<void*>(t[1]);
+    const int Co = (int)t[2], Ci = (int)t[3], Nout = (int)t[4], Kin = (int)t[5], mode = (int)t[6];
+    const int KSG = Kin / CPK, NT = Nout / 16;
+    const size_t total = (size_t)9 * KSG * NT * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        size_t u = i >> 6;
+        const int nt = u % NT; u /= NT;
+        const int ks = u % KSG; const int tap = u / KSG;
+        const int n = chan_of(nt, lane & 15, NT);
+        float f[P16];
+#pragma unroll
+        for (int e = 0; e < P16; ++e) {
+            const int c = ks * CPK + (lane >> 4) * P16 + e;
+            float v = 0.f;
+            if (mode == 0) { if (n < Co && c < Ci) v = w[((size_t)n * Ci + c) * 9 + tap]; }
+            else           { if (c < Co && n < Ci) v = w[((size_t)c * Ci + n) * 9 + (8 - tap)]; }
+            f[e] = v;
+        }
+        reinterpret_cast<typename E::vec16*>(dst)[i] = E::pack(f);
+    }
+}
+
 template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
@@ -594,4 +626,18 @@ extern "C" int ka_pack_conv3x3(const float* w, void* dst, int Co, int Ci, int No
         hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, st, w, dst, Co, Ci, Nout, Kin, mode);
     else { ka_set_error("pack_conv3x3: unknown dtype %d", dtype); return KA_ERR_ARG; }
     return ka_check_launch("pack_conv3x3");
+}
+
+// table: device int64 [n][8] = {src weight pointer, dst pack pointer, Co, Ci, Nout, Kin, mode, 0} (see ka_pack_conv3x3
+// for the meaning of each); max_pieces = the largest 9*(Kin/cpk)*(Nout/16)*64 among the entries (sizes the grid)
+extern "C" int ka_pack_conv3x3_multi(const long long* table, int n, long long max_pieces, int dtype, void* stream) {
+    KA_REQUIRE(table && n > 0 && max_pieces > 0, "pack_conv3x3_multi: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int bx = (int)((max_pieces + 255) / 256 < 64 ? (max_pieces + 255) / 256 : 64);
+    if (dtype == KA_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_conv3x3_multi_kernel<bf16_t>, dim3(bx, n), dim3(256), 0, st, table);
+    else if (dtype == KA_DTYPE_F32)
+        hipLaunchKernelGGL(pack_conv3x3_multi_kernel<float>, dim3(bx, n), dim3(256), 0, st, table);
+    else { ka_set_error("pack_conv3x3_multi: unknown dtype %d", dtype); return KA_ERR_ARG; }
+    return ka_check_launch("pack_conv3x3_multi");
 }

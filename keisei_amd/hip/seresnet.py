@@ -47,6 +47,9 @@ class SEResNetEngine:
         self._scratch: Optional[torch.Tensor] = None
         self._redws: Optional[torch.Tensor] = None
         self._side = None
+        self._pack_tkey = None
+        self._pack_table = None
+        self._pack_max = 0
         self._wslab: Optional[torch.Tensor] = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
         self._in_forward = False
@@ -121,18 +124,29 @@ class SEResNetEngine:
             return self._packs
         code, st = _lib.dtype_code(T), _lib.stream_ptr(device)
         cpk = 32 if T == torch.bfloat16 else 16
-        packs = {}
-        for name, conv in convs:
-            w = conv.weight.detach()
-            co, ci = w.shape[0], w.shape[1]
-            ci_pad = _round_up(ci, 64) if name == "input_conv" else ci   # only the 50-plane stem input is padded
-            fwd = torch.empty(9 * (ci_pad // cpk) * (co // 16) * 1024, dtype=torch.uint8, device=device)
-            _call("ka_pack_conv3x3", w, fwd, co, ci, co, ci_pad, 0, code, st)
-            dg = None
-            if name != "input_conv":
-                dg = torch.empty(9 * (co // cpk) * (ci // 16) * 1024, dtype=torch.uint8, device=device)
-                _call("ka_pack_conv3x3", w, dg, co, ci, ci, co, 1, code, st)
-            packs[name] = (fwd, dg)
+        # pack buffers and the device-side job table are built once per (dtype, parameter storage); after an optimiser
+        # step only the single multi-layer pack launch is repeated
+        tkey = (T, str(device), tuple(c.weight.data_ptr() for _, c in convs))
+        if tkey != self._pack_tkey:
+            packs, jobs, mx = {}, [], 0
+            for name, conv in convs:
+                w = conv.weight
+                co, ci = w.shape[0], w.shape[1]
+                ci_pad = _round_up(ci, 64) if name == "input_conv" else ci   # only the 50-plane stem input is padded
+                nf = 9 * (ci_pad // cpk) * (co // 16) * 64
+                fwd = torch.empty(nf * 16, dtype=torch.uint8, device=device)
+                jobs.append([w.data_ptr(), fwd.data_ptr(), co, ci, co, ci_pad, 0, 0]); mx = max(mx, nf)
+                dg = None
+                if name != "input_conv":
+                    nd = 9 * (co // cpk) * (ci // 16) * 64
+                    dg = torch.empty(nd * 16, dtype=torch.uint8, device=device)
+                    jobs.append([w.data_ptr(), dg.data_ptr(), co, ci, ci, co, 1, 0]); mx = max(mx, nd)
+                packs[name] = (fwd, dg)
+            self._packs = packs
+            self._pack_table = torch.tensor(jobs, dtype=torch.int64).to(device)
+            self._pack_max, self._pack_tkey = mx, tkey
+        _call("ka_pack_conv3x3_multi", self._pack_table, self._pack_table.shape[0], self._pack_max, code, st)
+        packs = self._packs
         self._packs, self._pack_key = packs, key
         return packs
 

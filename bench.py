@@ -176,10 +176,16 @@ def main() -> None:
     if not args.no_kernel_events:
         engine.kernel_events = {"conv3x3": [], "wgrad": [], "conv3x3_fwd": []}
     torch.cuda.synchronize()
+    if os.environ.get("KA_HOST_TIMING"):
+        fs["host_ms"] = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
+    if fs.get("host_ms") is not None:
+        print(f"[bench] host enqueue ms/step: total {1e3 * t_enq / args.steps:.1f} " +
+              " ".join(f"{k} {v / args.steps:.1f}" for k, v in fs["host_ms"].items()), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import dataclasses
 import logging
+import time
 from typing import Any, Callable
 
 import torch
@@ -621,7 +622,10 @@ class KataGoPPOAlgorithm:
         group = self.optimizer.param_groups[0]
         beta1, beta2 = group["betas"]
         B, A = idx.shape[0], d["masks"].shape[1]
+        ht = fs.get("host_ms")                  # optional host-side (enqueue) timing per phase, no GPU sync (bench diagnostics)
+        t0 = time.perf_counter() if ht is not None else 0.0
         out = self.forward_model(d["obs"], gather_idx=idx)
+        t1 = time.perf_counter() if ht is not None else 0.0
         logits = out.policy_logits.reshape(B, A)
         dlogits = torch.empty_like(logits)
         new_lp = torch.empty(B, device=device); rowloss = torch.empty(B, device=device); rowent = torch.empty(B, device=device)
@@ -633,12 +637,18 @@ class KataGoPPOAlgorithm:
              fs["out_m"], fs["acc"], fs["gscale"], float(p.lambda_policy), float(fs["lam_v"]), float(fs["lam_s"]),
              float(self.current_entropy_coeff), fs["combined"], B, sp)
         self.optimizer.zero_grad(set_to_none=True)
+        t2 = time.perf_counter() if ht is not None else 0.0
         torch.autograd.backward([out.policy_logits, out.value_logits, out.score_lead],
                                 [dlogits.view_as(out.policy_logits), dv, ds])
+        t3 = time.perf_counter() if ht is not None else 0.0
         tab = self._upload_table(st, device)
         call("ka_clip_adam_step", tab, st["blk_t"], st["blk_o"], st["nblocks"], st["partial"], st["ctl"],
              st["step_dev"], fs["scaler_t"], fs["flags"], fs["acc"][4:5], float(p.grad_clip), float(group["lr"]),
              float(beta1), float(beta2), float(group["eps"]), sp)
+        if ht is not None:
+            t4 = time.perf_counter()
+            for k, v in (("forward", t1 - t0), ("loss", t2 - t1), ("backward", t3 - t2), ("optimizer", t4 - t3)):
+                ht[k] = ht.get(k, 0.0) + 1e3 * v
         self._notify_weights_changed()
         fs["n_updates"] += 1
 

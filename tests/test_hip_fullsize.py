@@ -1,0 +1,129 @@
+"""Parity at BASELINE.json's full sizes (B = 4096 boards, C = 256, bf16 and f32) through size-independent
+properties plus exact spot checks: the oracle cannot finish a 4096-board convolution in seconds, so
+
+* a random subset of boards of the full-size result is compared with CPU fp32 math (a conv output row depends only
+  on its own board, so every board of the big launch is an independent small problem);
+* linearity in the input / in dy, the per-board-sum and sum-of-squares identities of the fused statistics, and
+  additivity over the batch (weight gradient of the whole batch = sum over disjoint chunks) tie the rest together.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from keisei_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, C = 4096, 256
+
+
+def st():
+    return _lib.stream_ptr()
+
+
+def pack(w, dt, mode):
+    cpk = 32 if dt == torch.bfloat16 else 16
+    buf = torch.empty(9 * (C // cpk) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, buf, C, C, C, C, mode, _lib.dtype_code(dt), st())
+    return buf
+
+
+def conv(x, wp, dt, stats=True):
+    out = torch.empty_like(x)
+    bsum = torch.empty(B, C, device=DEV) if stats else None
+    sq = torch.empty(_lib.query("ka_conv3x3_sqpart_rows", B), C, device=DEV) if stats else None
+    _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, _lib.dtype_code(dt), st())
+    return out, bsum, sq
+
+
+def nchw(t):     # (n,81,C) -> (n,C,9,9) cpu fp32
+    return t.float().cpu().reshape(t.shape[0], 9, 9, C).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtn", ["bf16", "f32"])
+def test_conv3x3_full_size(dtn):
+    dt = torch.bfloat16 if dtn == "bf16" else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x1 = torch.randn(B, 81, C, device=DEV, generator=g).to(dt)
+    x2 = torch.randn(B, 81, C, device=DEV, generator=g).to(dt)
+    w = torch.randn(C, C, 3, 3, device=DEV, generator=g) / 48.0
+    wp = pack(w, dt, 0)
+    y1, bsum, sq = conv(x1, wp, dt)
+    torch.cuda.synchronize()
+    # (1) exact spot check of 12 boards spread over the batch (first / last workgroups included) against CPU fp32
+    pick = torch.tensor([0, 1, 2, 1023, 1024, 2047, 2048, 3000, 3071, 4093, 4094, 4095])
+    wr = w.to(dt).float().cpu()
+    ref = F.conv2d(nchw(x1[pick.to(DEV)]), wr, padding=1)
+    tol = (1.2e-2 if dt == torch.bfloat16 else 3e-5) * float(ref.abs().max())
+    assert float((nchw(y1[pick.to(DEV)]) - ref).abs().max()) <= tol
+    # (2) fused statistics are the statistics of the fp32 accumulators: compare with sums over the stored output
+    tol_s = 2e-2 if dt == torch.bfloat16 else 1e-4
+    s_ref = y1.float().sum(dim=1)
+    assert float((bsum - s_ref).abs().max()) <= tol_s * float(s_ref.abs().max())
+    q_ref = (y1.float() ** 2).sum(dim=(0, 1))
+    assert float((sq.sum(0) - q_ref).abs().max()) <= tol_s * float(q_ref.max())
+    # (3) linearity in the input (f32: exact up to summation-order rounding; bf16: up to the output rounding)
+    y2, _, _ = conv(x2, wp, dt, stats=False)
+    xs = (x1.float() + x2.float())
+    if dt == torch.float32:
+        y12, _, _ = conv(xs, wp, dt, stats=False)
+        err = float((y12 - (y1 + y2)).abs().max())
+        assert err <= 2e-5 * float(y12.abs().max())
+    else:
+        # x1 + x2 is not representable in bf16; negation and doubling of the input are.  The matrix cores' internal
+        # accumulation is not exactly sign-symmetric, so "equal" means: within one bf16 ulp, and almost everywhere equal
+        def same_up_to_an_ulp(a, b):
+            d = (a.float() - b.float()).abs()
+            return float((d > 2.0 ** -7 * b.float().abs() + 1e-30).float().mean()) == 0.0 and float((d > 0).float().mean()) < 2e-2
+        yn, _, _ = conv((-x1.float()).to(dt), wp, dt, stats=False)
+        assert same_up_to_an_ulp(yn, (-y1.float()).to(dt))
+        yd, _, _ = conv((2 * x1.float()).to(dt), wp, dt, stats=False)
+        assert torch.equal(yd, (2 * y1.float()).to(dt))
+    # (4) every board is an independent problem: a permutation of the boards permutes the output
+    perm = torch.randperm(B, device=DEV, generator=g)
+    yp, _, _ = conv(x1[perm].contiguous(), wp, dt, stats=False)
+    assert torch.equal(yp, y1[perm])
+
+
+@pytest.mark.parametrize("dtn", ["bf16", "f32"])
+def test_wgrad_full_size(dtn):
+    dt = torch.bfloat16 if dtn == "bf16" else torch.float32
+    code = _lib.dtype_code(dt)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(B, 81, C, device=DEV, generator=g).to(dt)
+    dy = (torch.randn(B, 81, C, device=DEV, generator=g) / 64).to(dt)
+
+    def wgrad(xx, dd, nb):
+        ns = _lib.query("ka_wgrad_splits", nb, C, C, 0)
+        slab = torch.empty(ns * 9 * C * C, device=DEV)
+        dw = torch.empty(C, C, 3, 3, device=DEV)
+        _lib.call("ka_conv3x3_wgrad", dd, xx, None, None, None, 0, slab, dw, nb, C, C, C, 0, 0, code, st())
+        return dw
+
+    full = wgrad(x, dy, B)
+    # additivity over the batch: eight disjoint chunks of 512 boards
+    parts = sum(wgrad(x[i:i + 512].contiguous(), dy[i:i + 512].contiguous(), 512) for i in range(0, B, 512))
+    torch.cuda.synchronize()
+    scale = float(full.abs().max())
+    assert float((full - parts).abs().max()) <= (2e-5 if dt == torch.float32 else 1e-4) * scale
+    # one chunk against CPU fp32 math (64 boards)
+    ref = torch.nn.grad.conv2d_weight(nchw(x[:64]), (C, C, 3, 3), nchw(dy[:64]), padding=1)
+    got = wgrad(x[:64].contiguous(), dy[:64].contiguous(), 64).cpu()
+    assert float((got - ref).abs().max()) <= (3e-5 if dt == torch.float32 else 2e-3) * float(ref.abs().max())
+    # linearity in dy: exact scaling by 2 commutes with every rounding step
+    dbl = wgrad(x, (2 * dy.float()).to(dt), B)
+    assert float((dbl - 2 * full).abs().max()) <= 1e-6 * scale
+
+
+def test_dgrad_is_the_adjoint_of_forward_full_size():
+    """<conv(x), dy> == <x, dgrad(dy)> at the headline shape (f32 kernels, fp64 inner products)."""
+    dt = torch.float32
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(B, 81, C, device=DEV, generator=g)
+    dy = torch.randn(B, 81, C, device=DEV, generator=g)
+    w = torch.randn(C, C, 3, 3, device=DEV, generator=g) / 48.0
+    y, _, _ = conv(x, pack(w, dt, 0), dt, stats=False)
+    dx, _, _ = conv(dy, pack(w, dt, 1), dt, stats=False)
+    lhs = float((y.double() * dy.double()).sum())
+    rhs = float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3 * float(y.double().norm() * dy.double().norm()) * 1e-6

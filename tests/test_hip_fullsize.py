@@ -74,7 +74,8 @@ def test_conv3x3_full_size(dtn):
         # accumulation is not exactly sign-symmetric, so "equal" means: within one bf16 ulp, and almost everywhere equal
         def same_up_to_an_ulp(a, b):
             d = (a.float() - b.float()).abs()
-            return float((d > 2.0 ** -7 * b.float().abs() + 1e-30).float().mean()) == 0.0 and float((d > 0).float().mean()) < 2e-2
+            tol = 2.0 ** -7 * b.float().abs() + 1e-6 * float(b.float().abs().max())   # an output ulp, or fp32 noise near zero
+            return float((d > tol).float().mean()) == 0.0 and float((d > 0).float().mean()) < 1e-3
         yn, _, _ = conv((-x1.float()).to(dt), wp, dt, stats=False)
         assert same_up_to_an_ulp(yn, (-y1.float()).to(dt))
         yd, _, _ = conv((2 * x1.float()).to(dt), wp, dt, stats=False)

@@ -11,6 +11,7 @@
 // Reference semantics: keisei/training/models/se_resnet.py:68-98 (forward) and the autograd
 // derivatives of mean / amax (ties share the gradient equally) / std(correction=0) (zero where
 // sigma == 0) / BatchNorm2d (training mode) / sigmoid gate.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
     float* v_part = v_dse + 2 * C;           // [NTHR]
     float* v_dh = v_part + NTHR;         // [H]
     float* v_dsq = v_dh + H;                 // [C]
+    float* v_gate = v_dsq + C;               // [C]: sigmoid of the gate logits, one evaluation per channel
     const size_t base = (size_t)b * KA_BOARD * C + c0;
 
     float sc[P16], sh[P16], r1[P16], r2[P16];
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
         for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
         const float sg = sigmoidf_(se[(size_t)b * 2 * C + c]);
         const float d1 = t1 * sg * (1.f - sg);
+        v_gate[c] = sg;
         v_dse[c] = d1; v_dse[C + c] = t2;
         dse_out[(size_t)b * 2 * C + c] = d1; dse_out[(size_t)b * 2 * C + C + c] = t2;
     }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
     float gate[P16], add[P16], mu[P16], is[P16], a1[P16], a2[P16];
 #pragma unroll
     for (int e = 0; e < P16; ++e) {
-        gate[e] = sigmoidf_(se[(size_t)b * 2 * C + c0 + e]);
+        gate[e] = v_gate[c0 + e];
         add[e] = v_dsq[c0 + e] / KA_BOARD;
         mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
         a1[e] = 0.f; a2[e] = 0.f;
@@ -593,6 +596,193 @@ __global__ __launch_bounds__(kThreads) void block_dx_kernel(
     }
 }
 
+// ---------------------------------------------------------------- 16-byte-per-lane forms of the two kernels above
+// A thread owns one 16-byte channel piece (8 bf16 / 4 f32 channels) of every nsl-th square: 4x fewer memory
+// instructions than the channel-pair form, and the forward tail keeps its squares in registers so that the pooled
+// statistics are an exact two-pass computation (sum and max first, then squared deviations and ties) with two LDS
+// combines instead of a serial Welford chain with a division per element.
+template <typename T, int MAXSQ, int NTHR>
+__global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
+    const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P16 = E::kPer16;
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int groups = C / P16, nsl = NTHR / groups;
+    const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
+    float* redA = lds;                   // [nsl][C]
+    float* redB = redA + nsl * C;        // [nsl][C]
+    float* redC = redB + nsl * C;        // [nsl][C]
+    const size_t base = (size_t)b * KA_BOARD * C + c0;
+    const bool raw = scale == nullptr;       // pooled statistics of y as it is (ka_pool_fwd): no transform, no store
+    // v = (y*scale + shift)*gate + bias = y*ca + cb: the two per-channel coefficients (one sigmoid per channel) are
+    // computed once per workgroup and shared through LDS (redA/redB are free until the first combine)
+    if (!raw) {
+        for (int c = tid; c < C; c += NTHR) {
+            const float gt = se ? sigmoidf_(se[(size_t)b * 2 * C + c]) : 1.f;
+            redA[c] = scale[c] * gt;
+            redB[c] = shift[c] * gt + (se ? se[(size_t)b * 2 * C + C + c] : 0.f);
+        }
+        __syncthreads();
+    }
+    float ca[P16], cb[P16], sum[P16], mx[P16], mn[P16];
+#pragma unroll
+    for (int e = 0; e < P16; ++e) {
+        ca[e] = raw ? 1.f : redA[c0 + e]; cb[e] = raw ? 0.f : redB[c0 + e];
+        sum[e] = 0.f; mx[e] = -INFINITY; mn[e] = INFINITY;
+    }
+    if (!raw) __syncthreads();               // coefficients read before redA/redB are reused
+    vec16 ov[MAXSQ];
+#pragma unroll
+    for (int i = 0; i < MAXSQ; ++i) {
+        const int p = slice + i * nsl;
+        ov[i] = vec16{};
+        if (p < KA_BOARD) {
+            float u[P16], r[P16];
+            E::unpack(*reinterpret_cast<const vec16*>(y + base + (size_t)p * C), u);
+            if (res) E::unpack(*reinterpret_cast<const vec16*>(res + base + (size_t)p * C), r);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) {
+                float v = u[e];
+                if (!raw) {
+                    v = fmaf(v, ca[e], cb[e]);
+                    if (res) v += r[e];
+                    v = rnd<T>(fmaxf(v, 0.f));
+                }
+                u[e] = v;
+                sum[e] += v; mx[e] = fmaxf(mx[e], v); mn[e] = fminf(mn[e], v);
+            }
+            ov[i] = E::pack(u);
+            if (!raw) *reinterpret_cast<vec16*>(out + base + (size_t)p * C) = ov[i];
+        }
+    }
+    if (!pool) return;
+    // combine 1 (one thread per channel, conflict-free): sum -> mean, max, min; totals go back through LDS row 0
+#pragma unroll
+    for (int e = 0; e < P16; ++e) { redA[slice * C + c0 + e] = sum[e]; redB[slice * C + c0 + e] = mx[e]; redC[slice * C + c0 + e] = mn[e]; }
+    __syncthreads();
+    float tmean = 0.f, thi = -INFINITY, tlo = INFINITY;
+    for (int c = tid; c < C; c += NTHR) {
+        float t = 0.f;
+        thi = -INFINITY; tlo = INFINITY;
+        for (int s2 = 0; s2 < nsl; ++s2) {
+            t += redA[s2 * C + c];
+            thi = fmaxf(thi, redB[s2 * C + c]);
+            tlo = fminf(tlo, redC[s2 * C + c]);
+        }
+        tmean = t / KA_BOARD;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NTHR) { redA[c] = tmean; redB[c] = thi; redC[c] = tlo; }
+    __syncthreads();
+    float mean[P16];
+    bool flat[P16];
+#pragma unroll
+    for (int e = 0; e < P16; ++e) {
+        mean[e] = redA[c0 + e]; mx[e] = redB[c0 + e];
+        flat[e] = redB[c0 + e] == redC[c0 + e];                    // a constant plane has variance exactly 0
+        sum[e] = 0.f; mn[e] = 0.f;                                  // reused: squared deviations, tie count
+    }
+#pragma unroll
+    for (int i = 0; i < MAXSQ; ++i) {
+        const int p = slice + i * nsl;
+        if (p < KA_BOARD) {
+            float u[P16];
+            E::unpack(ov[i], u);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) {
+                const float d = u[e] - mean[e];
+                sum[e] += d * d;
+                mn[e] += u[e] == mx[e] ? 1.f : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // combine 2: squared deviations and tie counts (rows 1.. of redA/redB; row 0 still holds mean / max)
+    float* sqd = redC;                       // [nsl][C] (min no longer needed)
+    float* tie = redC + nsl * C;             // [nsl][C]
+#pragma unroll
+    for (int e = 0; e < P16; ++e) { sqd[slice * C + c0 + e] = flat[e] ? 0.f : sum[e]; tie[slice * C + c0 + e] = mn[e]; }
+    __syncthreads();
+    float* row = pool + (size_t)b * 4 * C;
+    for (int c = tid; c < C; c += NTHR) {
+        float m2 = 0.f, ties = 0.f;
+        for (int s2 = 0; s2 < nsl; ++s2) { m2 += sqd[s2 * C + c]; ties += tie[s2 * C + c]; }
+        row[c] = redA[c];
+        row[C + c] = redB[c];
+        row[2 * C + c] = sqrtf(m2 / KA_BOARD);
+        row[3 * C + c] = ties;
+    }
+}
+
+template <typename T, int NTHR>
+__global__ __launch_bounds__(NTHR) void block_dx16_kernel(
+    const T* __restrict__ dxc, const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+    const float* __restrict__ xpool, const float* __restrict__ dpool, T* __restrict__ dx, int C) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P16 = E::kPer16;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int groups = C / P16, nsl = NTHR / groups;
+    const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
+    const size_t base = (size_t)b * KA_BOARD * C + c0;
+    // per-channel coefficients once per workgroup (divisions!), shared through LDS: [5][C]
+    extern __shared__ float lds[];
+    {
+        const float* xp = xpool + (size_t)b * 4 * C;
+        const float* dp = dpool + (size_t)b * 3 * C;
+        for (int c = tid; c < C; c += NTHR) {
+            const float sd = xp[2 * C + c];
+            lds[c] = xp[c];
+            lds[C + c] = xp[C + c];
+            lds[2 * C + c] = dp[c] / KA_BOARD;
+            lds[3 * C + c] = dp[C + c] / xp[3 * C + c];
+            lds[4 * C + c] = sd > 0.f ? dp[2 * C + c] / (KA_BOARD * sd) : 0.f;
+        }
+    }
+    __syncthreads();
+    float mean[P16], mxx[P16], gm[P16], gx[P16], gs[P16];
+#pragma unroll
+    for (int e = 0; e < P16; ++e) {
+        mean[e] = lds[c0 + e]; mxx[e] = lds[C + c0 + e]; gm[e] = lds[2 * C + c0 + e];
+        gx[e] = lds[3 * C + c0 + e]; gs[e] = lds[4 * C + c0 + e];
+    }
+#pragma unroll 3
+    for (int p = slice; p < KA_BOARD; p += nsl) {
+        float v[P16], g[P16];
+        E::unpack(*reinterpret_cast<const vec16*>(x + base + (size_t)p * C), v);
+#pragma unroll
+        for (int e = 0; e < P16; ++e) g[e] = gm[e] + gs[e] * (v[e] - mean[e]) + (v[e] == mxx[e] ? gx[e] : 0.f);
+        if (dxc) {
+            float t[P16];
+            E::unpack(*reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C), t);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) g[e] += t[e];
+        }
+        if (dout) {
+            float t[P16], o[P16];
+            E::unpack(*reinterpret_cast<const vec16*>(dout + base + (size_t)p * C), t);
+            E::unpack(*reinterpret_cast<const vec16*>(out + base + (size_t)p * C), o);
+#pragma unroll
+            for (int e = 0; e < P16; ++e) g[e] += o[e] > 0.f ? t[e] : 0.f;
+        }
+        *reinterpret_cast<vec16*>(dx + base + (size_t)p * C) = E::pack(g);
+    }
+}
+
+// workgroup size / squares per thread of the 16-byte-per-lane board kernels (0 = shape not covered)
+static int board16_plan(int C, int dtype, int* nthr) {
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+    if (C <= 0 || C % p16 != 0) return 0;
+    const int groups = C / p16;
+    const int nt = groups >= 32 ? 512 : 256;
+    if (groups > nt || nt % groups != 0) return 0;
+    *nthr = nt;
+    return (KA_BOARD + nt / groups - 1) / (nt / groups);
+}
+
 template <typename T> size_t red_bytes(int C) {
     const int pairs = C >> 1, cpw = pairs < 128 ? pairs : 128;
     int ph = kThreads / cpw; if (ph > KA_BOARD) ph = KA_BOARD;
@@ -696,8 +886,23 @@ extern "C" int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, vo
 extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se,
                                  const void* res, void* out, float* pool, int B, int C, int dtype, void* stream) {
     KA_REQUIRE(y && scale && shift && out, "block_tail_fwd: null tensor");
-    KA_BOARD_CHECK("block_tail_fwd");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int nt = 0;
+    const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
+    if (nsq > 0 && nsq <= 11 && B > 0) {
+        const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+        const size_t lds = (size_t)4 * (nt / (C / p16)) * C * sizeof(float);
+#define KA_TAILF_LAUNCH(MAXSQ, NTHR) \
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
+                                                (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C))
+        if (lds <= 64 * 1024) {
+            if (nt == 512) { if (nsq <= 6) KA_TAILF_LAUNCH(6, 512); else KA_TAILF_LAUNCH(11, 512); }
+            else           { if (nsq <= 6) KA_TAILF_LAUNCH(6, 256); else KA_TAILF_LAUNCH(11, 256); }
+            return ka_check_launch("block_tail_fwd");
+        }
+#undef KA_TAILF_LAUNCH
+    }
+    KA_BOARD_CHECK("block_tail_fwd");
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_tail_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
                                             (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C));
     return ka_check_launch("block_tail_fwd");
@@ -705,8 +910,23 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
 
 extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, void* stream) {
     KA_REQUIRE(x && pool, "pool_fwd: null tensor");
-    KA_BOARD_CHECK("pool_fwd");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int nt = 0;
+    const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
+    if (nsq > 0 && nsq <= 11 && B > 0) {
+        const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+        const size_t lds = (size_t)4 * (nt / (C / p16)) * C * sizeof(float);
+#define KA_POOL_LAUNCH(MAXSQ, NTHR) \
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
+                                                (const T*)x, nullptr, nullptr, nullptr, nullptr, (T*)nullptr, pool, C))
+        if (lds <= 64 * 1024) {
+            if (nt == 512) { if (nsq <= 6) KA_POOL_LAUNCH(6, 512); else KA_POOL_LAUNCH(11, 512); }
+            else           { if (nsq <= 6) KA_POOL_LAUNCH(6, 256); else KA_POOL_LAUNCH(11, 256); }
+            return ka_check_launch("pool_fwd");
+        }
+#undef KA_POOL_LAUNCH
+    }
+    KA_BOARD_CHECK("pool_fwd");
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
                                             (const T*)x, pool, C));
     return ka_check_launch("pool_fwd");
@@ -767,7 +987,7 @@ extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* 
     int nt = 0;
     const int nsq = tail_fused_plan(C, H, dtype, &nt);
     const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, nsl = nt / (C / p16);
-    const size_t lds = ((size_t)2 * nsl * C + 2 * C + nt + H + C) * sizeof(float);
+    const size_t lds = ((size_t)2 * nsl * C + 2 * C + nt + H + 2 * C) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
 #define KA_TAIL_LAUNCH(MAXSQ, NTHR) \
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
@@ -793,8 +1013,19 @@ extern "C" int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float*
 extern "C" int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* xpool,
                            const float* dpool, void* dx, int B, int C, int dtype, void* stream) {
     KA_REQUIRE(x && xpool && dpool && dx && ((dout == nullptr) == (out == nullptr)), "block_dx: bad arguments");
-    KA_BOARD_CHECK("block_dx");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int nt = 0;
+    if (B > 0 && !getenv("KA_BOARD_PAIRS") && board16_plan(C, dtype, &nt) > 0) {
+        if (nt == 512) {
+            KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_dx16_kernel<T, 512>), dim3(B), dim3(512), (size_t)5 * C * sizeof(float), st, (const T*)dxc,
+                                                    (const T*)dout, (const T*)out, (const T*)x, xpool, dpool, (T*)dx, C));
+        } else {
+            KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_dx16_kernel<T, 256>), dim3(B), dim3(256), (size_t)5 * C * sizeof(float), st, (const T*)dxc,
+                                                    (const T*)dout, (const T*)out, (const T*)x, xpool, dpool, (T*)dx, C));
+        }
+        return ka_check_launch("block_dx");
+    }
+    KA_BOARD_CHECK("block_dx");
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_dx_kernel<T>, dim3(B), dim3(kThreads), 0, st, (const T*)dxc,
                                             (const T*)dout, (const T*)out, (const T*)x, xpool, dpool, (T*)dx, C));
     return ka_check_launch("block_dx");

@@ -396,44 +396,52 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                     }
                 }
             } else {
-                // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da, one tile at a time
+                // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da, one PAIR of tiles (8
+                // consecutive channels, 16-byte accesses) at a time; a lone tile (NTW == 1) uses 8-byte accesses
+                constexpr int TP = NTW >= 2 ? 2 : 1, NE = 4 * TP;
+                typedef __attribute__((ext_vector_type(NE))) __bf16 bvec;
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
+                for (int j = 0; j < NTW; j += TP) {
                     if (nt0 + j >= NT) continue;
-                    bf16x4 yv[kMTW];
+                    bvec yv[kMTW];
 #pragma unroll
                     for (int mt = 0; mt < kMTW; ++mt) {
                         const int p = mt * 16 + r;
-                        yv[mt] = bf16x4{};
+                        yv[mt] = bvec{};
                         if (p < KA_BOARD)
-                            yv[mt] = *reinterpret_cast<const bf16x4*>(static_cast<const char*>(a.ep_y) +
-                                                                      ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2);
+                            yv[mt] = *reinterpret_cast<const bvec*>(static_cast<const char*>(a.ep_y) +
+                                                                    ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2);
                     }
-                    const f32x4 esc = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]);
-                    const f32x4 esh = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
-                    const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]);
-                    const f32x4 eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
-                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+                    float esc[NE], esh[NE], emu[NE], eis[NE], t1[NE], t2[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        esc[e] = a.ep_scale[cb[j] + e]; esh[e] = a.ep_shift[cb[j] + e];
+                        emu[e] = a.ep_mean[cb[j] + e]; eis[e] = a.ep_invstd[cb[j] + e];
+                        t1[e] = 0.f; t2[e] = 0.f;
+                    }
 #pragma unroll
                     for (int mt = 0; mt < kMTW; ++mt) {
                         const int p = mt * 16 + r;
                         const bool in = p < KA_BOARD;
-                        bf16x4 o;
+                        bvec o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float y = (float)yv[mt][i];
-                            const __bf16 db = (__bf16)acc[mt][j][i];
-                            const float d = (in && y * esc[i] + esh[i] > 0.f) ? (float)db : 0.f;
-                            t1[i] += d; t2[i] += d * ((y - emu[i]) * eis[i]);
-                            o[i] = (__bf16)d;
+                        for (int e = 0; e < NE; ++e) {
+                            const float y = (float)yv[mt][e];
+                            const __bf16 db = (__bf16)acc[mt][j + (e >> 2)][e & 3];
+                            const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                            t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
+                            o[e] = (__bf16)d;
                         }
-                        if (in) *reinterpret_cast<bf16x4*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2) = o;
+                        if (in) *reinterpret_cast<bvec*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2) = o;
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { t1[i] = row_sum16(t1[i]); t2[i] = row_sum16(t2[i]); }
+                    for (int e = 0; e < NE; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
                     if (r == 0) {
-                        *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
-                        *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+#pragma unroll
+                        for (int e = 0; e < NE; e += 4) {
+                            *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
+                            *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
+                        }
                     }
                 }
             }

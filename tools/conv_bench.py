@@ -33,11 +33,20 @@ if which == "tune":
             ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr()), n=20)
             print(f"stagger={stg} prio={prio}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
 elif which == "conv":
-    for kc, ntw, wm in [(128, 4, 2), (64, 4, 2), (128, 4, 1), (64, 4, 1), (256, 4, 1)]:
-        os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = str(wm)
-        for name, args in (("plain", (None, None, None, 0)), ("fused", (sc, sh, g, 1))):
-            ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, args[0], args[1], args[2], args[3], bsum, sq, B, C, C, code, _lib.stream_ptr()))
-            print(f"conv KC={kc:3d} NTW={ntw} WM={wm} {name}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
+    k3 = torch.cat([torch.rand(C, device=dev) + 0.5, 0.1 * torch.randn(C, device=dev), 0.2 * torch.randn(C, device=dev)])
+    x2 = torch.randn(B, 81, C, device=dev).to(dt); yprev = torch.randn(B, 81, C, device=dev).to(dt)
+    dyo = torch.empty_like(x); e1 = torch.empty(rows, C, device=dev); e2 = torch.empty(rows, C, device=dev)
+    mu = 0.1 * torch.randn(C, device=dev); istd = torch.rand(C, device=dev) + 0.5
+    for kc, wm in [(128, 1), (64, 1), (128, 2)]:
+        os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_WM"] = str(wm)
+        for name, fn in (
+            ("plain (conv1 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())),
+            ("bn+relu+bias input (conv2 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, code, _lib.stream_ptr())),
+            ("dgrad fused, masked epilogue (conv2 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, code, _lib.stream_ptr())),
+            ("dgrad fused, plain epilogue (conv1 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, code, _lib.stream_ptr())),
+        ):
+            ms = timeit(fn, n=20)
+            print(f"conv KC={kc:3d} WM={wm} {name:42s}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
 else:
     ns = _lib.query("ka_wgrad_splits", B, C, C, 0)
     slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)

@@ -98,6 +98,13 @@ int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums,
 int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const double* count_dev,
                      const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k,
                      int C, int train, void* stream);
+/* One launch less per BatchNorm layer when no cross-rank reduction sits between the two steps: ka_bn_reduce /
+ * ka_pair_reduce with sums == NULL stop after their first stage, and these read the partials in `part` directly. */
+int ka_bn_coeffs_parts(const double* part, double count, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, float momentum, float eps, float* scale,
+                       float* shift, float* mean, float* invstd, int C, void* stream);
+int ka_bn_bwd_coeffs_parts(const double* part, double count, const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* k, int C, int train, void* stream);
 int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, void* dy, int B, int C, int dtype, void* stream);
 int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C, void* stream);
 

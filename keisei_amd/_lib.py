@@ -30,6 +30,8 @@ _SIGS = {
     "ka_reduce_workspace_doubles": "i",
     "ka_pair_reduce": "pp ii pp p",
     "ka_bn_coeffs": "p d p pppp p ff pppp i p",
+    "ka_bn_coeffs_parts": "p d pppp p ff pppp i p",
+    "ka_bn_bwd_coeffs_parts": "p d ppp ppp i i p",
     "ka_bn_eval_coeffs": "pppp f pp i p",
     "ka_bn_bwd_coeffs": "pp d p ppp ppp i i p",
     "ka_affine_rows": "ppp f p ii p",

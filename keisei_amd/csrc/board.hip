@@ -137,7 +137,13 @@ __global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* _
 
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
-__global__ void bn_coeffs_kernel(const double* __restrict__ sums, double count, const double* __restrict__ count_dev,
+// `sums` is either the reduced [2C] vector (nparts == 1) or the stage-1 partials [nparts][2C], summed here in slice order
+__device__ __forceinline__ double sum_parts(const double* __restrict__ p, int nparts, int stride, int c) {
+    double s = 0.0;
+    for (int k = 0; k < nparts; ++k) s += p[(size_t)k * stride + c];
+    return s;
+}
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps,
                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
@@ -146,8 +152,8 @@ __global__ void bn_coeffs_kernel(const double* __restrict__ sums, double count, 
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
     if (count_dev) count = *count_dev;          // global element count after a cross-rank all-reduce
-    const double mean = sums[c] / count;
-    double var = sums[C + c] / count - mean * mean;
+    const double mean = sum_parts(sums, nparts, 2 * C, c) / count;
+    double var = sum_parts(sums, nparts, 2 * C, C + c) / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
@@ -174,19 +180,22 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 
 // dgamma/dbeta from the LOCAL sums; dy = k1*dz + k2 + k3*y from the (possibly all-reduced) sums
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
-                                     double count, const double* __restrict__ count_dev,
+                                     int nparts, double count, const double* __restrict__ count_dev,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, float* __restrict__ k, int C, int train) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (count_dev) count = *count_dev;
-    if (dgamma) { dbeta[c] = (float)sums_local[c]; dgamma[c] = (float)sums_local[C + c]; }
+    // nparts > 1: both pointers are the same stage-1 partials (no cross-rank reduction in between)
+    const double l1 = sum_parts(sums_local, nparts, 2 * C, c), l2 = sum_parts(sums_local, nparts, 2 * C, C + c);
+    const double g1 = nparts > 1 ? l1 : sums_global[c], g2 = nparts > 1 ? l2 : sums_global[C + c];
+    if (dgamma) { dbeta[c] = (float)l1; dgamma[c] = (float)l2; }
     const double g = gamma[c], is = invstd[c], mu = mean[c];
     const double k1 = g * is;
     // eval mode (running statistics are constants): dy = gamma*invstd*dz
-    const double k3 = train ? -g * is * is * sums_global[C + c] / count : 0.0;
-    const double k2 = train ? -g * is * sums_global[c] / count - k3 * mu : 0.0;
+    const double k3 = train ? -g * is * is * g2 / count : 0.0;
+    const double k2 = train ? -g * is * g1 / count - k3 * mu : 0.0;
     k[c] = (float)k1; k[C + c] = (float)k2; k[2 * C + c] = (float)k3;
 }
 
@@ -817,7 +826,8 @@ extern "C" int ka_nhwc_to_nchw(const void* in, float* out, int B, int C, int dty
 static int colsum2(const float* A, int rowsA, const float* Bp, int rowsB, int C, double* sums, double* part,
                    hipStream_t st, const char* what) {
     hipLaunchKernelGGL(colsum2_stage1_kernel, dim3((C + 63) / 64, kRedSlices), dim3(256), 0, st, A, rowsA, Bp, rowsB, C, part);
-    hipLaunchKernelGGL(colsum2_stage2_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, st, part, sums, 2 * C);
+    if (sums)   // NULL: leave the partials in `part` for ka_bn_coeffs_parts / ka_bn_bwd_coeffs_parts
+        hipLaunchKernelGGL(colsum2_stage2_kernel, dim3((2 * C + 127) / 128), dim3(128), 0, st, part, sums, 2 * C);
     return ka_check_launch(what);
 }
 
@@ -826,12 +836,12 @@ extern "C" int ka_reduce_workspace_doubles(int C) { return kRedSlices * 2 * C; }
 
 extern "C" int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R, int C, double* sums, double* part,
                             void* stream) {
-    KA_REQUIRE(bsum && sqpart && sums && part, "bn_reduce: null tensor");
+    KA_REQUIRE(bsum && sqpart && part, "bn_reduce: null tensor");
     return colsum2(bsum, B, sqpart, R, C, sums, part, static_cast<hipStream_t>(stream), "bn_reduce");
 }
 
 extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, double* part, void* stream) {
-    KA_REQUIRE(p1 && p2 && sums && part, "pair_reduce: null tensor");
+    KA_REQUIRE(p1 && p2 && part, "pair_reduce: null tensor");
     return colsum2(p1, B, p2, B, C, sums, part, static_cast<hipStream_t>(stream), "pair_reduce");
 }
 
@@ -840,10 +850,21 @@ extern "C" int ka_bn_coeffs(const double* sums, double count, const double* coun
                             float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C,
                             void* stream) {
     KA_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && count > 0, "bn_coeffs: bad arguments");
-    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums,
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), sums, 1,
                        count, count_dev, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                        shift, mean, invstd, C);
     return ka_check_launch("bn_coeffs");
+}
+
+// as ka_bn_coeffs, reading the stage-1 partials of ka_bn_reduce(sums = NULL) directly (one launch less per layer)
+extern "C" int ka_bn_coeffs_parts(const double* part, double count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                  float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
+    KA_REQUIRE(part && gamma && beta && scale && shift && mean && invstd && count > 0, "bn_coeffs_parts: bad arguments");
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), part,
+                       kRedSlices, count, nullptr, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                       eps, scale, shift, mean, invstd, C);
+    return ka_check_launch("bn_coeffs_parts");
 }
 
 extern "C" int ka_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -859,8 +880,18 @@ extern "C" int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_glo
                                 float* dgamma, float* dbeta, float* k, int C, int train, void* stream) {
     KA_REQUIRE(sums_local && sums_global && gamma && mean && invstd && k && count > 0, "bn_bwd_coeffs: bad arguments");
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
-                       sums_local, sums_global, count, count_dev, gamma, mean, invstd, dgamma, dbeta, k, C, train);
+                       sums_local, sums_global, 1, count, count_dev, gamma, mean, invstd, dgamma, dbeta, k, C, train);
     return ka_check_launch("bn_bwd_coeffs");
+}
+
+// as ka_bn_bwd_coeffs, reading the stage-1 partials of ka_pair_reduce(sums = NULL) directly
+extern "C" int ka_bn_bwd_coeffs_parts(const double* part, double count, const float* gamma, const float* mean,
+                                      const float* invstd, float* dgamma, float* dbeta, float* k, int C, int train,
+                                      void* stream) {
+    KA_REQUIRE(part && gamma && mean && invstd && k && count > 0, "bn_bwd_coeffs_parts: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), part, part,
+                       kRedSlices, count, nullptr, gamma, mean, invstd, dgamma, dbeta, k, C, train);
+    return ka_check_launch("bn_bwd_coeffs_parts");
 }
 
 extern "C" int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C,

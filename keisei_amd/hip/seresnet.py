@@ -162,23 +162,29 @@ class SEResNetEngine:
         if not train:
             _call("ka_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C, st)
             return scale, shift, None, None
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
-        _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, self._red_ws(C, device), st)
-        if self._sync_group(bn):
+        sync = self._sync_group(bn)
+        ws = self._red_ws(C, device)
+        if sync:
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
+            _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, ws, st)
             sums[2 * C] = float(count)
             dist.all_reduce(sums)
             count_t = sums[2 * C:]
         else:
-            count_t = None
+            _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, None, ws, st)     # stage 1 only: partials stay in ws
         mean = torch.empty(C, device=device); invstd = torch.empty(C, device=device)
         track = bn.track_running_stats and bn.running_mean is not None
         if track and bn.momentum is None:
             momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)      # cumulative average (host sync; non-default)
         else:
             momentum = float(bn.momentum if bn.momentum is not None else 0.0)
-        _call("ka_bn_coeffs", sums, float(count), count_t, bn.weight, bn.bias,
-              bn.running_mean if track else None, bn.running_var if track else None,
-              bn.num_batches_tracked if track else None, momentum, float(bn.eps), scale, shift, mean, invstd, C, st)
+        rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if track else (None, None, None)
+        if sync:
+            _call("ka_bn_coeffs", sums, float(count), count_t, bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
+                  scale, shift, mean, invstd, C, st)
+        else:
+            _call("ka_bn_coeffs_parts", ws, float(count), bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
+                  scale, shift, mean, invstd, C, st)
         return scale, shift, mean, invstd
 
     def _gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, st, abf=0, bbf=0, cbf=0, relu=0, acc=0, ns=1):
@@ -331,18 +337,20 @@ class SEResNetEngine:
 
     # ------------------------------------------------------------------ backward
     def _bn_backward(self, bn, s1p, s2p, rows, C, count, mu, istd, train, grads, prefix, dev, st):
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-        _call("ka_pair_reduce", s1p, s2p, rows, C, sums, self._red_ws(C, dev), st)
-        gsums, count_t = sums, None
+        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
+        k = torch.empty(3 * C, device=dev)
+        ws = self._red_ws(C, dev)
         if train and self._sync_group(bn):
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+            _call("ka_pair_reduce", s1p, s2p, rows, C, sums, ws, st)
             gsums = sums.clone()
             gsums[2 * C] = float(count)
             dist.all_reduce(gsums)
-            count_t = gsums[2 * C:]
-        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
-        k = torch.empty(3 * C, device=dev)
-        _call("ka_bn_bwd_coeffs", sums, gsums, float(count), count_t, bn.weight, mu, istd, dgam, dbet, k, C,
-              1 if train else 0, st)
+            _call("ka_bn_bwd_coeffs", sums, gsums, float(count), gsums[2 * C:], bn.weight, mu, istd, dgam, dbet, k, C,
+                  1 if train else 0, st)
+        else:
+            _call("ka_pair_reduce", s1p, s2p, rows, C, None, ws, st)             # stage 1 only: partials stay in ws
+            _call("ka_bn_bwd_coeffs_parts", ws, float(count), bn.weight, mu, istd, dgam, dbet, k, C, 1 if train else 0, st)
         grads[prefix + ".weight"], grads[prefix + ".bias"] = dgam, dbet
         return k
 

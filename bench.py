@@ -71,6 +71,34 @@ def synth_dataset(total, seed, device):
     }
 
 
+def whole_update_rate(algo, adapter, T, N, device):
+    """SURVEY 8(d) secondary metric: one update() through the public API from a host-side KataGoRolloutBuffer of T x N
+    transitions -- batched GAE, advantage normalisation, the pinned H2D of the epoch dataset (PCIe-inclusive), the
+    epochs_per_batch x ceil(TN/B) minibatch steps and the metric read-back.  Filling the buffer is not timed."""
+    from keisei_amd.training.katago_ppo import KataGoRolloutBuffer
+    g = torch.Generator().manual_seed(99)
+    A = 11259
+    buf = KataGoRolloutBuffer(N, (50, 9, 9), A)
+    masks = torch.zeros(N, A, dtype=torch.bool)
+    masks[:, : A // 3] = True
+    for t in range(T):
+        last = t == T - 1
+        done = torch.full((N,), last, dtype=torch.bool)
+        cats = torch.randint(0, 3, (N,), generator=g) if last else torch.full((N,), -1, dtype=torch.long)
+        buf.add(torch.randn(N, 50, 9, 9, generator=g), torch.randint(0, A // 3, (N,), generator=g),
+                -8.2 + 0.05 * torch.randn(N, generator=g), torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g),
+                done, done, masks, cats, torch.randn(N, generator=g).clamp(-1.5, 1.5))
+    nv = torch.randn(N, generator=g).to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    algo.update(buf, nv, value_adapter=adapter)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_s": round(algo.params.epochs_per_batch * T * N / dt, 1), "seconds": round(dt, 3),
+            "transitions": T * N, "epochs_per_batch": algo.params.epochs_per_batch,
+            "includes": "GAE, advantage normalisation, pinned H2D of the epoch dataset, minibatch gathers, metric read-back"}
+
+
 def cpu_baseline(shape, seconds_budget=25.0):
     """Times the oracle's PPO minibatch step (fp32 CPU PyTorch restatement of the reference) on this host.
     Bounded: threads = the CPUs this process may use (<= 16, the box's share per GPU), minibatch sized from a
@@ -118,6 +146,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="override the minibatch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whole-update", action="store_true",
+                    help="also time one KataGoPPOAlgorithm.update() from a host rollout buffer (GAE, H2D, gather included)")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
@@ -194,6 +224,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     metrics = algo._fused_end(fs)
+    whole = None
+    if args.whole_update and rank == 0:
+        whole = whole_update_rate(algo, adapter, T, N, device)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -249,6 +282,8 @@ def main() -> None:
             "train_metrics": {k: round(v, 5) for k, v in metrics.items()},
         }
         out.update(extra)
+        if whole is not None:
+            out["whole_update"] = whole
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((nb, C, Rr, G, P, V, S))
         else:

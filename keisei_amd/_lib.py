@@ -12,7 +12,8 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "libkeisei_amd.so"
+# KEISEI_AMD_LIB: alternative build of the same library (A/B timing of kernel changes); never a fallback
+_LIB_PATH = Path(os.environ.get("KEISEI_AMD_LIB") or Path(__file__).resolve().parent / "libkeisei_amd.so")
 
 # signature strings: p = pointer (torch tensor | int | None), i = int, f = float, d = double, q = long long
 _SIGS = {

@@ -26,8 +26,8 @@ __device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int BK = 32;
-    __shared__ __attribute__((aligned(16))) float As[BK][64 + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
@@ -85,12 +85,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 
 // Fast path: fp32 operands, 16-byte aligned rows (lda/ldb % 4 == 0, K-range % 4 == 0).  float4 global loads
-// along the operand's contiguous axis, next K-tile prefetched into registers while the current one is multiplied.
+// along the operand's contiguous axis, next K-tile prefetched into registers while the current one is multiplied
+// on the matrix cores with the exact-f32 v_mfma_f32_16x16x4_f32 (wave w owns rows 16w..16w+15 of the 64x64 tile and
+// all four 16-column tiles: 32 MFMAs per K-tile and wave, one ds_read_b32 per operand fragment, row stride 80 floats
+// = conflict-free for the (row/col, k) lane layout).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
     constexpr int BK = 32;
-    __shared__ __attribute__((aligned(16))) float As[BK][64 + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
     const float* __restrict__ A = static_cast<const float*>(g.A);
     const float* __restrict__ Bp = static_cast<const float*>(g.B);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -148,35 +151,37 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
             }
         }
     };
-    float acc[4][4] = {};
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (k0 + BK < kend) load_tile(k0 + BK);          // in flight during the FMA block
+        if (k0 + BK < kend) load_tile(k0 + BK);          // in flight during the MFMA block
 #pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
+        for (int kk = 0; kk < BK; kk += 4) {
+            const float a = As[kk + q][wave * 16 + r];      // A[m = 16w + r][k = kk + q]
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[kk + q][j * 16 + r], acc[j], 0, 0, 0);
         }
     }
+    // accumulator lane (r, q), element i: C[m = 16w + 4q + i][n = 16j + r]
     const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
     float* C = static_cast<float*>(g.C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= g.M) continue;
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + r;
+        if (n >= g.N) continue;
+        const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= g.N) continue;
-            float v = acc[i][j];
-            if (g.bias) v += g.bias[n];
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wave * 16 + 4 * q + i;
+            if (m >= g.M) continue;
+            float v = acc[j][i] + bv;
             if (g.relu) v = fmaxf(v, 0.f);
             const size_t o = slab + (size_t)m * g.ldc + n;
             C[o] = g.accumulate ? C[o] + v : v;

@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int kTN = 128, kTC = 64;
+constexpr int kTC = 64;      // c-tile width; the n-tile width TN (128 or 64) is a template parameter
 
 struct WgradArgs {
     const void* dy;      // (B,81,Cout)
@@ -33,26 +33,31 @@ struct WgradArgs {
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <typename T> struct WG;
-template <> struct WG<bf16_t> {
+template <typename T, int TN> struct WG;
+template <int TN> struct WG<bf16_t, TN> {
     static constexpr int KROWS = 96;                 // 81 -> 3 k-steps of 32
-    static constexpr int SY = kTN * 2 + 32;          // dY tile row stride (bytes)
+    static constexpr int SY = TN * 2 + 32;           // dY tile row stride (bytes)
     static constexpr int SX = kTC * 2 + 32;
 };
-template <> struct WG<float> {
+template <int TN> struct WG<float, TN> {
     static constexpr int KROWS = 84;                 // 81 -> 21 k-steps of 4
-    static constexpr int SY = kTN * 4 + 64;
+    static constexpr int SY = TN * 4 + 64;
     static constexpr int SX = kTC * 4 + 64;
 };
 
-template <typename T>
-__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+// TN = 128: 512 threads, wave (nh, cq) = 64 output channels x 16 input channels; one workgroup per CU.
+// TN = 64 : 256 threads, wave cq = all 64 output channels x 16 input channels; two independent workgroups per CU (the
+//           staging / barrier phases of one run under the MFMAs of the other, and a workgroup can share a CU with a
+//           workgroup of another kernel when the weight gradient overlaps the main stream).
+template <typename T, int TN>
+__global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradArgs a) {
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
+    constexpr int NTHR = TN * 4;
     constexpr int ESZ = E::kSize, P16 = E::kPer16;
-    constexpr int SY = WG<T>::SY, SX = WG<T>::SX, KROWS = WG<T>::KROWS;
-    constexpr int PY = kTN * ESZ / 16, PX = kTC * ESZ / 16;      // 16-byte pieces per tile row
-    constexpr int NY = (KA_BOARD * PY + 511) / 512, NX = (KA_BOARD * PX + 511) / 512;
+    constexpr int SY = WG<T, TN>::SY, SX = WG<T, TN>::SX, KROWS = WG<T, TN>::KROWS;
+    constexpr int PY = TN * ESZ / 16, PX = kTC * ESZ / 16;      // 16-byte pieces per tile row
+    constexpr int NY = (KA_BOARD * PY + NTHR - 1) / NTHR, NX = (KA_BOARD * PX + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // bf16: two tile sets (double buffer) -- a wave writes board b+1 into the other set while slower waves still
     // multiply board b, one barrier per board.  f32 tiles are twice as large: single set, two barriers per board.
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int nh = wave & 1, cq = wave >> 1;
+    const int nh = TN == 128 ? (wave & 1) : 0, cq = TN == 128 ? (wave >> 1) : wave;
     // XCD-aware workgroup -> (tile, split) map: workgroups are dealt round-robin over the 8 XCDs, so linear id L sits
     // on XCD L % 8.  All output tiles of one board range (split) are placed on the SAME XCD: they read the same dY / X
     // boards (dY is needed by every c-tile, X by every n-tile), which then hit that XCD's L2 instead of being fetched
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     const int split = xcd + 8 * (slot / a.ntiles);
     if (split >= a.nsplit) return;               // padding workgroups when nsplit % 8 != 0 (uniform exit, no barrier yet)
     const int tn = tile % a.ntn, tc = tile / a.ntn;
-    const int n0 = tn * kTN, c0 = tc * kTC;
+    const int n0 = tn * TN, c0 = tc * kTC;
     const int bbeg = split * a.boards_per_split;
     const int bend = min(a.B, bbeg + a.boards_per_split);
 
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // zero both tiles once: dY pad rows (81..KROWS) and the X halo stay zero forever
-    for (int i = tid; i < NBUF * TILE_BYTES / 16; i += 512)
+    for (int i = tid; i < NBUF * TILE_BYTES / 16; i += NTHR)
         reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
 
     // staging roles
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int row = (tid + i * 512) / PY;
+            const int row = (tid + i * NTHR) / PY;
             ry[i] = (row < KA_BOARD && ycol_ok)
                         ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.dy) +
                               ((size_t)(b * KA_BOARD + row) * a.Cout + n0 + yj * P16) * ESZ)
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int row = (tid + i * 512) / PX;
+            const int row = (tid + i * NTHR) / PX;
             rx[i] = (row < KA_BOARD && xcol_ok)
                         ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.x) +
                               ((size_t)(b * KA_BOARD + row) * a.Cin + c0 + xj * P16) * ESZ)
@@ -129,12 +134,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     auto store_board = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int row = (tid + i * 512) / PY;
+            const int row = (tid + i * NTHR) / PY;
             if (row < KA_BOARD) *reinterpret_cast<vec16*>(ytile + row * SY + yj * 16) = ry[i];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int row = (tid + i * 512) / PX;
+            const int row = (tid + i * NTHR) / PX;
             if (row < KA_BOARD) {
                 vec16 v = rx[i];
                 if (xcol_ok && (has_aff || a.relu || a.in_bias)) {
@@ -303,16 +308,45 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 
 }  // namespace
 
-// target_wgs: workgroups to aim for (0 = one per CU, 256).  Fewer leaves CUs free for kernels that run concurrently
-// on another stream (the engine overlaps wgrad with the HBM-bound backward kernels and asks for 192).
+// n-tile width / workgroup size of the kernel.  Alone on the chip the 64-wide form (256 threads, 2 workgroups per CU) is
+// 16 % faster for a plain input (0.40 vs 0.47 ms at B=4096, C=256) and slower with the fused BatchNorm+ReLU+bias
+// input transform, which it repeats for twice as many n-tiles.  Inside the training step, where the kernel shares the
+// chip with the main stream, the two forms are within 0.3 % of each other (A/B on one box), so the 128-wide form stays
+// the default; KA_WGRAD_TN=64 selects the other.  Both give the same split count.
+static int wgrad_tn(bool fused_input) {
+    (void)fused_input;
+    if (const char* e = getenv("KA_WGRAD_TN")) { if (atoi(e) == 64) return 64; }
+    return 128;
+}
+
+// target_wgs: CUs to aim for (0 = all 256).  Fewer leaves CUs free for kernels that run concurrently on another
+// stream (the engine overlaps wgrad with the HBM-bound backward kernels and asks for 192).
 extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
-    const int tiles = ((Cout + kTN - 1) / kTN) * ((Cin + kTC - 1) / kTC);
+    const int tn = 128;            // the 64-wide variant has twice the tiles and twice the workgroups per CU: same count
+    const int tiles = ((Cout + tn - 1) / tn) * ((Cin + kTC - 1) / kTC);
     if (const char* e = getenv("KA_WGRAD_WGS")) { const int v = atoi(e); if (v > 0) target_wgs = v; }   // experiments
     int s = (target_wgs > 0 ? target_wgs : 256) / tiles;
     if (s < 1) s = 1;
     if (s > B) s = B;
     const int bps = (B + s - 1) / s;
     return (B + bps - 1) / bps;
+}
+
+template <typename T, int TN>
+static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;
+    const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + KA_PADBOARD * WG<T, TN>::SX);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            ka_set_error("wgrad: hipFuncSetAttribute failed");
+            return KA_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<T, TN>), grid, dim3(TN * 4), lds, st, a);
+    return ka_check_launch("wgrad");
 }
 
 extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_scale, const float* in_shift,
@@ -322,40 +356,16 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     KA_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0 && Cin_real <= Cin, "wgrad: need Cin,Cout %% 16 == 0");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tn = wgrad_tn(in_scale || in_bias || relu);
     const int nsplit = ka_wgrad_splits(B, Cin, Cout, target_wgs);
     const int bps = (B + nsplit - 1) / nsplit;
-    const int ntn = (Cout + kTN - 1) / kTN, ntiles = ntn * ((Cin + kTC - 1) / kTC);
+    const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + kTC - 1) / kTC);
     WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit};
     dim3 grid(8 * ntiles * ((nsplit + 7) / 8));
-    if (dtype == KA_DTYPE_BF16) {
-        const size_t lds = 2 * (WG<bf16_t>::KROWS * WG<bf16_t>::SY + KA_PADBOARD * WG<bf16_t>::SX);
-        static bool attr_bf = false;
-        if (!attr_bf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                ka_set_error("wgrad: hipFuncSetAttribute failed");
-                return KA_ERR_HIP;
-            }
-            attr_bf = true;
-        }
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(512), lds, st, a);
-    } else if (dtype == KA_DTYPE_F32) {
-        const size_t lds = WG<float>::KROWS * WG<float>::SY + KA_PADBOARD * WG<float>::SX;
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                ka_set_error("wgrad: hipFuncSetAttribute failed");
-                return KA_ERR_HIP;
-            }
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(512), lds, st, a);
-    } else {
-        ka_set_error("wgrad: unknown dtype %d", dtype);
-        return KA_ERR_ARG;
-    }
-    int rc = ka_check_launch("wgrad");
+    int rc;
+    if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? launch_wgrad<bf16_t, 64>(a, grid, st) : launch_wgrad<bf16_t, 128>(a, grid, st);
+    else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? launch_wgrad<float, 64>(a, grid, st) : launch_wgrad<float, 128>(a, grid, st);
+    else { ka_set_error("wgrad: unknown dtype %d", dtype); return KA_ERR_ARG; }
     if (rc) return rc;
     const size_t total = (size_t)9 * Cout * (Cin / 4);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

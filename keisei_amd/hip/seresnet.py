@@ -93,6 +93,8 @@ class SEResNetEngine:
 
     def _wgrad_launch(self, side, main, inputs, *args) -> None:
         """ka_conv3x3_wgrad on the side stream, ordered after everything already queued on the main stream."""
+        if os.environ.get("KA_DEBUG_SKIP_WGRAD"):        # timing experiments only: gradients are garbage
+            return
         if side is None:
             self._timed("wgrad", "ka_conv3x3_wgrad", *args, _lib.stream_ptr(main.device))
             return

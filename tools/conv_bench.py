@@ -48,9 +48,12 @@ elif which == "conv":
             ms = timeit(fn, n=20)
             print(f"conv KC={kc:3d} WM={wm} {name:42s}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
 else:
-    ns = _lib.query("ka_wgrad_splits", B, C, C, 0)
-    slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
     dy = torch.randn(B, 81, C, device=dev).to(dt)
-    for name, args in (("plain", (None, None, None, 0)), ("fused", (sc, sh, g, 1))):
-        ms = timeit(lambda: _lib.call("ka_conv3x3_wgrad", dy, x, args[0], args[1], args[2], args[3], slab, dw, B, C, C, C, 0, 0, code, _lib.stream_ptr()))
-        print(f"wgrad {name}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
+    for tn in ("128", "64"):
+        os.environ["KA_WGRAD_TN"] = tn
+        for twg in (0, 192):
+            ns = _lib.query("ka_wgrad_splits", B, C, C, twg)
+            slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
+            for name, args in (("plain", (None, None, None, 0)), ("fused", (sc, sh, g, 1))):
+                ms = timeit(lambda: _lib.call("ka_conv3x3_wgrad", dy, x, args[0], args[1], args[2], args[3], slab, dw, B, C, C, C, 0, twg, code, _lib.stream_ptr()))
+                print(f"wgrad TN={tn} target={twg} splits={ns} {name}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)

@@ -562,6 +562,9 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     // workgroups share a CU, and inside the training step that is worth 15 %
     if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;
     int ntw = a.Cout > 128 ? 4 : (a.Cout > 64 ? 2 : 1);
+    // small batches (rollout inference): narrower channel slabs until there is about one workgroup per CU -- measured
+    // at C = 256: 128 boards 34 -> 27 us with 2 tiles per wave, 64 boards 34 -> 24 us with 1
+    while (ntw > 1 && (long long)((a.B + wm - 1) / wm) * ((a.Cout + 64 * ntw - 1) / (64 * ntw)) < 256) ntw >>= 1;
     a.tune_prio = 1;          // static priority for the second wave of every SIMD: it reaches its epilogue first
     // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave
     if (const char* e = getenv("KA_CONV_KC")) { const int v = atoi(e); if (v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v; }

@@ -89,8 +89,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // on the matrix cores with the exact-f32 v_mfma_f32_16x16x4_f32 (wave w owns rows 16w..16w+15 of the 64x64 tile and
 // all four 16-column tiles: 32 MFMAs per K-tile and wave, one ds_read_b32 per operand fragment, row stride 80 floats
 // = conflict-free for the (row/col, k) lane layout).
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
+// NW = waves per workgroup: 4 (each wave a 16x64 strip) or 16 (each wave ONE 16x16 tile) -- the latter for problems with
+// few workgroups (small-batch rollout inference), where the chain of 32 dependent-issue f32 MFMAs per K-tile and wave,
+// not the machine, sets the time; only the first 256 threads stage the tiles.
+template <bool TA, bool TB, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
     constexpr int BK = 32;
     __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
     __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
     //   contiguous-K operand (A not transposed / B transposed): row = t>>3 (+32), k4 = t&7
     //   contiguous-M/N operand: k = t>>4 (+16), col4 = t&15
     f32x4 ra[2], rb[2];
+    const bool loader = NW == 4 || tid < 256;
     auto load_tile = [&](int k0) {
+        if (!loader) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!TA) {
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
         }
     };
     auto store_tile = [&]() {
+        if (!loader) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!TA) {
@@ -152,9 +158,11 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
         }
     };
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    f32x4 acc[4];
+    const int wm = wave & 3, wn = wave >> 2;      // 16-row strip; for NW == 16 also the wave's 16-column tile
+    constexpr int NJ = NW == 4 ? 4 : 1;           // column tiles per wave
+    f32x4 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
@@ -163,23 +171,23 @@ __global__ __launch_bounds__(256) void gemm_f32_fast_kernel(GemmArgs g) {
         if (k0 + BK < kend) load_tile(k0 + BK);          // in flight during the MFMA block
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            const float a = As[kk + q][wave * 16 + r];      // A[m = 16w + r][k = kk + q]
+            const float a = As[kk + q][wm * 16 + r];        // A[m = 16 wm + r][k = kk + q]
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[kk + q][j * 16 + r], acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[kk + q][(NW == 4 ? j : wn) * 16 + r], acc[j], 0, 0, 0);
         }
     }
-    // accumulator lane (r, q), element i: C[m = 16w + 4q + i][n = 16j + r]
+    // accumulator lane (r, q), element i: C[m = 16 wm + 4q + i][n = 16 j + r]
     const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
     float* C = static_cast<float*>(g.C);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + j * 16 + r;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + (NW == 4 ? j : wn) * 16 + r;
         if (n >= g.N) continue;
         const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wave * 16 + 4 * q + i;
+            const int m = m0 + wm * 16 + 4 * q + i;
             if (m >= g.M) continue;
             float v = acc[j][i] + bv;
             if (g.relu) v = fmaxf(v, 0.f);
@@ -311,10 +319,16 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
                          (transA || K % 4 == 0) && (!transB || K % 4 == 0) &&
                          (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
     if (aligned) {
-        if (transA && transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), grid, dim3(256), 0, st, g);
-        else if (transA) hipLaunchKernelGGL((gemm_f32_fast_kernel<true, false>), grid, dim3(256), 0, st, g);
-        else if (transB) hipLaunchKernelGGL((gemm_f32_fast_kernel<false, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_f32_fast_kernel<false, false>), grid, dim3(256), 0, st, g);
+        // few workgroups: 16 waves per workgroup shorten the per-wave MFMA chain (latency-bound small-batch GEMMs)
+        const bool wide = (long long)grid.x * grid.y * grid.z < 128;
+#define KA_GEMM_LAUNCH(TA_, TB_) \
+        do { if (wide) hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 16>), grid, dim3(1024), 0, st, g); \
+             else hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, g); } while (0)
+        if (transA && transB) KA_GEMM_LAUNCH(true, true);
+        else if (transA) KA_GEMM_LAUNCH(true, false);
+        else if (transB) KA_GEMM_LAUNCH(false, true);
+        else KA_GEMM_LAUNCH(false, false);
+#undef KA_GEMM_LAUNCH
     } else {
         hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
     }

@@ -20,6 +20,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional
 
 import os
+import threading
 
 import torch
 import torch.distributed as dist
@@ -48,6 +49,8 @@ class SEResNetEngine:
         self._redws: Optional[torch.Tensor] = None
         self._side = None
         self._pack_tkey = None
+        self._graphs = {}             # (batch, dtype, parameter storage) -> captured eval forward (rollout inference path)
+        self._graph_lock = threading.Lock()
         self._pack_table = None
         self._pack_max = 0
         self._wslab: Optional[torch.Tensor] = None
@@ -230,6 +233,43 @@ class SEResNetEngine:
         dx = dx_out if dx_out is not None else torch.empty(M, K, device=dev)
         self._gemm(dy, lin.weight, dx, None, M, K, N, N, K, K, 0, 0, st, acc=acc_dx)
         return dx
+
+    # ------------------------------------------------------------------ rollout inference: graph-captured eval forward
+    def forward_eval_graphed(self, obs: torch.Tensor, T: torch.dtype):
+        """Eval-mode forward without saved activations, replayed from a captured HIP graph.  The small-batch rollout
+        forward (select_actions: N = number of environments) is ~500 short launches and therefore launch-bound; a
+        graph per (batch size, dtype, parameter storage) replays them without per-launch host work.  BatchNorm eval
+        coefficients are computed inside the graph from the live running statistics; the fragment-ordered weight
+        packs are refreshed (outside the graph, only when the weights changed) into the buffers the graph reads."""
+        m = self.model
+        dev = obs.device
+        if obs.dtype != torch.float32 or not obs.is_contiguous():
+            obs = obs.float().contiguous()
+        self._get_packs(T, dev)
+        key = (tuple(obs.shape), T, str(dev), self._pack_tkey,
+               tuple(b.data_ptr() for b in m.buffers()), tuple(q.data_ptr() for q in m.parameters()))
+        with self._graph_lock:
+            ent = self._graphs.get(key)
+            if ent is None:
+                if len(self._graphs) >= 8:
+                    self._graphs.clear()
+                static_in = obs.clone()
+                saved_overlap = self.overlap_wgrad
+                self.overlap_wgrad = False              # single-stream capture
+                try:
+                    self.forward(static_in, False, False, T, None)            # warm-up: one-time kernel attributes etc.
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        out = self.forward(static_in, False, False, T, None)[:3]
+                finally:
+                    self.overlap_wgrad = saved_overlap
+                ent = (graph, static_in, out)
+                self._graphs[key] = ent
+            graph, static_in, out = ent
+            static_in.copy_(obs)
+            graph.replay()
+            return tuple(t.clone() for t in out)
 
     # ------------------------------------------------------------------ forward
     def forward(self, obs: torch.Tensor, train: bool, keep: bool, T: torch.dtype, idx: Optional[torch.Tensor] = None):
@@ -572,6 +612,10 @@ def run_model(model: nn.Module, obs: torch.Tensor, idx: Optional[torch.Tensor] =
     T = torch.bfloat16 if bf16 else torch.float32
     named = [(n, p) for n, p in model.named_parameters()]
     keep = torch.is_grad_enabled() and any(p.requires_grad for _, p in named)
+    if (not keep and not model.training and idx is None and not torch.is_grad_enabled() and obs.shape[0] <= 2048
+            and os.environ.get("KA_EVAL_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
+        with torch.autocast("cuda", enabled=False):
+            return engine.forward_eval_graphed(obs, T)
     names = tuple(n for n, _ in named)
     with torch.autocast("cuda", enabled=False):
         return _SEResNetFunction.apply(engine, obs, idx, model.training, keep, T, names, *[p for _, p in named])

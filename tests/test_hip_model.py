@@ -210,3 +210,37 @@ def test_bf16_backward_tracks_fp32_gradients():
         worst = min(worst, cos)
         assert cos > 0.95 and 0.8 < ratio < 1.25, (n, cos, ratio)
     print("worst cosine", worst)
+
+
+def test_eval_graph_matches_eager_and_tracks_weights(monkeypatch):
+    """The graph-captured eval forward (rollout inference) equals the eager launch sequence, is deterministic on
+    replay, and sees in-place weight / running-statistics updates made after the capture."""
+    torch.manual_seed(3)
+    m = SEResNetModel(SEResNetParams(num_blocks=2, channels=32, se_reduction=8, global_pool_channels=16,
+                                     policy_channels=8, value_fc_size=32, score_fc_size=16, obs_channels=50)).to(DEV).eval()
+    obs = torch.randn(6, 50, 9, 9, device=DEV)
+
+    def run(graph):
+        monkeypatch.setenv("KA_EVAL_GRAPH", "1" if graph else "0")
+        with torch.no_grad():
+            o = m(obs)
+        return o.policy_logits.clone(), o.value_logits.clone(), o.score_lead.clone()
+
+    eager = run(False)
+    first = run(True)        # capture
+    replay = run(True)       # replay
+    for a, b, c in zip(eager, first, replay):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    with torch.no_grad():
+        m.blocks[0].conv1.weight.mul_(1.25)
+        m.input_bn.running_mean.add_(0.05)
+        m.value_fc2.bias.add_(0.5)
+    eager2 = run(False)
+    replay2 = run(True)
+    assert not torch.equal(eager2[0], eager[0])
+    for a, b in zip(eager2, replay2):
+        assert torch.equal(a, b)
+    # a different batch size gets its own graph
+    obs = torch.randn(3, 50, 9, 9, device=DEV)
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // bf16: two tile sets (double buffer) -- a wave writes board b+1 into the other set while slower waves still
     // multiply board b, one barrier per board.  f32 tiles are twice as large: single set, two barriers per board.
-    constexpr int NBUF = (sizeof(T) == 2) ? 2 : 1;
+    // FLAT (bf16, 128-wide tile): the K dimension is the FLAT row index over the workgroup's whole board range, cut
+    // into steps of 32 rows that may straddle two boards (a ring of three board tiles), instead of 3 steps per board
+    // with 15 zero rows in the last one: 81/32 = 2.53 steps per board, 15.6 % fewer MFMAs.
+    constexpr bool FLAT = sizeof(T) == 2 && TN == 128;
+    constexpr int NBUF = FLAT ? 3 : ((sizeof(T) == 2) ? 2 : 1);
     constexpr int TILE_BYTES = KROWS * SY + KA_PADBOARD * SX;
     char* ytile = smem;
     char* xtile = smem + KROWS * SY;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     const bool c_ok = c0 + cq * 16 < a.Cin;
 
     if (bbeg < bend) load_board(bbeg);
-    if (NBUF == 2) {
+    if (NBUF >= 2) {
         __syncthreads();                 // zero fill complete
         if (bbeg < bend) { store_board(bbeg); if (bbeg + 1 < bend) load_board(bbeg + 1); }
         __syncthreads();
@@ -183,9 +187,9 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
         } else {
             // stage board b+1 into the other tile set (its registers were loaded one iteration ago), then start
             // the loads of board b+2; the single barrier at the bottom closes both hazards
-            const int cur = (b - bbeg) & 1;
+            const int cur = (b - bbeg) % NBUF, nxt = (b - bbeg + 1) % NBUF;
             if (b + 1 < bend) {
-                ytile = smem + (cur ^ 1) * TILE_BYTES; xtile = ytile + KROWS * SY;
+                ytile = smem + nxt * TILE_BYTES; xtile = ytile + KROWS * SY;
                 store_board(b + 1);
                 if (b + 2 < bend) load_board(b + 2);
             }
@@ -198,35 +202,61 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             // branch-free MFMA stream: tiles beyond Cout multiply zero-filled LDS columns and are never stored.
             // B fragments (the tap-shifted X rows) are fetched one tap ahead; the issue order is pinned so each
             // pair of transpose reads sits in front of the 4 MFMAs of the previous tap.
-            auto load_b = [&](int ks, int tap) {
-                const int k1 = ks * 32 + 4 * q + (r >> 2), k2 = k1 + 16;   // k-slot permutation, see below
-                const int i1 = (k1 < KA_BOARD) ? pad_index(k1) : 12, i2 = (k2 < KA_BOARD) ? pad_index(k2) : 12;
-                const int colx = (cq * 16 + 4 * (r & 3)) * 2;
-                const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i1 + toff) * SX + colx));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xtile + (i2 + toff) * SX + colx));
-                return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            // rows of k-step ks for this lane: k1 = 32 ks + 4q + (r>>2), k2 = k1 + 16 (k-slot permutation, see below).
+            // Per board: ks = 0..2, rows >= 81 are the zero pad rows of the dY tile.  FLAT: ks counts 32-row steps of the
+            // flat row index over the board range; a row belongs to board jl (this iteration's) or jl-1 (the previous
+            // tile of the ring); rows past the range read the zero pad row 81.
+            const int jl = b - bbeg, nb = bend - bbeg;
+            const char* yprev = smem + ((jl + NBUF - 1) % NBUF) * TILE_BYTES;
+            auto row_ptrs = [&](int k, const char*& yrow, const char*& xrow) {
+                if (FLAT) {
+                    int p = k - KA_BOARD * jl;
+                    const bool prev = p < 0;
+                    p = prev ? p + KA_BOARD : p;
+                    const char* yt = prev ? yprev : ytile;
+                    const bool pad = p >= KA_BOARD;                 // only past the end of the range (last step)
+                    yrow = yt + (pad ? KA_BOARD : p) * SY;
+                    xrow = yt + KROWS * SY + (pad ? 12 : pad_index(p)) * SX;
+                } else {
+                    yrow = ytile + k * SY;
+                    xrow = xtile + ((k < KA_BOARD) ? pad_index(k) : 12) * SX;
+                }
             };
+            const int ks_lo = FLAT ? (KA_BOARD * jl) / 32 : 0;
+            const int ks_hi = FLAT ? (jl + 1 == nb ? (KA_BOARD * nb + 31) / 32 : (KA_BOARD * (jl + 1)) / 32) : 3;
 #pragma unroll 1
-            for (int ks = 0; ks < 3; ++ks) {
+            for (int ks = ks_lo; ks < ks_hi; ++ks) {
                 // MFMA k-slot (q, j) is mapped to tile row 4q+j (j<4) / 16+4q+(j-4) (j>=4) for BOTH operands (any
                 // common permutation of k is legal): each 32-lane half of a transpose read then covers 8 CONSECUTIVE
                 // rows, which the 32*odd-byte row strides spread over all 64 banks (the natural 8q+j map makes a half
                 // read rows {k..k+3, k+8..k+11}: a guaranteed 2-way conflict)
                 const int k1 = ks * 32 + 4 * q + (r >> 2), k2 = k1 + 16;
+                const char *y1, *x1, *y2, *x2;
+                row_ptrs(k1, y1, x1);
+                row_ptrs(k2, y2, x2);
+                const int colx = (cq * 16 + 4 * (r & 3)) * 2;
+                // B fragments (the tap-shifted X rows) are fetched one tap ahead; the issue order is pinned so each pair
+                // of transpose reads sits in front of the 4 MFMAs of the previous tap.  Branch-free MFMA stream: tiles
+                // beyond Cout multiply zero-filled LDS columns and are never stored.
+                auto load_b = [&](int tap) {
+                    const int toff = ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * SX + colx;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(x1 + toff));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(x2 + toff));
+                    return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
                 bf16x8 af[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int colb = ((nh * 4 + t) * 16 + 4 * (r & 3)) * 2;
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ytile + k1 * SY + colb));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ytile + k2 * SY + colb));
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(y1 + colb));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(y2 + colb));
                     af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                bf16x8 bcur = load_b(ks, 0);
+                bf16x8 bcur = load_b(0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     bf16x8 bnext = bcur;
-                    if (tap < 8) bnext = load_b(ks, tap + 1);
+                    if (tap < 8) bnext = load_b(tap + 1);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bcur, acc[tap][t], 0, 0, 0);
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             }
         }
         }
-        if (NBUF == 2) __syncthreads();
+        if (NBUF >= 2) __syncthreads();
     }
 
     // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
@@ -334,7 +364,7 @@ extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
 
 template <typename T, int TN>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
-    constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;
+    constexpr int NBUF = (sizeof(T) == 2 && TN == 128) ? 3 : (sizeof(T) == 2 ? 2 : 1);   // as in the kernel
     const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + KA_PADBOARD * WG<T, TN>::SX);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {

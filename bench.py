@@ -224,6 +224,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     metrics = algo._fused_end(fs)
+    timed_events = getattr(engine, "kernel_events", None)
+    engine.kernel_events = None                  # the per-launch events belong to the timed region only
     whole = None
     if args.whole_update and rank == 0:
         whole = whole_update_rate(algo, adapter, T, N, device)
@@ -237,7 +239,7 @@ def main() -> None:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         roof = None
         extra = {}
-        ev = getattr(engine, "kernel_events", None)
+        ev = timed_events
         if ev and ev["conv3x3"]:
             conv_ms = [a.elapsed_time(b) for a, b in ev["conv3x3"]]
             conv_flop = 2.0 * B * 81 * 9 * C * C

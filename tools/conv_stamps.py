@@ -12,8 +12,8 @@ _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, code, _lib.stream_ptr())
 out = torch.empty_like(x); rows = _lib.query("ka_conv3x3_sqpart_rows", B)
 bsum = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)
 for kc, ntw, wm in [(128, 4, 2), (64, 4, 2)]:
-    os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = str(wm)
-    nwg = (B + 1) // 2
+    os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = "1"
+    nwg = B
     for _ in range(3):
         _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())
     stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)

@@ -3,24 +3,25 @@
 //   out[b,p,n] = sum_{tap,c} X'[b, p+tap, c] * W[n,c,tap]      X' = optional fused transform of the input
 //
 // Layout: activations are NHWC (B,81,C), channel-contiguous, so every HBM access is a
-// coalesced run along the channel axis.  One workgroup (8 waves, two per SIMD) owns NB=2 whole
-// boards and a slab of output channels: the boards are staged ONCE into LDS as zero-haloed
-// 17-wide tiles ([padded square][channel]), after which each of the 9 taps is just a constant
-// LDS offset ((dy*17+dx)*row_stride) on the MFMA operand read -- the input is read from HBM
-// exactly once per output-channel slab.  Weights are pre-packed (pack_conv3x3_kernel) in MFMA
-// fragment order so a wave streams them from L2 with perfectly coalesced 1 KiB loads straight
-// into registers; no weight goes through LDS.
+// coalesced run along the channel axis.  One 256-thread workgroup (4 waves, one per SIMD) owns
+// ONE whole board and a slab of output channels, and two such workgroups share a CU: they are
+// independent, so the staging and epilogue of one run under the MFMA loop of the other (the
+// 512-thread form with two boards per workgroup is kept behind KA_CONV_WM=2).  The board is
+// staged ONCE into LDS as a zero-haloed 17-wide image ([padded square][channel]), after which
+// each of the 9 taps is just a constant LDS offset ((dy*17+dx)*row_stride) on the MFMA operand
+// read -- the input is read from HBM exactly once per output-channel slab.  Weights are
+// pre-packed (pack_conv3x3_kernel) in MFMA fragment order so a wave streams them from L2 with
+// perfectly coalesced 1 KiB loads straight into registers; no weight goes through LDS.
 //
-// Wave tile: wave (h, w) owns board h of the pair -- its 81 squares padded to 6 row tiles of 16
-// -- and the w-th quarter of the channel slab.  The weights are the MFMA "A" operand and the
-// activations the "B" operand, i.e. the kernel computes out^T: an accumulator lane then holds
-// 4 CONSECUTIVE channel slots of one square, and the pack interleaves neighbouring 16-channel
-// tiles so that a lane owns runs of 8 consecutive channels.  The epilogue therefore works
-// entirely in registers: the per-board channel sums (= SE squeeze, and summed over boards the
-// BN mean) and sums of squares are DPP reductions over the 16 square lanes of a wave that owns
-// the whole board, and the output tile is stored straight from the accumulators in 16-byte
-// pieces -- no LDS transpose and no barrier after the main loop, so the wave of a SIMD that
-// finishes first (static priority) runs its epilogue under the other wave's MFMAs.
+// Wave tile: wave w owns the board's 81 squares, padded to 6 row tiles of 16, and the w-th
+// quarter of the channel slab.  The weights are the MFMA "A" operand and the activations the
+// "B" operand, i.e. the kernel computes out^T: an accumulator lane then holds 4 CONSECUTIVE
+// channel slots of one square, and the pack interleaves neighbouring 16-channel tiles so that
+// a lane owns runs of 8 consecutive channels.  The epilogue therefore works entirely in
+// registers: the per-board channel sums (= SE squeeze, and summed over boards the BN mean) and
+// sums of squares are DPP reductions over the 16 square lanes of a wave that owns the whole
+// board, and the output tile is stored straight from the accumulators in 16-byte pieces -- no
+// LDS transpose and no barrier after the main loop.
 // (v_mfma_f32_16x16x32_bf16 / 4x v_mfma_f32_16x16x4_f32; the f32 path is exact f32 (parity
 // mode), the bf16 path is the throughput mode.)
 //

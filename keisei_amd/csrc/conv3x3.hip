@@ -351,6 +351,23 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
         int cb[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) cb[j] = chan_of(min(nt0 + j, NT - 1), 4 * q, NT);
+        // masked epilogue: the y pieces of the first tile pair are requested BEFORE the statistics arithmetic, which
+        // then covers their HBM latency (requesting both pairs up front spills and is slower)
+        constexpr int TP0 = NTW >= 2 ? 2 : 1;
+        typedef __attribute__((ext_vector_type(4 * TP0))) __bf16 bvec0;
+        bvec0 yv0[kMTW];
+        if constexpr (sizeof(T) == 2) {
+            if (a.ep_y) {
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const int p = mt * 16 + r;
+                    yv0[mt] = bvec0{};
+                    if (p < KA_BOARD)
+                        yv0[mt] = *reinterpret_cast<const bvec0*>(static_cast<const char*>(a.ep_y) +
+                                                                  ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[0]) * 2);
+                }
+            }
+        }
         if (a.bsum || a.sqpart) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
@@ -408,6 +425,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < kMTW; ++mt) {
                         const int p = mt * 16 + r;
+                        if (j == 0) { yv[mt] = yv0[mt]; continue; }
                         yv[mt] = bvec{};
                         if (p < KA_BOARD)
                             yv[mt] = *reinterpret_cast<const bvec*>(static_cast<const char*>(a.ep_y) +

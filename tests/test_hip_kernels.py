@@ -557,3 +557,66 @@ def test_tail_bwd_fused_matches_unfused_sequence(dtn, B, C, H):
     close(s1.cpu(), s1r.cpu(), torch.float32, k=10)
     close(s2.cpu(), s2r.cpu(), torch.float32, k=10)
     assert not _lib.query("ka_tail_bwd_fused_supported", 48, 5, code)
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
+def test_pack_multi_equals_single_packs(dtn):
+    """ka_pack_conv3x3_multi (all layers in one launch) writes byte-identical packs to per-layer ka_pack_conv3x3 calls."""
+    dt = DT[dtn]
+    code = _lib.dtype_code(dt)
+    cpk = 32 if dt == torch.bfloat16 else 16
+    g = torch.Generator().manual_seed(77)
+    specs = [(64, 50, 64, 64, 0), (64, 64, 64, 64, 0), (64, 64, 64, 64, 1), (128, 64, 128, 64, 0), (128, 64, 64, 128, 1)]
+    ws, singles, multis, jobs, mx = [], [], [], [], 0
+    for co, ci, nout, kin, mode in specs:
+        w = torch.randn(co, ci, 3, 3, generator=g).to(DEV)
+        n = 9 * (kin // cpk) * (nout // 16) * 64
+        a = torch.zeros(n * 16, dtype=torch.uint8, device=DEV); b = torch.zeros_like(a)
+        _lib.call("ka_pack_conv3x3", w, a, co, ci, nout, kin, mode, code, st())
+        jobs.append([w.data_ptr(), b.data_ptr(), co, ci, nout, kin, mode, 0]); mx = max(mx, n)
+        ws.append(w); singles.append(a); multis.append(b)
+    table = torch.tensor(jobs, dtype=torch.int64).to(DEV)
+    _lib.call("ka_pack_conv3x3_multi", table, len(jobs), mx, code, st())
+    torch.cuda.synchronize()
+    for a, b in zip(singles, multis):
+        assert torch.equal(a, b)
+
+
+def test_bn_coefficients_from_partials_match_two_step_path():
+    """ka_bn_reduce / ka_pair_reduce with sums == NULL + ka_bn_(bwd_)coeffs_parts == the reduced-sums path."""
+    B, C = 37, 64
+    g = torch.Generator().manual_seed(5)
+    bsum = torch.randn(B, C, generator=g).to(DEV); sq = (torch.rand(B, C, generator=g) + 1.0).to(DEV) * 81
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    count = float(B * 81)
+    ws = torch.empty(_lib.query("ka_reduce_workspace_doubles", C), dtype=torch.float64, device=DEV)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        sc, sh, mu, istd = (torch.empty(C, device=DEV) for _ in range(4))
+        if fused:
+            _lib.call("ka_bn_reduce", bsum, B, sq, B, C, None, ws, st())
+            _lib.call("ka_bn_coeffs_parts", ws, count, gamma, beta, rm, rv, nbt, 0.1, 1e-5, sc, sh, mu, istd, C, st())
+        else:
+            _lib.call("ka_bn_reduce", bsum, B, sq, B, C, sums, ws, st())
+            _lib.call("ka_bn_coeffs", sums, count, None, gamma, beta, rm, rv, nbt, 0.1, 1e-5, sc, sh, mu, istd, C, st())
+        outs.append((sc, sh, mu, istd, rm, rv, nbt.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    s1, s2 = torch.randn(B, C, generator=g).to(DEV), torch.randn(B, C, generator=g).to(DEV)
+    mu, istd = outs[0][2], outs[0][3]
+    outs = []
+    for fused in (False, True):
+        dg, db, k = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)
+        if fused:
+            _lib.call("ka_pair_reduce", s1, s2, B, C, None, ws, st())
+            _lib.call("ka_bn_bwd_coeffs_parts", ws, count, gamma, mu, istd, dg, db, k, C, 1, st())
+        else:
+            _lib.call("ka_pair_reduce", s1, s2, B, C, sums, ws, st())
+            _lib.call("ka_bn_bwd_coeffs", sums, sums, count, None, gamma, mu, istd, dg, db, k, C, 1, st())
+        outs.append((dg, db, k))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

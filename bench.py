@@ -156,11 +156,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    backend = os.environ.get("KA_BENCH_BACKEND", "nccl")     # "gloo": rehearse the N > 1 wiring with several ranks on ONE GPU
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams
     from keisei_amd.training.model_registry import build_model
@@ -178,7 +183,7 @@ def main() -> None:
     fwd_model = model
     if world > 1:
         fwd_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        fwd_model = torch.nn.parallel.DistributedDataParallel(fwd_model, device_ids=[local_rank], gradient_as_bucket_view=True)
+        fwd_model = torch.nn.parallel.DistributedDataParallel(fwd_model, device_ids=[dev_index], gradient_as_bucket_view=True)
         model = fwd_model.module
     pp = KataGoPPOParams(batch_size=B, use_amp=(args.dtype == "bf16"), lambda_score=0.1, score_blend_alpha=0.1,
                          compile_mode="default")        # keisei-katago.toml:33-49 (compile_mode accepted, unused)

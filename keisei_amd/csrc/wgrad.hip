@@ -35,11 +35,17 @@ typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
 template <typename T, int TN> struct WG;
 template <int TN> struct WG<bf16_t, TN> {
-    static constexpr int KROWS = 96;                 // 81 -> 3 k-steps of 32
+    // 128-wide tile (flat K): 81 rows + one zero row; the haloed X tile is 17 squares wide (as the conv3x3 image: a
+    // board-row wrap then advances the square index by 9 = 1 mod 8, so the 8 consecutive rows of a transpose-read half
+    // stay on 8 different 32-byte bank groups -- with the natural 11-wide tile two of them collide at every wrap;
+    // rocprof: 30 % of the LDS cycles of this kernel were bank conflicts).  64-wide tile: per-board K, 81 -> 96 rows.
+    static constexpr int KROWS = TN == 128 ? 82 : 96;
+    static constexpr int PW = TN == 128 ? 17 : 11;   // padded board-row width of the X tile
     static constexpr int SY = TN * 2 + 32;           // dY tile row stride (bytes)
     static constexpr int SX = kTC * 2 + 32;
 };
 template <int TN> struct WG<float, TN> {
+    static constexpr int PW = 11;
     static constexpr int KROWS = 84;                 // 81 -> 21 k-steps of 4
     static constexpr int SY = TN * 4 + 64;
     static constexpr int SX = kTC * 4 + 64;
@@ -56,6 +62,8 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     constexpr int NTHR = TN * 4;
     constexpr int ESZ = E::kSize, P16 = E::kPer16;
     constexpr int SY = WG<T, TN>::SY, SX = WG<T, TN>::SX, KROWS = WG<T, TN>::KROWS;
+    constexpr int PW = WG<T, TN>::PW, XSQ = 11 * PW;             // haloed X tile: 11 rows of PW squares
+    auto xsq = [](int p) { return (p / 9 + 1) * PW + (p % 9) + 1; };   // tile index of board square p
     constexpr int PY = TN * ESZ / 16, PX = kTC * ESZ / 16;      // 16-byte pieces per tile row
     constexpr int NY = (KA_BOARD * PY + NTHR - 1) / NTHR, NX = (KA_BOARD * PX + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     // with 15 zero rows in the last one: 81/32 = 2.53 steps per board, 15.6 % fewer MFMAs.
     constexpr bool FLAT = sizeof(T) == 2 && TN == 128;
     constexpr int NBUF = FLAT ? 3 : ((sizeof(T) == 2) ? 2 : 1);
-    constexpr int TILE_BYTES = KROWS * SY + KA_PADBOARD * SX;
+    constexpr int TILE_BYTES = KROWS * SY + XSQ * SX;
     char* ytile = smem;
     char* xtile = smem + KROWS * SY;
 
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
                     }
                     v = E::pack(f);
                 }
-                *reinterpret_cast<vec16*>(xtile + pad_index(row) * SX + xj * 16) = v;
+                *reinterpret_cast<vec16*>(xtile + xsq(row) * SX + xj * 16) = v;
             }
         }
     };
@@ -216,10 +224,10 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
                     const char* yt = prev ? yprev : ytile;
                     const bool pad = p >= KA_BOARD;                 // only past the end of the range (last step)
                     yrow = yt + (pad ? KA_BOARD : p) * SY;
-                    xrow = yt + KROWS * SY + (pad ? 12 : pad_index(p)) * SX;
+                    xrow = yt + KROWS * SY + xsq(pad ? 0 : p) * SX;
                 } else {
                     yrow = ytile + k * SY;
-                    xrow = xtile + ((k < KA_BOARD) ? pad_index(k) : 12) * SX;
+                    xrow = xtile + xsq(k < KA_BOARD ? k : 0) * SX;
                 }
             };
             const int ks_lo = FLAT ? (KA_BOARD * jl) / 32 : 0;
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
                 // of transpose reads sits in front of the 4 MFMAs of the previous tap.  Branch-free MFMA stream: tiles
                 // beyond Cout multiply zero-filled LDS columns and are never stored.
                 auto load_b = [&](int tap) {
-                    const int toff = ((tap / 3 - 1) * 11 + (tap % 3 - 1)) * SX + colx;
+                    const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * SX + colx;
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(x1 + toff));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(x2 + toff));
                     return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     af[t] = *reinterpret_cast<const float*>(ytile + k * SY + ((nh * 4 + t) * 16 + r) * 4);
-                const int ik = (k < KA_BOARD) ? pad_index(k) : 12;
+                const int ik = xsq(k < KA_BOARD ? k : 0);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int toff = (tap / 3 - 1) * 11 + (tap % 3 - 1);
+                    const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
                     const float bv = *reinterpret_cast<const float*>(xtile + (ik + toff) * SX + (cq * 16 + r) * 4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -365,7 +373,7 @@ extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
 template <typename T, int TN>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NBUF = (sizeof(T) == 2 && TN == 128) ? 3 : (sizeof(T) == 2 ? 2 : 1);   // as in the kernel
-    const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + KA_PADBOARD * WG<T, TN>::SX);
+    const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + 11 * WG<T, TN>::PW * WG<T, TN>::SX);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TN>),

@@ -55,7 +55,10 @@ template <int TN> struct WG<float, TN> {
 // TN = 64 : 256 threads, wave cq = all 64 output channels x 16 input channels; two independent workgroups per CU (the
 //           staging / barrier phases of one run under the MFMAs of the other, and a workgroup can share a CU with a
 //           workgroup of another kernel when the weight gradient overlaps the main stream).
-template <typename T, int TN>
+// FUSED = the X operand gets the BatchNorm+ReLU+bias input transform (conv2's weight gradient); the plain form carries
+// no per-channel coefficients.  (Ablation: the board-prefetch global loads cost 14 % of the kernel at their one-board
+// distance; a second register set for a two-board distance does not fit -- it spills and is 30 % slower.)
+template <typename T, int TN, bool FUSED>
 __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradArgs a) {
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
@@ -108,21 +111,22 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     // staging roles
     const int yj = tid % PY, xj = tid % PX;
     const bool ycol_ok = n0 + yj * P16 < a.Cout, xcol_ok = c0 + xj * P16 < a.Cin;
-    float sc[P16], sh[P16];
-    const bool has_aff = a.in_scale != nullptr;
+    constexpr int NSETS = 1;                              // board-prefetch register sets (two do not fit, see above)
+    float sc[FUSED ? P16 : 1], sh[FUSED ? P16 : 1];
+    const bool has_aff = FUSED && a.in_scale != nullptr;
     if (has_aff && xcol_ok) {
 #pragma unroll
         for (int e = 0; e < P16; ++e) { sc[e] = a.in_scale[c0 + xj * P16 + e]; sh[e] = a.in_shift[c0 + xj * P16 + e]; }
     }
-    vec16 ry[NY], rx[NX];
-    float rb[P16];                          // per-board bias of this thread's X channel piece
+    vec16 ry[NSETS][NY], rx[NSETS][NX];
+    float rb[FUSED ? P16 : 1];              // per-board bias of this thread's X channel piece
     auto zero16 = [&] { float z[P16];
 #pragma unroll
         for (int e = 0; e < P16; ++e) z[e] = 0.f;
         return E::pack(z); };
 
-    auto load_board = [&](int b) {
-        if (a.in_bias && xcol_ok) {
+    auto load_board = [&](int b, vec16 (&ry)[NY], vec16 (&rx)[NX]) {
+        if (FUSED && a.in_bias && xcol_ok) {
 #pragma unroll
             for (int e = 0; e < P16; ++e) rb[e] = a.in_bias[(size_t)b * a.Cin + c0 + xj * P16 + e];
         }
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
                         : zero16();
         }
     };
-    auto store_board = [&](int b) {
+    auto store_board = [&](int b, const vec16 (&ry)[NY], const vec16 (&rx)[NX]) {
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int row = (tid + i * NTHR) / PY;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             const int row = (tid + i * NTHR) / PX;
             if (row < KA_BOARD) {
                 vec16 v = rx[i];
-                if (xcol_ok && (has_aff || a.relu || a.in_bias)) {
+                if (FUSED && xcol_ok && (has_aff || a.relu || a.in_bias)) {
                     float f[P16];
                     E::unpack(v, f);
                     if (has_aff) {
@@ -180,27 +184,39 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     const int ntn_valid = min(4, max(0, (a.Cout - n0 - nh * 64 + 15) / 16));   // valid n-tiles of this wave
     const bool c_ok = c0 + cq * 16 < a.Cin;
 
-    if (bbeg < bend) load_board(bbeg);
+    // Board j of the range travels through register set j % NSETS.  One set: the loads of board b+2 are issued in
+    // iteration b, right after the set was emptied into the tile of board b+1.  Two sets: iteration b empties the set of
+    // board b+1 and refills it with board b+3.
+    constexpr int AHEAD = NSETS + 1;
+    if (bbeg < bend) load_board(bbeg, ry[0], rx[0]);
     if (NBUF >= 2) {
         __syncthreads();                 // zero fill complete
-        if (bbeg < bend) { store_board(bbeg); if (bbeg + 1 < bend) load_board(bbeg + 1); }
+        if (bbeg < bend) {
+            store_board(bbeg, ry[0], rx[0]);
+            if (bbeg + 1 < bend) load_board(bbeg + 1, ry[NSETS - 1], rx[NSETS - 1]);
+            if (NSETS == 2 && bbeg + 2 < bend) load_board(bbeg + 2, ry[0], rx[0]);
+        }
         __syncthreads();
     }
-    for (int b = bbeg; b < bend; ++b) {
+    auto stage_next = [&](int b, vec16 (&ys)[NY], vec16 (&xs)[NX]) {
+        // stage board b+1 into the next tile of the ring (its registers were loaded AHEAD-1 iterations ago), then start
+        // the loads of board b+AHEAD into the same set; the single barrier at the bottom closes both hazards
+        if (b + 1 < bend) {
+            ytile = smem + ((b - bbeg + 1) % NBUF) * TILE_BYTES; xtile = ytile + KROWS * SY;
+            store_board(b + 1, ys, xs);
+            if (b + AHEAD < bend) load_board(b + AHEAD, ys, xs);
+        }
+    };
+    // one board; ys/xs = the register set of board b+1 (compile-time choice: the loop below is unrolled by two)
+    auto board_iter = [&](int b, vec16 (&ys)[NY], vec16 (&xs)[NX]) {
         if (NBUF == 1) {
             __syncthreads();                 // previous board fully consumed
-            store_board(b);
+            store_board(b, ys, xs);
             __syncthreads();
-            if (b + 1 < bend) load_board(b + 1);      // in flight during the MFMA phase
+            if (b + 1 < bend) load_board(b + 1, ys, xs);      // in flight during the MFMA phase
         } else {
-            // stage board b+1 into the other tile set (its registers were loaded one iteration ago), then start
-            // the loads of board b+2; the single barrier at the bottom closes both hazards
-            const int cur = (b - bbeg) % NBUF, nxt = (b - bbeg + 1) % NBUF;
-            if (b + 1 < bend) {
-                ytile = smem + nxt * TILE_BYTES; xtile = ytile + KROWS * SY;
-                store_board(b + 1);
-                if (b + 2 < bend) load_board(b + 2);
-            }
+            const int cur = (b - bbeg) % NBUF;
+            stage_next(b, ys, xs);
             ytile = smem + cur * TILE_BYTES; xtile = ytile + KROWS * SY;
         }
         const bool skip = !c_ok || ntn_valid == 0;    // wave-uniform
@@ -300,6 +316,15 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
         }
         }
         if (NBUF >= 2) __syncthreads();
+    };
+    if (NSETS == 2) {
+        for (int b = bbeg; b < bend; b += 2) {           // board b+1 is odd within the range -> set 1, b+2 even -> set 0
+            board_iter(b, ry[NSETS - 1], rx[NSETS - 1]);
+            if (b + 1 < bend) board_iter(b + 1, ry[0], rx[0]);
+        }
+    } else {
+#pragma unroll 1
+        for (int b = bbeg; b < bend; ++b) board_iter(b, ry[0], rx[0]);
     }
 
     // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
@@ -370,20 +395,20 @@ extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
     return (B + bps - 1) / bps;
 }
 
-template <typename T, int TN>
+template <typename T, int TN, bool FUSED>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NBUF = (sizeof(T) == 2 && TN == 128) ? 3 : (sizeof(T) == 2 ? 2 : 1);   // as in the kernel
     const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + 11 * WG<T, TN>::PW * WG<T, TN>::SX);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TN, FUSED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             ka_set_error("wgrad: hipFuncSetAttribute failed");
             return KA_ERR_HIP;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, TN>), grid, dim3(TN * 4), lds, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, FUSED>), grid, dim3(TN * 4), lds, st, a);
     return ka_check_launch("wgrad");
 }
 
@@ -401,8 +426,11 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit};
     dim3 grid(8 * ntiles * ((nsplit + 7) / 8));
     int rc;
-    if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? launch_wgrad<bf16_t, 64>(a, grid, st) : launch_wgrad<bf16_t, 128>(a, grid, st);
-    else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? launch_wgrad<float, 64>(a, grid, st) : launch_wgrad<float, 128>(a, grid, st);
+    const bool fused = in_scale || in_bias || relu;
+#define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
+    if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
+    else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);
+#undef KA_WG
     else { ka_set_error("wgrad: unknown dtype %d", dtype); return KA_ERR_ARG; }
     if (rc) return rc;
     const size_t total = (size_t)9 * Cout * (Cin / 4);

@@ -571,12 +571,17 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     int wm = 1;
     if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }   // experiments
     const int img_squares = wm == 2 ? kLdsSquares : 11 * kPW;
-    // largest LDS chunk that fits: squares x (KC*size + 32) <= 150 KiB
-    int kc = a.Cin;
-    while ((size_t)img_squares * (kc * E::kSize + 32) > 150 * 1024) {
-        KA_REQUIRE(kc % 2 == 0 && (kc / 2) % CPK == 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
-        kc /= 2;
+    // LDS chunk: the largest divisor of Cin (in k-steps) whose 16-byte pieces tile the 256 staging threads of a board
+    // and whose image fits: squares x (KC*size + 32) <= 150 KiB
+    int kc = 0;
+    for (int steps = a.Cin / CPK; steps >= 1; --steps) {
+        const int cand = steps * CPK;
+        if (a.Cin % cand != 0 || 256 % (cand * E::kSize / 16) != 0) continue;
+        if ((size_t)img_squares * (cand * E::kSize + 32) > 150 * 1024) continue;
+        kc = cand;
+        break;
     }
+    KA_REQUIRE(kc > 0, "conv3x3: cannot chunk Cin=%d", a.Cin);
     // measured (bf16, C=256): 2 chunks of 128 beat one of 256 -- with one board per workgroup the smaller tile lets two
     // workgroups share a CU, and inside the training step that is worth 15 %
     if (E::kSize == 2 && kc > 128 && a.Cin % 128 == 0) kc = 128;

@@ -620,3 +620,20 @@ def test_bn_coefficients_from_partials_match_two_step_path():
     torch.cuda.synchronize()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtn,B,cin,cout", [("f32", 1, 48, 48), ("f32", 2, 96, 80), ("bf16", 7, 96, 32), ("bf16", 1, 64, 96)])
+def test_conv3x3_odd_shapes(dtn, B, cin, cout):
+    """single boards, channel counts that are not powers of two (chunking by a divisor of Cin, a lone last output tile)"""
+    dt = DT[dtn]
+    g = torch.Generator().manual_seed(B * 31 + cin + cout)
+    x = torch.randn(B, cin, 9, 9, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    ref = F.conv2d(rnd(x, dt), rnd(w, dt), padding=1)
+    out, bsum, sq = run_conv(to_nhwc(x, dt), pack(w, dt, 0, cout, cin), B, cin, cout, dt)
+    close(from_nhwc(out), ref, dt)
+    close(bsum.cpu(), ref.sum(dim=(2, 3)), torch.float32, k=20 if dt == torch.float32 else 200)
+    close(sq.sum(0).cpu(), (ref ** 2).sum(dim=(0, 2, 3)), torch.float32, k=20 if dt == torch.float32 else 200)
+    refd = torch.nn.grad.conv2d_input((B, cin, 9, 9), rnd(w, dt), rnd(ref, dt), padding=1)
+    outd, _, _ = run_conv(to_nhwc(ref, dt), pack(w, dt, 1, cin, cout), B, cout, cin, dt)
+    close(from_nhwc(outd), refd, dt)

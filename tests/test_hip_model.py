@@ -244,3 +244,49 @@ def test_eval_graph_matches_eager_and_tracks_weights(monkeypatch):
     obs = torch.randn(3, 50, 9, 9, device=DEV)
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("channels,se_red,gpc,pol", [(96, 8, 24, 8), (48, 4, 20, 12)])
+def test_unusual_channel_counts(channels, se_red, gpc, pol, amp):
+    """Channel counts that are not powers of two (the 16-byte board kernels, the single-pass tail backward and the wide
+    conv slabs do not apply; their fallbacks do): forward and gradients against the same module on the CPU.  fp32:
+    rel-L2 2e-2 per gradient tensor; bf16 (channels % 32 == 0 only): cosine > 0.95 as in the 6x128 test above."""
+    if amp and channels % 32:
+        pytest.skip("bf16 convolutions need channels % 32 == 0 (DESIGN.md section 3)")
+    torch.manual_seed(11)
+    params = SEResNetParams(num_blocks=2, channels=channels, se_reduction=se_red, global_pool_channels=gpc,
+                            policy_channels=pol, value_fc_size=40, score_fc_size=24, obs_channels=50)
+    ref = SEResNetModel(params)
+    m = SEResNetModel(params)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    if amp:
+        m.configure_amp(True, torch.bfloat16, "cuda")
+    B = 37
+    obs = torch.randn(B, 50, 9, 9)
+    cot = [torch.randn(B, 9, 9, 139) / 50, torch.randn(B, 3), torch.randn(B, 1)]
+    for mod in (ref, m):
+        mod.train()
+        freeze_bn(mod)
+    o_ref = ref(obs)
+    (o_ref.policy_logits * cot[0]).sum().add((o_ref.value_logits * cot[1]).sum()).add((o_ref.score_lead * cot[2]).sum()).backward()
+    o = m(obs.to(DEV))
+    ((o.policy_logits * cot[0].to(DEV)).sum() + (o.value_logits * cot[1].to(DEV)).sum() + (o.score_lead * cot[2].to(DEV)).sum()).backward()
+    if not amp:
+        assert torch.allclose(o.policy_logits.cpu(), o_ref.policy_logits, rtol=2e-4, atol=1e-4)
+        assert torch.allclose(o.value_logits.cpu(), o_ref.value_logits, rtol=2e-4, atol=1e-4)
+    else:
+        d = float((o.policy_logits.detach().float().cpu() - o_ref.policy_logits.detach()).abs().max())
+        assert d <= 0.06 * float(o_ref.policy_logits.detach().abs().max())
+    gr = dict(ref.named_parameters())
+    for n, p in m.named_parameters():
+        r, got = gr[n].grad.double().flatten(), p.grad.double().cpu().flatten()
+        if float(r.norm()) == 0:
+            continue
+        if amp:
+            cos = float((r * got).sum() / (r.norm() * got.norm() + 1e-30))
+            assert cos > 0.95 and 0.8 < float(got.norm() / r.norm()) < 1.25, (n, cos)
+        else:
+            err = float((got - r).norm() / r.norm())
+            assert err < 2e-2, (n, err)

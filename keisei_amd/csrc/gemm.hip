@@ -3,10 +3,10 @@
 //
 //   C[M,N] = act( opA(A)[M,K] * opB(B)[K,N] + bias[N] )
 //
-// These are < 0.4 % of the model's FLOPs; they run as an exact-fp32
-// LDS-tiled FMA kernel (64x64x16 tile, 4x4 outputs per thread) with split-K for the
-// weight-gradient forms whose reduction runs over B*81 rows.  Operands may be fp32 or bf16
-// (activations) and are widened on load; accumulation is always fp32.
+// These are < 0.4 % of the model's FLOPs; they run on the exact-f32 matrix
+// instruction (64x64x32 LDS tiles) with split-K for the weight-gradient forms whose reduction runs
+// over B*81 rows.  Operands may be fp32 or bf16 (activations) and are widened on load, rows need no
+// alignment (the 139-wide logit rows); accumulation is always fp32.
 //
 // Replaces nn.Linear / 1x1 nn.Conv2d at se_resnet.py:57-61,65-66,120-130 and their backward.
 #include "common.h"
@@ -18,73 +18,36 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc;
     int transA, transB;          // opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k]; same for B[k,n]
     int a_bf16, b_bf16, c_bf16, relu, ksplit_len, accumulate;
+    int a_vec, b_vec;            // rows of the operand are 16-byte (fp32) / 8-byte (bf16) aligned: 4-element vector loads
 };
 
 __device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
     return bf16 ? bf2f(static_cast<const uint16_t*>(p)[i]) : static_cast<const float*>(p)[i];
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    constexpr int BK = 32;
-    __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
-    float acc[4][4] = {};
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // A tile: 64 rows x BK k  (index so that consecutive lanes walk the contiguous axis of the operand)
-        for (int i = tid; i < 64 * BK; i += 256) {
-            int m, k;
-            if (g.transA) { m = i & 63; k = i >> 6; } else { k = i & (BK - 1); m = i / BK; }
-            const int gm = m0 + m, gk = k0 + k;
-            float v = 0.f;
-            if (gm < g.M && gk < kend)
-                v = ldx(g.A, g.transA ? (size_t)gk * g.lda + gm : (size_t)gm * g.lda + gk, g.a_bf16);
-            As[k][m] = v;
+// four consecutive elements of an fp32 / bf16 operand starting at element i, widened to fp32; `valid` (<= 0 .. >= 4) of
+// them exist, the rest read as zero.  One vector load when the operand's rows are aligned, element loads otherwise
+// (rows of 139 logits, ragged K).
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t i, int bf16, int vec, int valid) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid <= 0) return v;
+    if (vec && valid >= 4) {
+        if (bf16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + i);
+            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + i);
         }
-        for (int i = tid; i < 64 * BK; i += 256) {
-            int n, k;
-            if (g.transB) { k = i & (BK - 1); n = i / BK; } else { n = i & 63; k = i >> 6; }
-            const int gn = n0 + n, gk = k0 + k;
-            float v = 0.f;
-            if (gn < g.N && gk < kend)
-                v = ldx(g.B, g.transB ? (size_t)gn * g.ldb + gk : (size_t)gk * g.ldb + gn, g.b_bf16);
-            Bs[k][n] = v;
-        }
-        __syncthreads();
+    } else {
 #pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
+        for (int e = 0; e < 4; ++e)
+            if (e < valid) v[e] = ldx(base, i + e, bf16);
     }
-    const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= g.N) continue;
-            float v = acc[i][j];
-            if (g.bias) v += g.bias[n];
-            if (g.relu) v = fmaxf(v, 0.f);
-            const size_t o = slab + (size_t)m * g.ldc + n;
-            if (g.c_bf16) static_cast<uint16_t*>(g.C)[o] = f2bf(v);
-            else static_cast<float*>(g.C)[o] = g.accumulate ? static_cast<float*>(g.C)[o] + v : v;
-        }
-    }
+    return v;
 }
 
-
-// Fast path: fp32 operands, 16-byte aligned rows (lda/ldb % 4 == 0, K-range % 4 == 0).  float4 global loads
+// fp32 or bf16 operands (widened on load, so every product is exact in fp32).  Four-element global loads
 // along the operand's contiguous axis, next K-tile prefetched into registers while the current one is multiplied
 // on the matrix cores with the exact-f32 v_mfma_f32_16x16x4_f32 (wave w owns rows 16w..16w+15 of the 64x64 tile and
 // all four 16-column tiles: 32 MFMAs per K-tile and wave, one ds_read_b32 per operand fragment, row stride 80 floats
@@ -97,9 +60,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
     constexpr int BK = 32;
     __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
     __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
-    const float* __restrict__ A = static_cast<const float*>(g.A);
-    const float* __restrict__ Bp = static_cast<const float*>(g.B);
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
     // per-thread load roles: two float4 per operand per tile
@@ -113,27 +74,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
         for (int h = 0; h < 2; ++h) {
             if (!TA) {
                 const int m = min(m0 + (tid >> 3) + 32 * h, g.M - 1), k = k0 + (tid & 7) * 4;
-                ra[h] = (k < kend) ? *reinterpret_cast<const f32x4*>(A + (size_t)m * g.lda + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[h] = ld4(g.A, (size_t)m * g.lda + k, g.a_bf16, g.a_vec, kend - k);
             } else {
                 const int k = k0 + (tid >> 4) + 16 * h, m = m0 + (tid & 15) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < kend) {
-                    if (m + 3 < g.M) v = *reinterpret_cast<const f32x4*>(A + (size_t)k * g.lda + m);
-                    else for (int e = 0; e < 4; ++e) if (m + e < g.M) v[e] = A[(size_t)k * g.lda + m + e];
-                }
-                ra[h] = v;
+                ra[h] = ld4(g.A, (size_t)k * g.lda + m, g.a_bf16, g.a_vec, k < kend ? g.M - m : 0);
             }
             if (TB) {
                 const int n = min(n0 + (tid >> 3) + 32 * h, g.N - 1), k = k0 + (tid & 7) * 4;
-                rb[h] = (k < kend) ? *reinterpret_cast<const f32x4*>(Bp + (size_t)n * g.ldb + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rb[h] = ld4(g.B, (size_t)n * g.ldb + k, g.b_bf16, g.b_vec, kend - k);
             } else {
                 const int k = k0 + (tid >> 4) + 16 * h, n = n0 + (tid & 15) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < kend) {
-                    if (n + 3 < g.N) v = *reinterpret_cast<const f32x4*>(Bp + (size_t)k * g.ldb + n);
-                    else for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] = Bp[(size_t)k * g.ldb + n + e];
-                }
-                rb[h] = v;
+                rb[h] = ld4(g.B, (size_t)k * g.ldb + n, g.b_bf16, g.b_vec, k < kend ? g.N - n : 0);
             }
         }
     };
@@ -163,23 +114,27 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool rows_live = m0 + wm * 16 < g.M;
     load_tile(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         store_tile();
         __syncthreads();
         if (k0 + BK < kend) load_tile(k0 + BK);          // in flight during the MFMA block
+        if (!rows_live) continue;                        // strip beyond M (skinny weight-gradient forms): barriers only
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            const float a = As[kk + q][wm * 16 + r];        // A[m = 16 wm + r][k = kk + q]
+        for (int j = 0; j < NJ; ++j) {
+            const int nt = (NW == 4 ? j : wn) * 16;
+            if (n0 + nt >= g.N) continue;                // uniform: column tiles beyond N (N = 32 heads) cost nothing
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[kk + q][(NW == 4 ? j : wn) * 16 + r], acc[j], 0, 0, 0);
+            for (int kk = 0; kk < BK; kk += 4)           // A[m = 16 wm + r][k = kk + q] x B[k][n = nt + r]
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[kk + q][wm * 16 + r], Bs[kk + q][nt + r], acc[j], 0, 0, 0);
         }
     }
     // accumulator lane (r, q), element i: C[m = 16 wm + 4q + i][n = 16 j + r]
     const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
     float* C = static_cast<float*>(g.C);
+    if (!rows_live) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + (NW == 4 ? j : wn) * 16 + r;
@@ -192,7 +147,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
             float v = acc[j][i] + bv;
             if (g.relu) v = fmaxf(v, 0.f);
             const size_t o = slab + (size_t)m * g.ldc + n;
-            C[o] = g.accumulate ? C[o] + v : v;
+            if (g.c_bf16) static_cast<uint16_t*>(g.C)[o] = f2bf(v);
+            else C[o] = g.accumulate ? C[o] + v : v;
         }
     }
 }
@@ -315,23 +271,21 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
     dim3 grid((N + 63) / 64, (M + 63) / 64, nsplit);
     KA_REQUIRE(grid.y <= 65535, "gemm: M too large for grid.y (%d rows)", M);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool aligned = !a_bf16 && !b_bf16 && !c_bf16 && lda % 4 == 0 && ldb % 4 == 0 && len % 4 == 0 &&
-                         (transA || K % 4 == 0) && (!transB || K % 4 == 0) &&
-                         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
-    if (aligned) {
-        // few workgroups: 16 waves per workgroup shorten the per-wave MFMA chain (latency-bound small-batch GEMMs)
-        const bool wide = (long long)grid.x * grid.y * grid.z < 128;
+    auto rows_aligned = [](const void* p, int ld, int bf16) {
+        return ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & (bf16 ? 7 : 15)) == 0;
+    };
+    g.a_vec = rows_aligned(A, lda, a_bf16);
+    g.b_vec = rows_aligned(B, ldb, b_bf16);
+    // few workgroups: 16 waves per workgroup shorten the per-wave MFMA chain (latency-bound small-batch GEMMs)
+    const bool wide = (long long)grid.x * grid.y * grid.z < 128;
 #define KA_GEMM_LAUNCH(TA_, TB_) \
-        do { if (wide) hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 16>), grid, dim3(1024), 0, st, g); \
-             else hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, g); } while (0)
-        if (transA && transB) KA_GEMM_LAUNCH(true, true);
-        else if (transA) KA_GEMM_LAUNCH(true, false);
-        else if (transB) KA_GEMM_LAUNCH(false, true);
-        else KA_GEMM_LAUNCH(false, false);
+    do { if (wide) hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 16>), grid, dim3(1024), 0, st, g); \
+         else hipLaunchKernelGGL((gemm_f32_fast_kernel<TA_, TB_, 4>), grid, dim3(256), 0, st, g); } while (0)
+    if (transA && transB) KA_GEMM_LAUNCH(true, true);
+    else if (transA) KA_GEMM_LAUNCH(true, false);
+    else if (transB) KA_GEMM_LAUNCH(false, true);
+    else KA_GEMM_LAUNCH(false, false);
 #undef KA_GEMM_LAUNCH
-    } else {
-        hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, g);
-    }
     return ka_check_launch("gemm");
 }
 

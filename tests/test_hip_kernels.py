@@ -312,7 +312,8 @@ def test_relu_bn_backward_and_block_dx(dtn):
 
 # ------------------------------------------------------------------ small GEMMs
 
-@pytest.mark.parametrize("M,N,K,ta,tb", [(37, 50, 70, 0, 1), (130, 16, 768, 0, 1), (65, 96, 33, 0, 0), (40, 24, 1000, 1, 0)])
+@pytest.mark.parametrize("M,N,K,ta,tb", [(37, 50, 70, 0, 1), (130, 16, 768, 0, 1), (65, 96, 33, 0, 0), (40, 24, 1000, 1, 0),
+                                        (810, 32, 139, 0, 0), (139, 32, 1701, 1, 0), (243, 139, 32, 0, 1), (70, 33, 45, 1, 1)])
 def test_gemm_variants(M, N, K, ta, tb):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
@@ -334,6 +335,11 @@ def test_gemm_variants(M, N, K, ta, tb):
     Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     _lib.call("ka_gemm", A.to(DEV), Bm.to(DEV), Cb, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 0, 1, 0, 0, 1, st())
     assert torch.allclose(Cb.float().cpu(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)
+    # bf16 B operand, accumulate into C
+    Cacc = torch.full((M, N), 2.0, device=DEV)
+    _lib.call("ka_gemm", A.to(DEV), Bm.bfloat16().to(DEV), Cacc, None, M, N, K, A.shape[1], Bm.shape[1], N, ta, tb, 0, 1, 0, 0, 1, 1, st())
+    ref3 = (A.t() if ta else A) @ (Bm.bfloat16().float().t() if tb else Bm.bfloat16().float())
+    assert torch.allclose(Cacc.cpu(), ref3 + 2, rtol=1e-4, atol=1e-3)
 
 
 def test_row_kernels():

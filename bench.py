@@ -64,7 +64,7 @@ def synth_dataset(total, seed, device):
     actions = torch.randint(0, A // 3, (total,), generator=g)
     cats = torch.randint(-1, 3, (total,), generator=g)
     return {
-        "obs": obs.to(device), "masks": masks.to(device), "actions": actions.to(device),
+        "obs": obs.to(device), "masks": masks.to(device), "mask_words": 0, "n_actions": A, "actions": actions.to(device),
         "old_lp": (-8.2 + 0.05 * torch.randn(total, generator=g)).to(device),
         "adv": torch.randn(total, generator=g).to(device), "cats": cats.to(device),
         "score_t": torch.randn(total, generator=g).clamp(-1.5, 1.5).to(device),
@@ -72,31 +72,47 @@ def synth_dataset(total, seed, device):
 
 
 def whole_update_rate(algo, adapter, T, N, device):
-    """SURVEY 8(d) secondary metric: one update() through the public API from a host-side KataGoRolloutBuffer of T x N
-    transitions -- batched GAE, advantage normalisation, the pinned H2D of the epoch dataset (PCIe-inclusive), the
-    epochs_per_batch x ceil(TN/B) minibatch steps and the metric read-back.  Filling the buffer is not timed."""
+    """SURVEY 8(d) secondary metric and the 8(f1) row: T add() calls of N transitions with the step tensors on the
+    device (as katago_loop.py:1523 passes them), then one update() through the public API -- batched GAE, advantage
+    normalisation, the epochs_per_batch x ceil(TN/B) minibatch steps, the metric read-back.  Measured for both
+    stores: "host" = the reference's CPU buffer (ten .cpu() per add, pinned H2D of the epoch inside update()),
+    "device" = the device-resident store (one append launch per add, nothing uploaded)."""
     from keisei_amd.training.katago_ppo import KataGoRolloutBuffer
-    g = torch.Generator().manual_seed(99)
     A = 11259
-    buf = KataGoRolloutBuffer(N, (50, 9, 9), A)
-    masks = torch.zeros(N, A, dtype=torch.bool)
-    masks[:, : A // 3] = True
-    for t in range(T):
-        last = t == T - 1
-        done = torch.full((N,), last, dtype=torch.bool)
-        cats = torch.randint(0, 3, (N,), generator=g) if last else torch.full((N,), -1, dtype=torch.long)
-        buf.add(torch.randn(N, 50, 9, 9, generator=g), torch.randint(0, A // 3, (N,), generator=g),
-                -8.2 + 0.05 * torch.randn(N, generator=g), torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g),
-                done, done, masks, cats, torch.randn(N, generator=g).clamp(-1.5, 1.5))
-    nv = torch.randn(N, generator=g).to(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    algo.update(buf, nv, value_adapter=adapter)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"samples_per_s": round(algo.params.epochs_per_batch * T * N / dt, 1), "seconds": round(dt, 3),
-            "transitions": T * N, "epochs_per_batch": algo.params.epochs_per_batch,
-            "includes": "GAE, advantage normalisation, pinned H2D of the epoch dataset, minibatch gathers, metric read-back"}
+    out = {"transitions": T * N, "epochs_per_batch": algo.params.epochs_per_batch,
+           "includes": "GAE, advantage normalisation, epoch dataset hand-over, minibatch gathers, metric read-back"}
+    for store in ("host", "device"):
+        g = torch.Generator().manual_seed(99)
+        os.environ["KA_ROLLOUT_BUFFER"] = store
+        buf = KataGoRolloutBuffer(N, (50, 9, 9), A)
+        masks = torch.zeros(N, A, dtype=torch.bool)
+        masks[:, : A // 3] = True
+        masks = masks.to(device)
+        fill = 0.0
+        for t in range(T):
+            last = t == T - 1
+            done = torch.full((N,), last, dtype=torch.bool)
+            cats = torch.randint(0, 3, (N,), generator=g) if last else torch.full((N,), -1, dtype=torch.long)
+            step = [torch.randn(N, 50, 9, 9, generator=g), torch.randint(0, A // 3, (N,), generator=g),
+                    -8.2 + 0.05 * torch.randn(N, generator=g), torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g),
+                    done, done, None, cats, torch.randn(N, generator=g).clamp(-1.5, 1.5)]
+            step = [masks if v is None else v.to(device) for v in step]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            buf.add(*step)
+            torch.cuda.synchronize()
+            fill += time.perf_counter() - t0
+        nv = torch.randn(N, generator=g).to(device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        algo.update(buf, nv, value_adapter=adapter)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[store] = {"samples_per_s": round(algo.params.epochs_per_batch * T * N / dt, 1), "update_seconds": round(dt, 3),
+                      "add_ms_per_step": round(1e3 * fill / T, 3)}
+    os.environ.pop("KA_ROLLOUT_BUFFER", None)
+    out["samples_per_s"] = out["device"]["samples_per_s"]
+    return out
 
 
 def cpu_baseline(shape, seconds_budget=25.0):

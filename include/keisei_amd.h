@@ -160,13 +160,16 @@ int ka_rows_bn_bwd(float* dr, const float* in, const float* p0, const float* p1,
  *   actions, old_lp, adv) are rows of the epoch dataset addressed through idx (NULL = identity).
  *   w_policy = lambda_policy/B, w_entropy = entropy_coeff/B; gscale = optional device loss scale (GradScaler).
  *   flags[0] |= NaN in raw logits, flags[1] |= a sample without legal action (the reference's two guards).
+ *   legal: bool rows (S,A) when legal_words == 0, else packed rows (S,legal_words) uint32 with bit j of word w = action
+ *   32 w + j and legal_words == ka_mask_words(A) -- the device rollout store's column (ka_rollout_append).
  * ka_value_loss: W/D/L cross-entropy (ignore_index -1, all-ignored -> 0), score MSE, their gradients, the mean
  *   reductions of the per-sample policy terms, and the value metrics of compute_value_metrics (katago_ppo.py:60-78).
  *   out[9] = {policy_loss, value_ce, score_mse, entropy, total, n_valid, value_accuracy, frac_win, frac_draw};
  *   acc[4] += {policy, value (combined lambda-weighted when combined_value_metric), score, entropy}. */
 int ka_policy_loss(const float* logits, const void* legal, const long long* actions, const float* old_lp, const float* adv,
                    const long long* idx, float* dlogits, float* new_lp, float* rowloss, float* rowent, int* flags,
-                   const float* gscale, float clip_eps, float w_policy, float w_entropy, int B, int A, void* stream);
+                   const float* gscale, float clip_eps, float w_policy, float w_entropy, int B, int A, int legal_words,
+                   void* stream);
 int ka_value_loss(const float* vlogits, const float* score, const long long* cats, const float* targets,
                   const long long* idx, const float* rowloss, const float* rowent, float* dvlogits, float* dscore,
                   float* out, float* acc, const float* gscale, float lambda_policy, float lambda_value, float lambda_score,
@@ -190,6 +193,26 @@ int ka_clip_adam_step(const void* tab, const int* blk_tensor, const long long* b
 int ka_gae(const void* rewards, const void* values, const float* term, const void* next_value, const void* override_,
            const long long* lengths, void* adv, int T, int N, double gamma, double lam, int f64, void* stream);
 int ka_normalize_advantages(const float* x, float* out, long long n, void* stream);
+
+/* ---- Device-resident rollout store (KataGoRolloutBuffer.add / flatten, katago_ppo.py:128-388) --
+ * ka_rollout_append: one timestep of n transitions.  Sources are the tensors add() receives (obs fp32 (n,obs_elems),
+ *   legal bool (n,A), actions / cats / env_ids int64, log_probs / values / rewards / score / override fp32, dones /
+ *   terminated bytes); destinations are the store's columns already offset to the first row written; the mask row
+ *   is packed to ka_mask_words(A) uint32 (bit j of word w = action 32 w + j).  env_ids / override / d_env_ids /
+ *   d_override may be NULL; a store with an override column and no override supplied gets NaN (= no override).
+ *   The reference's input guards (katago_ppo.py:244-266) come back as flags: [0] terminated without done,
+ *   [1] category outside {-1,0,1,2}, [2] NaN score target, [3] = float bits of max |score target| seen.
+ * ka_unpack_mask_bits: bool rows out[r] = packed row idx[r] (idx NULL = identity) -- flatten()'s legal_masks.
+ * ka_pack_mask_bits: packed rows from bool rows. */
+int ka_mask_words(int A);
+int ka_rollout_append(const float* obs, const void* legal, const long long* actions, const float* log_probs,
+                      const float* values, const float* rewards, const void* dones, const void* terminated,
+                      const long long* cats, const float* score, const long long* env_ids, const float* override_,
+                      float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values, float* d_rewards,
+                      void* d_dones, void* d_terminated, long long* d_cats, float* d_score, long long* d_env_ids,
+                      float* d_override, int* flags, int n, int obs_elems, int A, void* stream);
+int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream);
+int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A, void* stream);
 
 #ifdef __cplusplus
 }

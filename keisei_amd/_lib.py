@@ -53,13 +53,17 @@ _SIGS = {
     "ka_rows_bn_bwd": "pppp q i i p",
     "ka_rows_bn_sums": "pppp pp ii i p",
     "ka_rows_sq_sums": "ppp ii i p",
-    "ka_policy_loss": "pppppp pppp pp fff ii p",
+    "ka_policy_loss": "pppppp pppp pp fff iii p",
     "ka_value_loss": "ppppp pp pp pp p ffff i i p",
     "ka_scalar_value": "pp f p i p",
     "ka_adam_chunk": "",
     "ka_clip_adam_step": "ppp i ppp ppp fffff p",
     "ka_gae": "ppppp pp ii dd i p",
     "ka_normalize_advantages": "pp q p",
+    "ka_mask_words": "i",
+    "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
+    "ka_unpack_mask_bits": "ppp ii p",
+    "ka_pack_mask_bits": "pp ii p",
     "ka_version": "",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}

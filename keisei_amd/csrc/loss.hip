@@ -20,7 +20,8 @@ constexpr int kPolThreads = 256;
 
 struct PolicyArgs {
     const float* logits;      // (B,A)
-    const uint8_t* legal;     // (S,A) bool, row idx[b]
+    const uint8_t* legal;     // (S,A) bool rows, or -- legal_words > 0 -- (S,legal_words) uint32 rows, bit j of word w =
+                              // action 32 w + j (the device rollout store's packing, rollout.hip); row idx[b]
     const long long* actions; // (S)
     const float* old_lp;      // (S)
     const float* adv;         // (S)
@@ -32,7 +33,7 @@ struct PolicyArgs {
     int* flags;               // [0]=NaN in logits, [1]=zero legal actions
     const float* gscale;      // device scalar: loss scale (GradScaler) or null (=1)
     float clip_eps, w_policy, w_entropy;   // w_* already divided by B
-    int A;
+    int A, legal_words;
 };
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
@@ -55,12 +56,13 @@ __global__ __launch_bounds__(kPolThreads) void policy_loss_kernel(PolicyArgs a) 
     const long long src = a.idx ? a.idx[b] : b;
     const float* lg = a.logits + (size_t)b * a.A;
     const uint8_t* lm = a.legal + (size_t)src * a.A;
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(a.legal) + (size_t)src * a.legal_words;
 
     float mx = -INFINITY, nlegal = 0.f;
     int nan_seen = 0;
     for (int j = tid; j < a.A; j += kPolThreads) {
         const float v = lg[j];
-        const uint8_t k = lm[j];
+        const uint8_t k = a.legal_words ? (uint8_t)((lw[j >> 5] >> (j & 31)) & 1u) : lm[j];
         row[j] = v; msk[j] = k;
         nan_seen |= (v != v);
         if (k) { mx = fmaxf(mx, v); nlegal += 1.f; }
@@ -212,11 +214,12 @@ __global__ void scalar_value_kernel(const float* __restrict__ vl, const float* _
 extern "C" int ka_policy_loss(const float* logits, const void* legal, const long long* actions, const float* old_lp,
                               const float* adv, const long long* idx, float* dlogits, float* new_lp, float* rowloss,
                               float* rowent, int* flags, const float* gscale, float clip_eps, float w_policy,
-                              float w_entropy, int B, int A, void* stream) {
+                              float w_entropy, int B, int A, int legal_words, void* stream) {
     KA_REQUIRE(logits && legal && actions && old_lp && adv && new_lp && rowloss && rowent && flags && B > 0 && A > 0,
                "policy_loss: null tensor");
+    KA_REQUIRE(legal_words == 0 || legal_words == (A + 31) / 32, "policy_loss: packed mask rows must hold %d words", (A + 31) / 32);
     PolicyArgs a{logits, static_cast<const uint8_t*>(legal), actions, old_lp, adv, idx, dlogits, new_lp, rowloss,
-                 rowent, flags, gscale, clip_eps, w_policy, w_entropy, A};
+                 rowent, flags, gscale, clip_eps, w_policy, w_entropy, A, legal_words};
     const size_t lds = ((size_t)A * 4 + 15) / 16 * 16 + ((size_t)A + 15) / 16 * 16;
     KA_REQUIRE(lds <= 64 * 1024, "policy_loss: action space %d too large for the LDS row", A);
     hipLaunchKernelGGL(policy_loss_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), a);

@@ -403,7 +403,7 @@ def test_fused_loss_matches_reference(golden, tag):
     flags = torch.zeros(2, dtype=torch.int32, device=DEV)
     lp, lv, ls, ce, eps = 1.0, 1.5, 0.1, 0.01, 0.2
     _lib.call("ka_policy_loss", logits, g[tag + "legal"].to(DEV), g[tag + "actions"].to(DEV), g[tag + "old_log_probs"].to(DEV),
-              g[tag + "advantages"].to(DEV), None, dl, nlp, rl, re, flags, None, eps, lp / B, ce / B, B, A, st())
+              g[tag + "advantages"].to(DEV), None, dl, nlp, rl, re, flags, None, eps, lp / B, ce / B, B, A, 0, st())
     out = torch.zeros(16, device=DEV)
     acc = torch.zeros(4, device=DEV)
     dv, ds = torch.empty(B, 3, device=DEV), torch.empty(B, device=DEV)
@@ -435,7 +435,7 @@ def test_loss_guards_and_gather():
     nlp, rl, re = (torch.empty(B, device=DEV) for _ in range(3))
     flags = torch.zeros(2, dtype=torch.int32, device=DEV)
     args = lambda lg, legal: ("ka_policy_loss", lg.to(DEV), legal.to(DEV), mb["actions"].to(DEV), old.to(DEV),
-                              mb["advantages"].to(DEV), idx.to(DEV), None, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B, B, A, st())
+                              mb["advantages"].to(DEV), idx.to(DEV), None, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B, B, A, 0, st())
     _lib.call(*args(logits, mb["legal"]))
     assert flags.cpu().tolist() == [0, 0]
     assert torch.allclose(nlp.cpu(), ref_lp, rtol=1e-5, atol=1e-5)

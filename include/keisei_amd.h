@@ -92,6 +92,9 @@ int ka_bn_coeffs(const double* sums, double count, const double* count_dev, cons
                  float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
 int ka_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, int C, void* stream);
+/* the same for n layers in one launch: device table of n rows {gamma, beta, running_mean, running_var, scale, shift,
+ * C, eps as float bits} (8 x int64 each); max_c = largest C.  Rollout inference: 82 launches -> 1. */
+int ka_bn_eval_coeffs_multi(const long long* table, int n, int max_c, void* stream);
 /* backward: sums = [sum dz | sum dz*yhat]; dgamma/dbeta from the LOCAL sums, dy = k[0:C]*dz + k[C:2C] + k[2C:3C]*y
  * from the (all-reduced) global sums; train = 0 gives the eval-mode derivative. */
 int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, double* part, void* stream);
@@ -144,6 +147,16 @@ int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* 
  * *_bf16 flags mark bf16 operands/outputs; nsplit > 1 writes raw fp32 partial slabs (reduce with ka_reduce_slabs). */
 int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
             int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int accumulate, int nsplit, void* stream);
+/* Two chained FC layers in one launch (se_resnet.py:57-66 global_fc / se_fc1+se_fc2, :125-130 value / score heads):
+ *   y (M,N2) = W2 (N2,H) * relu(W1 (H,K1) * x' + b1) + b2,   x' = x (M rows of ldx floats, first K1 used), or with
+ *   in_scale/in_shift: x'[m,k] = in_scale[k] * (x[m,k] * in_alpha) + in_shift[k] (the SE squeeze from the conv's per-board
+ *   sums).  x_out (M,K1) / hidden_out (M,H) optionally keep x' / the ReLU'd hidden rows for the backward.  Exact f32
+ *   matrix instructions, fp32 accumulation.  ka_fc_chain_supported() tells whether a shape is handled (K1 % 16, H in
+ *   {16,32,64} or a multiple of 16 >= 128, ...); otherwise issue ka_gemm twice. */
+int ka_fc_chain_supported(int K1, int ldx, int H, int N2);
+int ka_fc_chain(const float* x, const float* in_scale, const float* in_shift, float in_alpha, const float* W1,
+                const float* b1, const float* W2, const float* b2, float* x_out, float* hidden_out, float* y, int M, int K1,
+                int ldx, int H, int N2, void* stream);
 int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream);
 int ka_colsum(const float* A, const float* Bm, float* part, float* part2, int M, int N, int nsplit, void* stream);
 int ka_relu_mask(float* g, const float* h, long long n, void* stream);

@@ -60,6 +60,9 @@ _SIGS = {
     "ka_clip_adam_step": "ppp i ppp ppp fffff p",
     "ka_gae": "ppppp pp ii dd i p",
     "ka_normalize_advantages": "pp q p",
+    "ka_bn_eval_coeffs_multi": "p ii p",
+    "ka_fc_chain_supported": "iiii",
+    "ka_fc_chain": "ppp f pppp ppp iiiii p",
     "ka_mask_words": "i",
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",

@@ -178,6 +178,23 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+// every BatchNorm layer of the model in one launch (rollout inference): table rows {gamma, beta, running_mean,
+// running_var, scale, shift, C, eps (float bits)}; blockIdx.y = layer
+__global__ void bn_eval_coeffs_multi_kernel(const long long* __restrict__ table) {
+    const long long* t = table + (size_t)blockIdx.y * 8;
+    const int C = (int)t[6];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* gamma = reinterpret_cast<const float*>(t[0]);
+    const float* beta = reinterpret_cast<const float*>(t[1]);
+    const float* rm = reinterpret_cast<const float*>(t[2]);
+    const float* rv = reinterpret_cast<const float*>(t[3]);
+    const float eps = __uint_as_float((unsigned int)t[7]);
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    reinterpret_cast<float*>(t[4])[c] = sc;
+    reinterpret_cast<float*>(t[5])[c] = beta[c] - rm[c] * sc;
+}
+
 // dgamma/dbeta from the LOCAL sums; dy = k1*dz + k2 + k3*y from the (possibly all-reduced) sums
 __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
                                      int nparts, double count, const double* __restrict__ count_dev,
@@ -873,6 +890,13 @@ extern "C" int ka_bn_eval_coeffs(const float* gamma, const float* beta, const fl
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
                        gamma, beta, rm, rv, eps, scale, shift, C);
     return ka_check_launch("bn_eval_coeffs");
+}
+
+extern "C" int ka_bn_eval_coeffs_multi(const long long* table, int n, int max_c, void* stream) {
+    KA_REQUIRE(table && n > 0 && max_c > 0, "bn_eval_coeffs_multi: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_multi_kernel, dim3((max_c + 127) / 128, n), dim3(128), 0,
+                       static_cast<hipStream_t>(stream), table);
+    return ka_check_launch("bn_eval_coeffs_multi");
 }
 
 extern "C" int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count,

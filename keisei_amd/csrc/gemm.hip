@@ -153,6 +153,119 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
     }
 }
 
+// Two chained small FC layers of the board-vector paths (global-pool bias: 3C -> G -> C; squeeze-excite: C -> C/r -> 2C;
+// value / score heads) in ONE launch:
+//     y = W2 * relu(W1 * x' + b1) + b2,      x' = x                      (in_scale == NULL)
+//                                            x' = in_scale[k] * (x * in_alpha) + in_shift[k]   (the SE squeeze from the
+//                                                                         conv's per-board sums: BN affine and 1/81)
+// A 512-thread workgroup owns 16 rows.  x' is staged once in LDS; phase 1 spreads the H/16 hidden column tiles (and, when
+// there are fewer than 8 of them, K ranges) over the 8 waves, exact-f32 MFMAs with the weight rows read straight from
+// L2 as 16-byte pieces (lane (r, q) holds k = k0+4q .. +3 of row r: MFMA i contracts k0+4q+i on both operands); the
+// ReLU'd hidden rows go through LDS; phase 2 spreads the N2/16 output tiles over the waves.  The launches this replaces
+// (an affine kernel and two 64x64-tile GEMMs) are latency-bound at every batch size of this model: 2 x 17 us at 128
+// rows (rollout inference), 2 x 25-60 us at 4096.
+struct ChainArgs {
+    const float* x; const float* in_scale; const float* in_shift; float in_alpha;
+    const float* W1; const float* b1; const float* W2; const float* b2;
+    float* x_out;        // optional (M,K1): x' (kept for the backward)
+    float* hidden_out;   // optional (M,H): relu(W1 x' + b1)
+    float* y;            // (M,N2)
+    int M, K1, ldx, H, N2;
+};
+
+__global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int xs_ld = a.K1 + 4, hs_ld = a.H + 4;
+    float* xs = lds;                          // [16][K1+4]
+    float* hs = xs + 16 * xs_ld;              // [16][H+4]
+    float* part = hs + 16 * hs_ld;            // [ksplit][16][H]   (only when H/16 < 8)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    // ---- stage x' (rows beyond M repeat the last row; their results are never stored)
+    const int k4n = a.K1 >> 2;
+    for (int i = tid; i < 16 * k4n; i += 512) {
+        const int row = i / k4n, c4 = (i - row * k4n) * 4;
+        const int m = min(m0 + row, a.M - 1);
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + c4);
+        if (a.in_scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.in_scale + c4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.in_shift + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sc[e] * (v[e] * a.in_alpha) + sh[e];
+            if (a.x_out && m0 + row < a.M) *reinterpret_cast<f32x4*>(a.x_out + (size_t)m * a.K1 + c4) = v;
+        }
+        *reinterpret_cast<f32x4*>(xs + row * xs_ld + c4) = v;
+    }
+    __syncthreads();
+    // ---- phase 1: hidden = relu(x' W1^T + b1)
+    const int T1 = a.H >> 4;
+    const int ksplit = T1 >= 8 ? 1 : 8 / T1;            // T1 in {1,2,4} -> 8,4,2 K ranges per tile
+    {
+        const int klen = a.K1 / ksplit;
+        for (int unit = wave; unit < T1 * ksplit; unit += 8) {
+            const int tile = unit % T1, kp = unit / T1;
+            const float* wrow = a.W1 + (size_t)(tile * 16 + r) * a.K1 + 4 * q;
+            const float* xrow = xs + r * xs_ld + 4 * q;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int kbeg = kp * klen, kend = kbeg + klen;
+#pragma unroll 4
+            for (int k = kbeg; k < kend; k += 16) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + k);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(xrow + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+            }
+            // acc lane (r, q), element i: hidden[m = 4q+i][n = 16 tile + r]
+            if (ksplit == 1) {
+                const float bias = a.b1 ? a.b1[tile * 16 + r] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hs[(4 * q + i) * hs_ld + tile * 16 + r] = fmaxf(acc[i] + bias, 0.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[(kp * 16 + 4 * q + i) * a.H + tile * 16 + r] = acc[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (ksplit > 1) {
+        for (int i = tid; i < 16 * a.H; i += 512) {
+            const int row = i / a.H, n = i - row * a.H;
+            float v = a.b1 ? a.b1[n] : 0.f;
+            for (int kp = 0; kp < ksplit; ++kp) v += part[(kp * 16 + row) * a.H + n];
+            hs[row * hs_ld + n] = fmaxf(v, 0.f);
+        }
+        __syncthreads();
+    }
+    if (a.hidden_out)
+        for (int i = tid; i < 16 * a.H; i += 512) {
+            const int row = i / a.H, n = i - row * a.H;
+            if (m0 + row < a.M) a.hidden_out[(size_t)(m0 + row) * a.H + n] = hs[row * hs_ld + n];
+        }
+    // ---- phase 2: y = hidden W2^T + b2
+    const int T2 = (a.N2 + 15) >> 4;
+    for (int tile = wave; tile < T2; tile += 8) {
+        const int n = min(tile * 16 + r, a.N2 - 1);
+        const float* wrow = a.W2 + (size_t)n * a.H + 4 * q;
+        const float* hrow = hs + r * hs_ld + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < a.H; k += 16) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + k);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+        if (tile * 16 + r < a.N2) {
+            const float bias = a.b2 ? a.b2[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 4 * q + i;
+                if (m < a.M) a.y[(size_t)m * a.N2 + n] = acc[i] + bias;
+            }
+        }
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s*n + i]
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, size_t n,
                                     int accumulate) {
@@ -287,6 +400,40 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
     else KA_GEMM_LAUNCH(false, false);
 #undef KA_GEMM_LAUNCH
     return ka_check_launch("gemm");
+}
+
+// 1 when ka_fc_chain handles the shape (otherwise callers issue the two GEMMs)
+extern "C" int ka_fc_chain_supported(int K1, int ldx, int H, int N2) {
+    const int T1 = H / 16;
+    const int ksplit = T1 >= 8 ? 1 : (T1 > 0 ? 8 / T1 : 0);
+    return K1 >= 16 && K1 % 16 == 0 && K1 <= 2048 && ldx % 4 == 0 && ldx >= K1 && H >= 16 && H % 16 == 0 && H <= 512 &&
+           (T1 >= 8 || T1 == 1 || T1 == 2 || T1 == 4) && (K1 / ksplit) % 16 == 0 && N2 >= 1;
+}
+
+extern "C" int ka_fc_chain(const float* x, const float* in_scale, const float* in_shift, float in_alpha, const float* W1,
+                           const float* b1, const float* W2, const float* b2, float* x_out, float* hidden_out, float* y,
+                           int M, int K1, int ldx, int H, int N2, void* stream) {
+    KA_REQUIRE(x && W1 && W2 && y && M > 0, "fc_chain: null tensor");
+    KA_REQUIRE(ka_fc_chain_supported(K1, ldx, H, N2), "fc_chain: unsupported shape (K1=%d ldx=%d H=%d N2=%d)", K1, ldx, H, N2);
+    KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "fc_chain: in_scale / in_shift come together");
+    KA_REQUIRE(!x_out || in_scale, "fc_chain: x_out is the transformed input; without a transform pass x itself");
+    KA_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(W1) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(W2) & 15) == 0, "fc_chain: operands must be 16-byte aligned");
+    const int T1 = H / 16, ksplit = T1 >= 8 ? 1 : 8 / T1;
+    const size_t lds = (size_t)(16 * (K1 + 4) + 16 * (H + 4) + (ksplit > 1 ? ksplit * 16 * H : 0)) * sizeof(float);
+    KA_REQUIRE(lds <= 160 * 1024, "fc_chain: LDS %zu B", lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess) {
+            ka_set_error("fc_chain: hipFuncSetAttribute failed");
+            return KA_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2};
+    hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("fc_chain");
 }
 
 extern "C" int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream) {

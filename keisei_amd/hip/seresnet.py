@@ -54,6 +54,8 @@ class SEResNetEngine:
         self._pack_table = None
         self._pack_max = 0
         self._wslab: Optional[torch.Tensor] = None
+        self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
+        self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
         self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
@@ -155,6 +157,33 @@ class SEResNetEngine:
         self._packs, self._pack_key = packs, key
         return packs
 
+    def _eval_coeffs_all(self, device, st):
+        """Eval-mode scale/shift of EVERY BatchNorm layer from the live running statistics in one launch (the rollout
+        forward otherwise spends 82 tiny launches on them).  Returns {id(bn): (scale, shift)} or None when a layer has
+        no affine parameters / running statistics (then each layer computes its own)."""
+        import struct
+
+        bns = [b for b in self.model.modules() if isinstance(b, nn.modules.batchnorm._BatchNorm)]
+        if not bns or any(b.weight is None or b.bias is None or b.running_mean is None or b.running_var is None for b in bns):
+            return None
+        key = (str(device), tuple((b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
+                                   float(b.eps)) for b in bns))
+        if self._evalc is None or self._evalc[0] != key:
+            mx = max(b.num_features for b in bns)
+            out = torch.empty(len(bns), 2, mx, device=device)
+            rows, views = [], {}
+            for i, b in enumerate(bns):
+                C = b.num_features
+                sc, sh = out[i, 0, :C], out[i, 1, :C]
+                eps_bits = struct.unpack("<I", struct.pack("<f", float(b.eps)))[0]
+                rows.append([b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
+                             sc.data_ptr(), sh.data_ptr(), C, eps_bits])
+                views[id(b)] = (sc, sh)
+            self._evalc = (key, torch.tensor(rows, dtype=torch.int64).to(device), views, mx, out)
+        _, table, views, mx, _ = self._evalc
+        _call("ka_bn_eval_coeffs_multi", table, table.shape[0], mx, st)
+        return views
+
     @staticmethod
     def _sync_group(bn: nn.Module):
         if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -163,6 +192,9 @@ class SEResNetEngine:
 
     def _bn_forward(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
         """returns scale, shift, mean, invstd (fp32 [C])"""
+        if not train and self._evalc_live is not None and id(bn) in self._evalc_live:
+            scale, shift = self._evalc_live[id(bn)]
+            return scale, shift, None, None
         scale = torch.empty(C, device=device); shift = torch.empty(C, device=device)
         if not train:
             _call("ka_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C, st)
@@ -202,6 +234,30 @@ class SEResNetEngine:
         y = torch.empty(M, N, device=x.device)
         self._gemm(x, lin.weight, y, lin.bias, M, N, K, lda, K, N, 0, 1, st, relu=relu)
         return y
+
+    def _fc_chain(self, x, lin1: nn.Linear, lin2: nn.Linear, st, keep: bool, affine=None):
+        """(x', hidden, y) of y = lin2(relu(lin1(x'))): one fused launch when the shape allows, else two GEMMs.
+        ``affine`` = (scale, shift, alpha): x' = scale * (x * alpha) + shift (returned when kept), otherwise x' = x."""
+        M, ldx = x.shape
+        H, K1 = lin1.weight.shape
+        N2 = lin2.weight.shape[0]
+        dev = x.device
+        fused = (os.environ.get("KA_FC_CHAIN", "1") != "0" and lin1.weight.is_contiguous() and lin2.weight.is_contiguous()
+                 and _lib.query("ka_fc_chain_supported", K1, ldx, H, N2))
+        if not fused:
+            xp = x
+            if affine is not None:
+                xp = torch.empty(M, K1, device=dev)
+                _call("ka_affine_rows", x, affine[0], affine[1], float(affine[2]), xp, M, K1, st)
+            hidden = self._linear(xp, lin1, 1, st)
+            return (xp if affine is not None else None), hidden, self._linear(hidden, lin2, 0, st)
+        y = torch.empty(M, N2, device=dev)
+        hidden = torch.empty(M, H, device=dev) if keep else None
+        xp = torch.empty(M, K1, device=dev) if (keep and affine is not None) else None
+        sc, sh, alpha = affine if affine is not None else (None, None, 1.0)
+        _call("ka_fc_chain", x, sc, sh, float(alpha), lin1.weight, lin1.bias, lin2.weight, lin2.bias, xp, hidden, y,
+              M, K1, ldx, H, N2, st)
+        return xp, hidden, y
 
     def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0):
         """dW = dy^T x (split over rows), db = colsum(dy), dx = dy W."""
@@ -255,7 +311,9 @@ class SEResNetEngine:
                     self._graphs.clear()
                 static_in = obs.clone()
                 saved_overlap = self.overlap_wgrad
-                self.overlap_wgrad = False              # single-stream capture
+                # KA_EVAL_GRAPH_FORK=1: keep the global-pool FC chain on the side stream inside the capture (a fork /
+                # join in the graph, beside conv1); 0 = single-stream capture
+                self.overlap_wgrad = saved_overlap and os.environ.get("KA_EVAL_GRAPH_FORK", "1") != "0"
                 try:
                     self.forward(static_in, False, False, T, None)            # warm-up: one-time kernel attributes etc.
                     torch.cuda.synchronize(dev)
@@ -284,6 +342,7 @@ class SEResNetEngine:
         if obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.float().contiguous()
         packs = self._get_packs(T, dev)
+        self._evalc_live = self._eval_coeffs_all(dev, st) if (not train and not keep) else None
         rows = _lib.query("ka_conv3x3_sqpart_rows", B)
         count = B * 81
         sv = _Saved()
@@ -319,13 +378,13 @@ class SEResNetEngine:
                 with torch.cuda.stream(fside):
                     fside.wait_event(ev)
                     sts = _lib.stream_ptr(dev)
-                    g1 = self._linear(pool, blk.global_fc[0], 1, sts)
-                    g = self._linear(g1, blk.global_fc[2], 0, sts)
+                    _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], sts, keep)
                     g_ready = torch.cuda.Event(); g_ready.record(fside)
-                g1.record_stream(main_f); g.record_stream(main_f)
+                g.record_stream(main_f)
+                if g1 is not None:
+                    g1.record_stream(main_f)
             else:
-                g1 = self._linear(pool, blk.global_fc[0], 1, st)
-                g = self._linear(g1, blk.global_fc[2], 0, st)
+                _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], st, keep)
             y1 = new_act(C)
             bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
@@ -338,10 +397,7 @@ class SEResNetEngine:
             self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
                   bsum2, sq2 if train else None, B, C, C, code, st)
             sc2, sh2, mu2, is2 = self._bn_forward(blk.bn2, bsum2, B, sq2, rows, C, count, train, dev, st)
-            sqz = torch.empty(B, C, device=dev)
-            _call("ka_affine_rows", bsum2, sc2, sh2, 1.0 / 81.0, sqz, B, C, st)
-            se1 = self._linear(sqz, blk.se_fc1, 1, st)
-            se = self._linear(se1, blk.se_fc2, 0, st)
+            sqz, se1, se = self._fc_chain(bsum2, blk.se_fc1, blk.se_fc2, st, keep, affine=(sc2, sh2, 1.0 / 81.0))
             out = new_act(C)
             pool_out = torch.empty(B, 4 * C, device=dev)
             _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
@@ -368,13 +424,12 @@ class SEResNetEngine:
         logits = torch.empty(B, 9, 9, A, device=dev)
         wp2 = m.policy_conv2.weight
         self._gemm(p1r, wp2, logits, m.policy_conv2.bias, M, A, P, P, P, A, 0, 1, st)
-        v1 = self._linear(pool, m.value_fc1, 1, st)
-        v = self._linear(v1, m.value_fc2, 0, st)
-        s1 = self._linear(pool, m.score_fc1, 1, st)
-        s = self._linear(s1, m.score_fc2, 0, st)
+        _, v1, v = self._fc_chain(pool, m.value_fc1, m.value_fc2, st, keep)
+        _, s1, s = self._fc_chain(pool, m.score_fc1, m.score_fc2, st, keep)
         if keep:
             sv.heads = (x, pool, p1, scp, shp, mup, isp, p1r, v1, s1)
         self._in_forward = False
+        self._evalc_live = None
         return logits, v, s, (sv if keep else None)
 
     # ------------------------------------------------------------------ backward

@@ -643,3 +643,33 @@ def test_conv3x3_odd_shapes(dtn, B, cin, cout):
     refd = torch.nn.grad.conv2d_input((B, cin, 9, 9), rnd(w, dt), rnd(ref, dt), padding=1)
     outd, _, _ = run_conv(to_nhwc(ref, dt), pack(w, dt, 1, cin, cout), B, cout, cin, dt)
     close(from_nhwc(outd), refd, dt)
+
+
+@pytest.mark.parametrize("M,K1,ldx,H,N2,affine", [(37, 768, 1024, 128, 256, False), (130, 256, 256, 16, 512, True),
+                                                   (5, 768, 1024, 256, 3, False), (16, 128, 128, 32, 1, True),
+                                                   (4097, 64, 64, 64, 139, False)])
+def test_fc_chain_matches_two_linears(M, K1, ldx, H, N2, affine):
+    """y = W2 relu(W1 x' + b1) + b2 in one launch (global-pool bias, squeeze-excite and head FC chains) vs fp32 torch."""
+    g = torch.Generator().manual_seed(M + K1 + H + N2)
+    x = torch.randn(M, ldx, generator=g)
+    W1, b1 = torch.randn(H, K1, generator=g) / K1 ** 0.5, torch.randn(H, generator=g)
+    W2, b2 = torch.randn(N2, H, generator=g) / H ** 0.5, torch.randn(N2, generator=g)
+    sc, sh, alpha = torch.randn(K1, generator=g), torch.randn(K1, generator=g), 1.0 / 81.0
+    assert _lib.query("ka_fc_chain_supported", K1, ldx, H, N2) == 1
+    xp_ref = sc * (x[:, :K1] * alpha) + sh if affine else x[:, :K1]
+    hid_ref = torch.relu(xp_ref @ W1.t() + b1)
+    y_ref = hid_ref @ W2.t() + b2
+    y = torch.empty(M, N2, device=DEV)
+    hid = torch.empty(M, H, device=DEV)
+    xp = torch.empty(M, K1, device=DEV) if affine else None
+    _lib.call("ka_fc_chain", x.to(DEV), sc.to(DEV) if affine else None, sh.to(DEV) if affine else None, alpha, W1.to(DEV),
+              b1.to(DEV), W2.to(DEV), b2.to(DEV), xp, hid, y, M, K1, ldx, H, N2, st())
+    assert torch.allclose(hid.cpu(), hid_ref, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(y.cpu(), y_ref, rtol=1e-5, atol=5e-5)
+    if affine:
+        assert torch.allclose(xp.cpu(), xp_ref, rtol=1e-6, atol=1e-6)
+    # without the optional outputs and biases
+    y2 = torch.empty(M, N2, device=DEV)
+    _lib.call("ka_fc_chain", x.to(DEV), None, None, 1.0, W1.to(DEV), None, W2.to(DEV), None, None, None, y2, M, K1, ldx, H, N2, st())
+    assert torch.allclose(y2.cpu(), torch.relu(x[:, :K1] @ W1.t()) @ W2.t(), rtol=1e-5, atol=5e-5)
+    assert _lib.query("ka_fc_chain_supported", K1, ldx, 48, N2) == 0 and _lib.query("ka_fc_chain_supported", 100, 100, H, N2) == 0

@@ -5,7 +5,7 @@ import torch
 from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams
 from keisei_amd.training.model_registry import build_model
 dev = torch.device("cuda")
-for amp in (True, False):
+for amp in ((True,) if os.environ.get("KA_SELECT_AMP_ONLY", "1") == "1" else (True, False)):
     model = build_model("se_resnet", dict(num_blocks=40, channels=256, se_reduction=16, global_pool_channels=128,
                                           policy_channels=32, value_fc_size=256, score_fc_size=128, obs_channels=50)).to(dev)
     algo = KataGoPPOAlgorithm(KataGoPPOParams(batch_size=4096, use_amp=amp), model)

@@ -269,7 +269,8 @@ def main() -> None:
             traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
             pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
             if pmc.exists() and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
-                rec = json.loads(pmc.read_text())["kernels"].get("conv3x3_kernel<bf16_t, 4, 2>")
+                recs = [v for k, v in json.loads(pmc.read_text())["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
+                rec = max(recs, key=lambda v: v["launches"]) if recs else None      # the tower instantiation
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
             roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv; forward + data-gradient launches, the "
                                                "latter with fused BatchNorm-backward passes and concurrent with wgrad on a 2nd stream)",

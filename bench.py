@@ -115,6 +115,34 @@ def whole_update_rate(algo, adapter, T, N, device):
     return out
 
 
+def sl_epoch_rate(make_model, positions, batch, use_amp):
+    """one SLTrainer.train_epoch() over a synthetic shard directory (write_shard format, 16 220 B per
+    position, under /tmp) through the public API -- shard gather on a helper thread, pinned H2D, fused step."""
+    import tempfile
+    from pathlib import Path
+
+    import numpy as np
+    from keisei_amd.sl.dataset import OBS_SIZE, write_shard
+    from keisei_amd.sl.trainer import SLConfig, SLTrainer
+    rng = np.random.default_rng(7)
+    with tempfile.TemporaryDirectory() as tmp:
+        per = 4096
+        for i in range(positions // per):
+            write_shard(Path(tmp) / f"shard_{i}.bin", rng.standard_normal((per, OBS_SIZE), dtype=np.float32),
+                        rng.integers(0, 11259, per), rng.integers(0, 3, per), rng.standard_normal(per).astype(np.float32))
+        trainer = SLTrainer(make_model(), SLConfig(data_dir=tmp, batch_size=batch, use_amp=use_amp))
+        assert trainer._fused_path_available()
+        trainer.train_epoch()                       # warm-up: page cache, allocator, graph-free first launches
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = trainer.train_epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"positions_per_s": round(positions / dt, 1), "seconds": round(dt, 3), "positions": positions, "batch": batch,
+            "includes": "shuffled shard gather (mmap), pinned H2D, forward, CE/CE/MSE loss, backward, clip, Adam",
+            "policy_loss": round(m["policy_loss"], 4)}
+
+
 def cpu_baseline(shape, seconds_budget=25.0):
     """Times the oracle's PPO minibatch step (fp32 CPU PyTorch restatement of the reference) on this host.
     Bounded: threads = the CPUs this process may use (<= 16, the box's share per GPU), minibatch sized from a
@@ -164,6 +192,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whole-update", action="store_true",
                     help="also time one KataGoPPOAlgorithm.update() from a host rollout buffer (GAE, H2D, gather included)")
+    ap.add_argument("--sl-epoch", action="store_true", help="also time one SLTrainer.train_epoch() over synthetic shards")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
@@ -250,6 +279,11 @@ def main() -> None:
     whole = None
     if args.whole_update and rank == 0:
         whole = whole_update_rate(algo, adapter, T, N, device)
+    sl = None
+    if args.sl_epoch and rank == 0:
+        sl = sl_epoch_rate(lambda: build_model("se_resnet", dict(num_blocks=nb, channels=C, se_reduction=Rr, global_pool_channels=G,
+                                                                   policy_channels=P, value_fc_size=V, score_fc_size=S,
+                                                                   obs_channels=50)).to(device), 4 * B, B, args.dtype == "bf16")
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -308,6 +342,8 @@ def main() -> None:
         out.update(extra)
         if whole is not None:
             out["whole_update"] = whole
+        if sl is not None:
+            out["sl_epoch"] = sl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((nb, C, Rr, G, P, V, S))
         else:

@@ -183,6 +183,12 @@ int ka_policy_loss(const float* logits, const void* legal, const long long* acti
                    const long long* idx, float* dlogits, float* new_lp, float* rowloss, float* rowent, int* flags,
                    const float* gscale, float clip_eps, float w_policy, float w_entropy, int B, int A, int legal_words,
                    void* stream);
+/* Supervised policy cross-entropy (keisei/sl/trainer.py:150-152): rowloss[b] = logsumexp(logits[b]) - logits[b][t],
+ * t = targets[idx ? idx[b] : b]; dlogits (optional) = w_policy * (softmax - onehot) [* *gscale].  flags[0] |= NaN logits,
+ * flags[1] |= target outside [0,A).  ka_value_loss then supplies the W/D/L cross-entropy, the score MSE and the means
+ * (rowent = zeros, entropy_coeff = 0). */
+int ka_policy_ce(const float* logits, const long long* targets, const long long* idx, float* dlogits, float* rowloss,
+                 int* flags, const float* gscale, float w_policy, int B, int A, void* stream);
 int ka_value_loss(const float* vlogits, const float* score, const long long* cats, const float* targets,
                   const long long* idx, const float* rowloss, const float* rowent, float* dvlogits, float* dscore,
                   float* out, float* acc, const float* gscale, float lambda_policy, float lambda_value, float lambda_score,

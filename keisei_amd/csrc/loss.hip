@@ -110,6 +110,54 @@ __global__ __launch_bounds__(kPolThreads) void policy_loss_kernel(PolicyArgs a) 
     }
 }
 
+// Supervised policy head (keisei/sl/trainer.py:150-152, F.cross_entropy over all A actions, mean over the batch): one
+// workgroup per sample stages the logit row in LDS, rowloss[b] = logsumexp(row) - row[target[b]] and
+// dlogits = w * (softmax(row) - onehot(target)), w = lambda_policy / B (times the loss scale).  flags[0] |= NaN in the logits,
+// flags[1] |= a target outside [0, A).
+struct PolicyCeArgs {
+    const float* logits; const long long* targets; const long long* idx; float* dlogits; float* rowloss; int* flags;
+    const float* gscale; float w_policy; int A;
+};
+
+__global__ __launch_bounds__(kPolThreads) void policy_ce_kernel(PolicyCeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    __shared__ float red[kPolThreads / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long src = a.idx ? a.idx[b] : b;
+    const float* lg = a.logits + (size_t)b * a.A;
+    float mx = -INFINITY;
+    int nan_seen = 0;
+    for (int j = tid; j < a.A; j += kPolThreads) {
+        const float v = lg[j];
+        row[j] = v;
+        nan_seen |= (v != v);
+        mx = fmaxf(mx, v);
+    }
+    mx = block_reduce(mx, red, true);
+    const float nanf_ = block_reduce((float)nan_seen, red, false);
+    float s = 0.f;
+    for (int j = tid; j < a.A; j += kPolThreads) s += expf(row[j] - mx);
+    s = block_reduce(s, red, false);
+    const float lse = mx + logf(s);
+    const long long tgt = a.targets[src];
+    const bool ok = tgt >= 0 && tgt < a.A;
+    if (tid == 0) {
+        if (nanf_ > 0.f) atomicOr(&a.flags[0], 1);
+        if (!ok) atomicOr(&a.flags[1], 1);
+        a.rowloss[b] = ok ? lse - row[tgt] : 0.f;
+    }
+    if (a.dlogits) {
+        const float w = a.w_policy * (a.gscale ? *a.gscale : 1.f);
+        float* dl = a.dlogits + (size_t)b * a.A;
+        for (int j = tid; j < a.A; j += kPolThreads) {
+            float g = w * expf(row[j] - lse);
+            if (j == tgt) g -= w;
+            dl[j] = g;
+        }
+    }
+}
+
 struct ValueArgs {
     const float* vlogits;      // (B,3)
     const float* score;        // (B)
@@ -224,6 +272,16 @@ extern "C" int ka_policy_loss(const float* logits, const void* legal, const long
     KA_REQUIRE(lds <= 64 * 1024, "policy_loss: action space %d too large for the LDS row", A);
     hipLaunchKernelGGL(policy_loss_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("policy_loss");
+}
+
+extern "C" int ka_policy_ce(const float* logits, const long long* targets, const long long* idx, float* dlogits,
+                            float* rowloss, int* flags, const float* gscale, float w_policy, int B, int A, void* stream) {
+    KA_REQUIRE(logits && targets && rowloss && flags && B > 0 && A > 0, "policy_ce: null tensor");
+    PolicyCeArgs a{logits, targets, idx, dlogits, rowloss, flags, gscale, w_policy, A};
+    const size_t lds = ((size_t)A * 4 + 15) / 16 * 16;
+    KA_REQUIRE(lds <= 64 * 1024, "policy_ce: action space %d too large for the LDS row", A);
+    hipLaunchKernelGGL(policy_ce_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("policy_ce");
 }
 
 // out[9]: policy_loss, value_ce, score_mse, entropy, total, n_valid, value_accuracy, frac_win, frac_draw

@@ -16,6 +16,7 @@ Fixture inventory:
   g5_update     one full KataGoPPOAlgorithm.update() on CPU with recorded randperm sequences
   g6_adam       clip_grad_norm_ + Adam, 3 steps
   g7_scalar     mlp / transformer tiny forward
+  g8_sl         two SLTrainer.train_epoch() calls on a 3-shard directory: shard arrays, visiting order, metrics, weights
 """
 
 from __future__ import annotations
@@ -351,9 +352,61 @@ def g7_scalar() -> None:
     npz("g7_scalar", **arrays)
 
 
+def g8_sl() -> None:
+    """keisei/sl: write_shard -> SLDataset -> SLTrainer.train_epoch() x 2 (CPU fp32), with the order in which the
+    shuffling DataLoader visited the positions recorded per epoch."""
+    import tempfile
+
+    from keisei.sl import dataset as ref_ds
+    from keisei.sl.trainer import SLConfig, SLTrainer
+
+    rng = np.random.default_rng(88)
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = Path(tmp)
+        for shard, n in ((0, 9), (1, 6), (2, 7)):
+            obs = (rng.random((n, ref_ds.OBS_SIZE)) < 0.1).astype(np.float32) + 0.05 * rng.standard_normal((n, ref_ds.OBS_SIZE)).astype(np.float32)
+            pol, val = rng.integers(0, 11259, n), rng.integers(0, 3, n)
+            sc = np.clip(rng.standard_normal(n), -2, 2).astype(np.float32)
+            ref_ds.write_shard(tmp / f"shard_{shard}.bin", obs, pol, val, sc)
+            arrays[f"shard{shard}.obs"], arrays[f"shard{shard}.policy"] = obs, pol
+            arrays[f"shard{shard}.value"], arrays[f"shard{shard}.score"] = val, sc
+            arrays[f"shard{shard}.bytes"] = np.frombuffer((tmp / f"shard_{shard}.bin").read_bytes(), dtype=np.uint8)
+        torch.manual_seed(81)
+        mparams = dict(num_blocks=1, channels=32, se_reduction=8, global_pool_channels=16,
+                       policy_channels=8, value_fc_size=32, score_fc_size=16, obs_channels=50)
+        model = build_model("se_resnet", mparams)
+        arrays.update(sd_arrays("sd0.", model.state_dict()))
+        cfg = SLConfig(data_dir=str(tmp), batch_size=8, learning_rate=1e-3, total_epochs=5, lambda_score=0.05)
+        trainer = SLTrainer(model, cfg)
+        visited = []
+        real_get = ref_ds.SLDataset.__getitem__
+
+        def recording_get(self, idx):
+            visited.append(int(idx))
+            return real_get(self, idx)
+
+        ref_ds.SLDataset.__getitem__ = recording_get
+        try:
+            torch.manual_seed(82)
+            for ep in range(2):
+                visited.clear()
+                m = trainer.train_epoch()
+                arrays[f"order{ep}"] = np.array(visited, dtype=np.int64)
+                for k, v in m.items():
+                    arrays[f"metric{ep}.{k}"] = np.float64(v)
+                arrays[f"lr{ep}"] = np.float64(trainer.optimizer.param_groups[0]["lr"])
+                arrays.update(sd_arrays(f"sd{ep + 1}.", model.state_dict()))
+        finally:
+            ref_ds.SLDataset.__getitem__ = real_get
+        arrays["hyper"] = np.array([cfg.batch_size, cfg.learning_rate, cfg.total_epochs, cfg.lambda_policy, cfg.lambda_value,
+                                    cfg.lambda_score, cfg.grad_clip])
+    npz("g8_sl", **arrays)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1_block, g2_model_tiny, g2_model_mid, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar):
+    for fn in (g1_block, g2_model_tiny, g2_model_mid, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar, g8_sl):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

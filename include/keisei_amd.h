@@ -183,6 +183,11 @@ int ka_policy_loss(const float* logits, const void* legal, const long long* acti
                    const long long* idx, float* dlogits, float* new_lp, float* rowloss, float* rowent, int* flags,
                    const float* gscale, float clip_eps, float w_policy, float w_entropy, int B, int A, int legal_words,
                    void* stream);
+/* Rollout action selection (katago_ppo.py:566-584): probs[b] = softmax of logits[b] over the legal actions, 0 elsewhere;
+ * nlegal[b] = number of legal actions (0 -> the caller raises the reference's error); flags[0] |= NaN in the logits.
+ * legal as in ka_policy_loss (bool rows, or packed rows with legal_words = ka_mask_words(A)). */
+int ka_masked_softmax(const float* logits, const void* legal, float* probs, int* nlegal, int* flags, int B, int A,
+                      int legal_words, void* stream);
 /* Supervised policy cross-entropy (keisei/sl/trainer.py:150-152): rowloss[b] = logsumexp(logits[b]) - logits[b][t],
  * t = targets[idx ? idx[b] : b]; dlogits (optional) = w_policy * (softmax - onehot) [* *gscale].  flags[0] |= NaN logits,
  * flags[1] |= target outside [0,A).  ka_value_loss then supplies the W/D/L cross-entropy, the score MSE and the means

@@ -110,6 +110,46 @@ __global__ __launch_bounds__(kPolThreads) void policy_loss_kernel(PolicyArgs a) 
     }
 }
 
+// Rollout action selection (katago_ppo.py:566-584): probs[b] = softmax of the logits over the legal actions (0 elsewhere),
+// nlegal[b] = number of legal actions.  One pass over the LDS-staged row replaces the reference's sum / masked_fill /
+// softmax / renormalise / clamp / log chain of ~10 launches; sampling itself stays torch.multinomial on these rows.
+// legal: bool rows (legal_words == 0) or packed rows as in ka_policy_loss.  flags[0] |= NaN in the logits.
+__global__ __launch_bounds__(kPolThreads) void masked_softmax_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ legal,
+                                                                     float* __restrict__ probs, int* __restrict__ nlegal_out,
+                                                                     int* __restrict__ flags, int A, int legal_words) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    uint8_t* msk = reinterpret_cast<uint8_t*>(smem + ((size_t)A * 4 + 15) / 16 * 16);
+    __shared__ float red[kPolThreads / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (size_t)b * A;
+    const uint8_t* lm = legal + (size_t)b * A;
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(legal) + (size_t)b * legal_words;
+    float mx = -INFINITY, nlegal = 0.f;
+    int nan_seen = 0;
+    for (int j = tid; j < A; j += kPolThreads) {
+        const float v = lg[j];
+        const uint8_t k = legal_words ? (uint8_t)((lw[j >> 5] >> (j & 31)) & 1u) : lm[j];
+        row[j] = v; msk[j] = k;
+        nan_seen |= (v != v);
+        if (k) { mx = fmaxf(mx, v); nlegal += 1.f; }
+    }
+    mx = block_reduce(mx, red, true);
+    nlegal = block_reduce(nlegal, red, false);
+    const float nanf_ = block_reduce((float)nan_seen, red, false);
+    float s = 0.f;
+    for (int j = tid; j < A; j += kPolThreads)
+        if (msk[j]) s += expf(row[j] - mx);
+    s = block_reduce(s, red, false);
+    if (tid == 0) {
+        if (nanf_ > 0.f) atomicOr(&flags[0], 1);
+        nlegal_out[b] = (int)nlegal;
+    }
+    const float inv = 1.f / s;
+    float* pr = probs + (size_t)b * A;
+    for (int j = tid; j < A; j += kPolThreads) pr[j] = msk[j] ? expf(row[j] - mx) * inv : 0.f;
+}
+
 // Supervised policy head (keisei/sl/trainer.py:150-152, F.cross_entropy over all A actions, mean over the batch): one
 // workgroup per sample stages the logit row in LDS, rowloss[b] = logsumexp(row) - row[target[b]] and
 // dlogits = w * (softmax(row) - onehot(target)), w = lambda_policy / B (times the loss scale).  flags[0] |= NaN in the logits,
@@ -272,6 +312,17 @@ extern "C" int ka_policy_loss(const float* logits, const void* legal, const long
     KA_REQUIRE(lds <= 64 * 1024, "policy_loss: action space %d too large for the LDS row", A);
     hipLaunchKernelGGL(policy_loss_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("policy_loss");
+}
+
+extern "C" int ka_masked_softmax(const float* logits, const void* legal, float* probs, int* nlegal, int* flags, int B, int A,
+                                 int legal_words, void* stream) {
+    KA_REQUIRE(logits && legal && probs && nlegal && flags && B > 0 && A > 0, "masked_softmax: null tensor");
+    KA_REQUIRE(legal_words == 0 || legal_words == (A + 31) / 32, "masked_softmax: packed mask rows must hold %d words", (A + 31) / 32);
+    const size_t lds = ((size_t)A * 4 + 15) / 16 * 16 + ((size_t)A + 15) / 16 * 16;
+    KA_REQUIRE(lds <= 64 * 1024, "masked_softmax: action space %d too large for the LDS row", A);
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), logits,
+                       static_cast<const uint8_t*>(legal), probs, nlegal, flags, A, legal_words);
+    return ka_check_launch("masked_softmax");
 }
 
 extern "C" int ka_policy_ce(const float* logits, const long long* targets, const long long* idx, float* dlogits,

@@ -423,15 +423,31 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
             if device.type == "cuda":
                 end.record(stream)
                 self._timing_events["select_actions_forward_ms"].append((start, end))
-            n_legal = legal_masks.sum(dim=-1)
+            raw = out.policy_logits.reshape(obs.shape[0], -1)
+            if raw.is_cuda and legal_masks.is_cuda and legal_masks.dtype == torch.bool:
+                # one launch: masked softmax + legal-action counts (the tensor-op chain below is ~12 launches)
+                B_, A_ = raw.shape
+                logits32 = raw.float().contiguous()
+                masks_c = legal_masks.reshape(B_, A_).contiguous()
+                probs = torch.empty(B_, A_, device=raw.device)
+                n_legal = torch.empty(B_, dtype=torch.int32, device=raw.device)
+                nan_flag = torch.zeros(1, dtype=torch.int32, device=raw.device)
+                _lib.call("ka_masked_softmax", logits32, masks_c, probs, n_legal, nan_flag, B_, A_, 0, _lib.stream_ptr(raw.device))
+            else:
+                probs = None
+                n_legal = legal_masks.sum(dim=-1)
             if bool((n_legal == 0).any()):
                 empty = (n_legal == 0).nonzero(as_tuple=True)[0].tolist()
                 raise RuntimeError(f"Environments {empty} have zero legal actions — "
                                    f"all-False legal mask would produce NaN")
-            logits = out.policy_logits.reshape(obs.shape[0], -1).float().masked_fill(~legal_masks, float("-inf"))
-            dist = torch.distributions.Categorical(torch.softmax(logits, dim=-1), validate_args=False)
-            actions = dist.sample()
-            log_probs = dist.log_prob(actions)
+            if probs is not None:
+                actions = torch.multinomial(probs, 1, True).squeeze(1)          # what Categorical(probs).sample() draws
+                log_probs = probs.gather(1, actions.unsqueeze(1)).squeeze(1).log()
+            else:
+                logits = raw.float().masked_fill(~legal_masks, float("-inf"))
+                dist = torch.distributions.Categorical(torch.softmax(logits, dim=-1), validate_args=False)
+                actions = dist.sample()
+                log_probs = dist.log_prob(actions)
             if value_adapter is not None:
                 values = value_adapter.scalar_value_blended(out.value_logits, out.score_lead)
             else:

@@ -673,3 +673,36 @@ def test_fc_chain_matches_two_linears(M, K1, ldx, H, N2, affine):
     _lib.call("ka_fc_chain", x.to(DEV), None, None, 1.0, W1.to(DEV), None, W2.to(DEV), None, None, None, y2, M, K1, ldx, H, N2, st())
     assert torch.allclose(y2.cpu(), torch.relu(x[:, :K1] @ W1.t()) @ W2.t(), rtol=1e-5, atol=5e-5)
     assert _lib.query("ka_fc_chain_supported", K1, ldx, 48, N2) == 0 and _lib.query("ka_fc_chain_supported", 100, 100, H, N2) == 0
+
+
+def test_masked_softmax_for_action_selection():
+    """probs over the legal actions + legal counts in one launch == the reference's masked_fill/softmax/Categorical chain
+    (katago_ppo.py:566-584); torch.multinomial on them draws what Categorical(probs).sample() draws."""
+    B, A = 9, 11259
+    g = torch.Generator().manual_seed(2)
+    logits = 4 * torch.randn(B, A, generator=g)
+    legal = torch.rand(B, A, generator=g) < 0.02
+    legal[:, 100] = True
+    legal[3] = False                                   # a terminal-state row: count 0, row ignored by the caller
+    ref = torch.softmax(logits.masked_fill(~legal, float("-inf")), dim=-1)
+    probs = torch.empty(B, A, device=DEV)
+    cnt = torch.empty(B, dtype=torch.int32, device=DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.call("ka_masked_softmax", logits.to(DEV), legal.to(DEV), probs, cnt, flags, B, A, 0, st())
+    ok = [i for i in range(B) if i != 3]
+    assert cnt.cpu().tolist() == legal.sum(-1).tolist() and flags.item() == 0
+    assert torch.allclose(probs.cpu()[ok], ref[ok], rtol=2e-5, atol=1e-9)
+    assert float(probs[ok].sum(-1).sub(1).abs().max()) < 1e-5 and bool((probs.cpu()[ok][~legal[ok]] == 0).all())
+    bits = torch.empty(B, (A + 31) // 32, dtype=torch.int32, device=DEV)
+    _lib.call("ka_pack_mask_bits", legal.to(DEV), bits, B, A, st())
+    probs2 = torch.empty_like(probs)
+    _lib.call("ka_masked_softmax", logits.to(DEV), bits, probs2, cnt, flags, B, A, (A + 31) // 32, st())
+    assert torch.equal(probs2[ok], probs[ok])
+    torch.manual_seed(7)
+    a_ref = torch.distributions.Categorical(ref[ok].to(DEV), validate_args=False).sample()
+    torch.manual_seed(7)
+    a_got = torch.multinomial(probs[ok], 1, True).squeeze(1)
+    assert torch.equal(a_ref, a_got)
+    bad = logits.clone(); bad[5, 7] = float("nan")
+    _lib.call("ka_masked_softmax", bad.to(DEV), legal.to(DEV), probs, cnt, flags, B, A, 0, st())
+    assert flags.item() == 1

@@ -138,9 +138,19 @@ __global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* _
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
 // `sums` is either the reduced [2C] vector (nparts == 1) or the stage-1 partials [nparts][2C], summed here in slice order
+// (a thread owns a channel: the 64 partials are fetched 16 at a time BEFORE they are added, in slice order -- a plain
+// `s += p[k]` loop issues one L2 round trip per element and made these 4-workgroup kernels take 35 us each)
 __device__ __forceinline__ double sum_parts(const double* __restrict__ p, int nparts, int stride, int c) {
     double s = 0.0;
-    for (int k = 0; k < nparts; ++k) s += p[(size_t)k * stride + c];
+    int k = 0;
+    for (; k + 16 <= nparts; k += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(k + u) * stride + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; k < nparts; ++k) s += p[(size_t)k * stride + c];
     return s;
 }
 __global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,

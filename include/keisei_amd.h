@@ -147,6 +147,11 @@ int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* 
  * *_bf16 flags mark bf16 operands/outputs; nsplit > 1 writes raw fp32 partial slabs (reduce with ka_reduce_slabs). */
 int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
             int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int accumulate, int nsplit, void* stream);
+/* Every FC weight / bias gradient of a backward pass in one launch: job j computes dW_j (N,K) = dY_j^T X_j and, when db_j
+ * is non-zero, db_j (N) = column sums of dY_j (dY_j (M,N) fp32; X_j M rows of ldx floats or bf16).  table: device int64
+ * [njobs][10] = {dY, X, dW, db, M, N, K, ldx, x_bf16, first workgroup of the job}; a job owns ceil(N/64) *
+ * ceil((K + (db != 0)) / 64) consecutive workgroups, total_wgs = their sum.  No split-K: one fixed summation order. */
+int ka_gemm_grouped_wgrad(const long long* table, int njobs, int total_wgs, void* stream);
 /* Two chained FC layers in one launch (se_resnet.py:57-66 global_fc / se_fc1+se_fc2, :125-130 value / score heads):
  *   y (M,N2) = W2 (N2,H) * relu(W1 (H,K1) * x' + b1) + b2,   x' = x (M rows of ldx floats, first K1 used), or with
  *   in_scale/in_shift: x'[m,k] = in_scale[k] * (x[m,k] * in_alpha) + in_shift[k] (the SE squeeze from the conv's per-board

@@ -63,6 +63,7 @@ _SIGS = {
     "ka_gae": "ppppp pp ii dd i p",
     "ka_normalize_advantages": "pp q p",
     "ka_bn_eval_coeffs_multi": "p ii p",
+    "ka_gemm_grouped_wgrad": "p ii p",
     "ka_fc_chain_supported": "iiii",
     "ka_fc_chain": "ppp f pppp ppp iiiii p",
     "ka_mask_words": "i",

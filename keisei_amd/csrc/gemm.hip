@@ -55,14 +55,17 @@ __device__ __forceinline__ f32x4 ld4(const void* base, size_t i, int bf16, int v
 // NW = waves per workgroup: 4 (each wave a 16x64 strip) or 16 (each wave ONE 16x16 tile) -- the latter for problems with
 // few workgroups (small-batch rollout inference), where the chain of 32 dependent-issue f32 MFMAs per K-tile and wave,
 // not the machine, sets the time; only the first 256 threads stage the tiles.
-template <bool TA, bool TB, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
+// ONES (grouped weight-gradient form): B carries a virtual extra column of ones at n == N, so that output column is the
+// column sum of A over K -- the bias gradient -- and goes to `colsum_out` instead of C.
+template <bool TA, bool TB, int NW, bool ONES>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int bx, int by, int bz, float* colsum_out) {
     constexpr int BK = 32;
     __shared__ __attribute__((aligned(16))) float As[BK][64 + 16];
     __shared__ __attribute__((aligned(16))) float Bs[BK][64 + 16];
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
+    const int m0 = by * 64, n0 = bx * 64;
+    const int kbeg = bz * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
+    const int Neff = g.N + ((ONES && colsum_out) ? 1 : 0);
     // per-thread load roles: two float4 per operand per tile
     //   contiguous-K operand (A not transposed / B transposed): row = t>>3 (+32), k4 = t&7
     //   contiguous-M/N operand: k = t>>4 (+16), col4 = t&15
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
             } else {
                 const int k = k0 + (tid >> 4) + 16 * h, n = n0 + (tid & 15) * 4;
                 rb[h] = ld4(g.B, (size_t)k * g.ldb + n, g.b_bf16, g.b_vec, k < kend ? g.N - n : 0);
+                if (ONES && Neff > g.N && k < kend && g.N >= n && g.N < n + 4) rb[h][g.N - n] = 1.f;
             }
         }
     };
@@ -125,20 +129,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int nt = (NW == 4 ? j : wn) * 16;
-            if (n0 + nt >= g.N) continue;                // uniform: column tiles beyond N (N = 32 heads) cost nothing
+            if (n0 + nt >= Neff) continue;               // uniform: column tiles beyond N (N = 32 heads) cost nothing
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4)           // A[m = 16 wm + r][k = kk + q] x B[k][n = nt + r]
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[kk + q][wm * 16 + r], Bs[kk + q][nt + r], acc[j], 0, 0, 0);
         }
     }
     // accumulator lane (r, q), element i: C[m = 16 wm + 4q + i][n = 16 j + r]
-    const size_t slab = (size_t)blockIdx.z * g.M * g.ldc;
+    const size_t slab = (size_t)bz * g.M * g.ldc;
     float* C = static_cast<float*>(g.C);
     if (!rows_live) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + (NW == 4 ? j : wn) * 16 + r;
-        if (n >= g.N) continue;
+        if (n >= Neff) continue;
+        if (ONES && n == g.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 16 + 4 * q + i;
+                if (m < g.M) colsum_out[m] = acc[j][i];
+            }
+            continue;
+        }
         const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -151,6 +163,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
             else C[o] = g.accumulate ? C[o] + v : v;
         }
     }
+}
+
+template <bool TA, bool TB, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_fast_kernel(GemmArgs g) {
+    gemm_tile<TA, TB, NW, false>(g, blockIdx.x, blockIdx.y, blockIdx.z, nullptr);
+}
+
+// All FC weight / bias gradients of a backward pass in ONE launch (168 jobs at 40 blocks):
+//   job j: dW_j (N,K) = dY_j^T X_j,  db_j (N) = column sums of dY_j      (dY_j (M,N) fp32, X_j (M rows of ldx, fp32 or bf16))
+// table[j] = {dY, X, dW, db (or 0), M, N, K, ldx, x_bf16, first workgroup of the job}; a workgroup owns one 64x64 tile of one
+// job and runs the whole contraction over the M rows (no split-K: one fixed summation order, nothing to reduce).  As single
+// launches these were 6 GEMM + 8 slab-reduce + 4 column-sum launches per block on the critical stream of the backward.
+__global__ __launch_bounds__(256) void gemm_grouped_wgrad_kernel(const long long* __restrict__ table, int njobs) {
+    int lo = 0, hi = njobs - 1;                    // last job whose first workgroup is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)table[(size_t)mid * 10 + 9] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* t = table + (size_t)lo * 10;
+    const int M = (int)t[4], N = (int)t[5], K = (int)t[6], ldx = (int)t[7];
+    float* db = reinterpret_cast<float*>(t[3]);
+    GemmArgs g{reinterpret_cast<const void*>(t[0]), reinterpret_cast<const void*>(t[1]), reinterpret_cast<void*>(t[2]), nullptr,
+               N, K, M, N, ldx, K, 1, 0, 0, (int)t[8], 0, 0, (M + 31) / 32 * 32, 0, 0, 0};
+    g.a_vec = (N % 4 == 0) && ((t[0] & 15) == 0);
+    g.b_vec = (ldx % 4 == 0) && ((t[1] & (g.b_bf16 ? 7 : 15)) == 0);
+    const int tiles_x = (K + (db ? 1 : 0) + 63) / 64;
+    const int local = (int)blockIdx.x - (int)t[9];
+    gemm_tile<true, false, 4, true>(g, local % tiles_x, local / tiles_x, 0, db);
 }
 
 // Two chained small FC layers of the board-vector paths (global-pool bias: 3C -> G -> C; squeeze-excite: C -> C/r -> 2C;
@@ -400,6 +440,14 @@ extern "C" int ka_gemm(const void* A, const void* B, void* C, const float* bias,
     else KA_GEMM_LAUNCH(false, false);
 #undef KA_GEMM_LAUNCH
     return ka_check_launch("gemm");
+}
+
+// table: device int64 [njobs][10] = {dY, X, dW, db or 0, M, N, K, ldx, x_bf16, first workgroup}; total_wgs = sum over jobs of
+// ceil(N/64) * ceil((K + (db != 0)) / 64)
+extern "C" int ka_gemm_grouped_wgrad(const long long* table, int njobs, int total_wgs, void* stream) {
+    KA_REQUIRE(table && njobs > 0 && total_wgs > 0, "gemm_grouped_wgrad: bad arguments");
+    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(total_wgs), dim3(256), 0, static_cast<hipStream_t>(stream), table, njobs);
+    return ka_check_launch("gemm_grouped_wgrad");
 }
 
 // 1 when ka_fc_chain handles the shape (otherwise callers issue the two GEMMs)

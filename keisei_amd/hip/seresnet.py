@@ -54,6 +54,8 @@ class SEResNetEngine:
         self._pack_table = None
         self._pack_max = 0
         self._wslab: Optional[torch.Tensor] = None
+        self._fc_jobs = None          # open list of deferred FC weight-gradient jobs during a backward pass
+        self._row_ring = None
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
         self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
@@ -259,13 +261,64 @@ class SEResNetEngine:
               M, K1, ldx, H, N2, st)
         return xp, hidden, y
 
-    def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0):
+    def _upload_rows(self, rows, device):
+        """int64 table -> device through one of two rotating pinned buffers (the host never waits for the stream)."""
+        flat = torch.tensor(rows, dtype=torch.int64).reshape(-1)
+        ring = self._row_ring
+        if ring is None or ring["host"][0].numel() < flat.numel():
+            n = max(flat.numel(), 4096)
+            ring = {"host": [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(2)],
+                    "dev": [torch.empty(n, dtype=torch.int64, device=device) for _ in range(2)], "evt": [None, None], "flip": 0}
+            self._row_ring = ring
+        i = ring["flip"]
+        ring["flip"] ^= 1
+        if ring["evt"][i] is not None:
+            ring["evt"][i].synchronize()
+        ring["host"][i][:flat.numel()].copy_(flat)
+        ring["dev"][i][:flat.numel()].copy_(ring["host"][i][:flat.numel()], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["evt"][i] = ev
+        return ring["dev"][i]
+
+    def _flush_fc_jobs(self, grads, device, st) -> None:
+        """One grouped launch for every deferred FC weight / bias gradient of this backward pass."""
+        jobs, self._fc_jobs = self._fc_jobs, None
+        if not jobs:
+            return
+        total = sum(N * K + (N if bname is not None else 0) for (_, _, _, _, _, N, K, _, bname, _) in jobs)
+        flat = torch.empty(total, device=device)
+        rows, off, wg = [], 0, 0
+        for dy, x, ldx, xbf, M, N, K, wname, bname, wshape in jobs:
+            dW = flat[off:off + N * K]; off += N * K
+            db_ptr = 0
+            if bname is not None:
+                db = flat[off:off + N]; off += N
+                grads[bname] = db
+                db_ptr = db.data_ptr()
+            grads[wname] = dW.view(wshape)
+            rows.append([dy.data_ptr(), x.data_ptr(), dW.data_ptr(), db_ptr, M, N, K, ldx, xbf, wg])
+            wg += ((N + 63) // 64) * ((K + (1 if bname is not None else 0) + 63) // 64)
+        table = self._upload_rows(rows, device)
+        _call("ka_gemm_grouped_wgrad", table, len(jobs), wg, st)
+
+    def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0,
+                    defer=True):
         """dW = dy^T x (split over rows), db = colsum(dy), dx = dy W."""
         M, N = dy.shape
         K = lin.weight.shape[1] if lin.weight.ndim == 2 else lin.weight.shape[1]
         dev = dy.device
-        ns = max(1, min(64, (M + 511) // 512))
         ldx = x.shape[1]
+        if (defer and self._fc_jobs is not None and M <= 16384 and dy.dtype == torch.float32 and dy.is_contiguous()
+                and x.is_contiguous()):    # (the B*81-row policy-head GEMMs keep their split-K launches)
+            # weight / bias gradient deferred to the grouped launch at the end of the backward (nothing reads them earlier)
+            self._fc_jobs.append((dy, x, ldx, int(x_bf16), M, N, K, wname, bname, tuple(lin.weight.shape)))
+            if not need_dx:
+                return None
+            dx = dx_out if dx_out is not None else torch.empty(M, K, device=dev)
+            self._gemm(dy, lin.weight, dx, None, M, K, N, N, K, K, 0, 0, st, acc=acc_dx)
+            return dx
+        ns = max(1, min(64, (M + 511) // 512))
         dW = torch.empty(N, K, device=dev)
         if ns == 1:
             self._gemm(dy, x, dW, None, N, K, M, N, ldx, K, 1, 0, st, bbf=x_bf16)
@@ -465,6 +518,7 @@ class SEResNetEngine:
         grads: Dict[str, torch.Tensor] = {}
         M = B * 81
         count = M
+        self._fc_jobs = [] if os.environ.get("KA_FC_WGRAD_GROUPED", "1") != "0" else None
 
         def new_act(ch=C):
             return torch.empty(B, 81, ch, dtype=T, device=dev)
@@ -490,7 +544,7 @@ class SEResNetEngine:
         if dlogits is not None:
             dl = dlogits.float().contiguous().view(M, A)
             w2 = _FakeLinear(m.policy_conv2.weight.view(A, P), m.policy_conv2.bias)
-            dp = self._linear_bwd(dl, p1r, w2, grads, "policy_conv2.weight", "policy_conv2.bias", st)
+            dp = self._linear_bwd(dl, p1r, w2, grads, "policy_conv2.weight", "policy_conv2.bias", st, defer=False)
             grads["policy_conv2.weight"] = grads["policy_conv2.weight"].view_as(m.policy_conv2.weight)
             _call("ka_rows_bn_bwd", dp, p1, scp, shp, M, P, 0, st)                # ReLU mask
             nsp = max(1, min(256, (M + 2047) // 2048))
@@ -605,6 +659,7 @@ class SEResNetEngine:
         self._wgrad_launch(side, main, (dout, dW0), dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad,
                            p.obs_channels, C, 0, 0, code)
         grads["input_conv.weight"] = dW0
+        self._flush_fc_jobs(grads, dev, st)
         if side is not None:
             main.wait_stream(side)          # every dW is complete before autograd hands the gradients on
         return grads

@@ -706,3 +706,27 @@ def test_masked_softmax_for_action_selection():
     bad = logits.clone(); bad[5, 7] = float("nan")
     _lib.call("ka_masked_softmax", bad.to(DEV), legal.to(DEV), probs, cnt, flags, B, A, 0, st())
     assert flags.item() == 1
+
+
+def test_grouped_fc_weight_gradients():
+    """every FC weight / bias gradient of a backward pass in one launch == per-job dY^T X and column sums of dY."""
+    g = torch.Generator().manual_seed(31)
+    shapes = [(97, 128, 768, 1024, 0, True), (97, 256, 128, 128, 0, True), (97, 512, 16, 16, 0, True), (97, 16, 256, 256, 0, True),
+              (97, 3, 40, 40, 0, False), (300, 70, 33, 36, 1, True)]            # (M, N, K, ldx, x_bf16, has_bias)
+    rows, keep, wg = [], [], 0
+    for M, N, K, ldx, xbf, has_b in shapes:
+        dy = torch.randn(M, N, generator=g)
+        x = torch.randn(M, ldx, generator=g)
+        xd = x.bfloat16().to(DEV) if xbf else x.to(DEV)
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV) if has_b else None
+        dyd = dy.to(DEV)
+        keep.append((dy, x.bfloat16().float() if xbf else x, dW, db, dyd, xd, K))
+        rows.append([dyd.data_ptr(), xd.data_ptr(), dW.data_ptr(), db.data_ptr() if has_b else 0, M, N, K, ldx, xbf, wg])
+        wg += ((N + 63) // 64) * ((K + (1 if has_b else 0) + 63) // 64)
+    table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    _lib.call("ka_gemm_grouped_wgrad", table, len(rows), wg, st())
+    for dy, x, dW, db, _, _, K in keep:
+        assert torch.allclose(dW.cpu(), dy.t() @ x[:, :K], rtol=1e-4, atol=1e-3)
+        if db is not None:
+            assert torch.allclose(db.cpu(), dy.sum(0), rtol=1e-4, atol=1e-3)

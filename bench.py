@@ -322,6 +322,10 @@ def main() -> None:
                 extra["wgrad_kernel"] = {"avg_launch_ms": round(wavg, 4), "achieved_tflops": round(conv_flop / (wavg * 1e-3) / 1e12, 1),
                                          "launches_timed": len(w_ms)}
             extra["conv_share_of_step"] = round((sum(conv_ms) + sum(w_ms if ev["wgrad"] else [])) / (elapsed * 1e3), 3)
+            # all MFMA launches (conv + wgrad, which overlap on two streams) over the whole timed region, every phase included
+            n_mfma = len(conv_ms) + (len(w_ms) if ev["wgrad"] else 0)
+            extra["mfma_step_average"] = {"launches": n_mfma, "achieved_tflops": round(n_mfma * conv_flop / elapsed / 1e12, 1),
+                                          "frac": round(n_mfma * conv_flop / elapsed / 1e12 / peak, 4)}
         out = {
             "metric": "PPO samples/sec, se_resnet 40x256 on 50x9x9" if args.workload == "40x256" else f"PPO samples/sec, se_resnet {args.workload}",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

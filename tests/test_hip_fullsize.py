@@ -128,3 +128,49 @@ def test_dgrad_is_the_adjoint_of_forward_full_size():
     lhs = float((y.double() * dy.double()).sum())
     rhs = float((x.double() * dx.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3 * float(y.double().norm() * dy.double().norm()) * 1e-6
+
+
+def test_fc_kernels_full_size():
+    """The board-vector FC kernels at the headline batch (4096 rows): the fused forward chain against its own two-GEMM
+    fallback, and the grouped weight-gradient launch against per-job split-K GEMMs + column sums -- both pairs compute the
+    same fp32 contractions in different orders, so they agree to rounding; plus additivity of the gradients over the batch."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    M, K1, ldx, H, N2 = B, 3 * C, 4 * C, 128, C
+    x = torch.randn(M, ldx, device=DEV, generator=g)
+    W1, b1 = torch.randn(H, K1, device=DEV, generator=g) / K1 ** 0.5, torch.randn(H, device=DEV, generator=g)
+    W2, b2 = torch.randn(N2, H, device=DEV, generator=g) / H ** 0.5, torch.randn(N2, device=DEV, generator=g)
+    y, hid = torch.empty(M, N2, device=DEV), torch.empty(M, H, device=DEV)
+    _lib.call("ka_fc_chain", x, None, None, 1.0, W1, b1, W2, b2, None, hid, y, M, K1, ldx, H, N2, st())
+    hid2, y2 = torch.empty(M, H, device=DEV), torch.empty(M, N2, device=DEV)
+    _lib.call("ka_gemm", x, W1, hid2, b1, M, H, K1, ldx, K1, H, 0, 1, 0, 0, 0, 1, 0, 1, st())
+    _lib.call("ka_gemm", hid2, W2, y2, b2, M, N2, H, H, H, N2, 0, 1, 0, 0, 0, 0, 0, 1, st())
+    assert float((hid - hid2).abs().max()) <= 2e-5 * float(hid2.abs().max())
+    assert float((y - y2).abs().max()) <= 2e-5 * float(y2.abs().max())
+    # grouped weight gradients: dW1 = dh^T x, dW2 = dy^T hid, with their bias gradients
+    dy, dh = torch.randn(M, N2, device=DEV, generator=g), torch.randn(M, H, device=DEV, generator=g)
+
+    def grouped(rows_lo, rows_hi):
+        n = rows_hi - rows_lo
+        dW1, db1 = torch.empty(H, K1, device=DEV), torch.empty(H, device=DEV)
+        dW2, db2 = torch.empty(N2, H, device=DEV), torch.empty(N2, device=DEV)
+        a, bq, c, d = dh[rows_lo:rows_hi], x[rows_lo:rows_hi], dy[rows_lo:rows_hi], hid2[rows_lo:rows_hi]
+        wg1 = ((H + 63) // 64) * ((K1 + 1 + 63) // 64)
+        table = torch.tensor([[a.data_ptr(), bq.data_ptr(), dW1.data_ptr(), db1.data_ptr(), n, H, K1, ldx, 0, 0],
+                              [c.data_ptr(), d.data_ptr(), dW2.data_ptr(), db2.data_ptr(), n, N2, H, H, 0, wg1]], dtype=torch.int64).to(DEV)
+        _lib.call("ka_gemm_grouped_wgrad", table, 2, wg1 + ((N2 + 63) // 64) * ((H + 1 + 63) // 64), st())
+        return dW1, db1, dW2, db2
+
+    full = grouped(0, M)
+    ns = 8
+    slab = torch.empty(ns, H, K1, device=DEV)
+    ref1 = torch.zeros(H, K1, device=DEV)
+    _lib.call("ka_gemm", dh, x, slab, None, H, K1, M, H, ldx, K1, 1, 0, 0, 0, 0, 0, 0, ns, st())
+    _lib.call("ka_reduce_slabs", slab, ref1, ns, H * K1, 0, st())
+    torch.cuda.synchronize()
+    assert float((full[0] - ref1).abs().max()) <= 3e-5 * float(ref1.abs().max())
+    assert float((full[1] - dh.double().sum(0).float()).abs().max()) <= 1e-4 * float(full[1].abs().max())
+    assert float((full[3] - dy.double().sum(0).float()).abs().max()) <= 1e-4 * float(full[3].abs().max())
+    halves = [grouped(0, M // 2), grouped(M // 2, M)]
+    for i in range(4):
+        both = halves[0][i] + halves[1][i]
+        assert float((full[i] - both).abs().max()) <= 3e-5 * float(full[i].abs().max())

@@ -60,12 +60,23 @@ __global__ __launch_bounds__(kPolThreads) void policy_loss_kernel(PolicyArgs a) 
 
     float mx = -INFINITY, nlegal = 0.f;
     int nan_seen = 0;
-    for (int j = tid; j < a.A; j += kPolThreads) {
-        const float v = lg[j];
-        const uint8_t k = a.legal_words ? (uint8_t)((lw[j >> 5] >> (j & 31)) & 1u) : lm[j];
-        row[j] = v; msk[j] = k;
-        nan_seen |= (v != v);
-        if (k) { mx = fmaxf(mx, v); nlegal += 1.f; }
+    // four logits and mask entries are requested before the first is used (the row is one HBM round trip per pass otherwise)
+    for (int j0 = tid; j0 < a.A; j0 += 4 * kPolThreads) {
+        float v[4]; uint8_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * kPolThreads;
+            v[u] = j < a.A ? lg[j] : 0.f;
+            k[u] = j < a.A ? (a.legal_words ? (uint8_t)((lw[j >> 5] >> (j & 31)) & 1u) : lm[j]) : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * kPolThreads;
+            if (j >= a.A) break;
+            row[j] = v[u]; msk[j] = k[u];
+            nan_seen |= (v[u] != v[u]);
+            if (k[u]) { mx = fmaxf(mx, v[u]); nlegal += 1.f; }
+        }
     }
     mx = block_reduce(mx, red, true);
     nlegal = block_reduce(nlegal, red, false);

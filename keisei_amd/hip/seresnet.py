@@ -40,6 +40,11 @@ class _Saved:
     __slots__ = ("B", "T", "train", "xin", "stem", "blocks", "heads", "sync")
 
 
+# split-K slabs of the row-reduction GEMMs (weight / bias gradients over B or B*81 rows): more, shorter workgroups -- the
+# B*81-row policy-head forms are latency-bound chains of K-tiles (measured 64 -> 256: -0.6 % step time)
+_FC_SPLITS = int(os.environ.get("KA_FC_SPLITS", "256"))
+
+
 class SEResNetEngine:
     def __init__(self, model: nn.Module) -> None:
         self.model = model
@@ -318,7 +323,7 @@ class SEResNetEngine:
             dx = dx_out if dx_out is not None else torch.empty(M, K, device=dev)
             self._gemm(dy, lin.weight, dx, None, M, K, N, N, K, K, 0, 0, st, acc=acc_dx)
             return dx
-        ns = max(1, min(64, (M + 511) // 512))
+        ns = max(1, min(_FC_SPLITS, (M + 511) // 512))
         dW = torch.empty(N, K, device=dev)
         if ns == 1:
             self._gemm(dy, x, dW, None, N, K, M, N, ldx, K, 1, 0, st, bbf=x_bf16)
@@ -328,7 +333,7 @@ class SEResNetEngine:
             _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
         grads[wname] = dW.view_as(lin.weight)
         if bname is not None:
-            nsb = max(1, min(64, (M + 127) // 128))
+            nsb = max(1, min(_FC_SPLITS, (M + 127) // 128))
             db = torch.empty(N, device=dev)
             if nsb == 1:
                 _call("ka_colsum", dy, None, db, None, M, N, 1, st)
@@ -669,7 +674,7 @@ class SEResNetEngine:
         M, N = dy.shape
         K = lin.weight.shape[1]
         dev = dy.device
-        ns = max(1, min(64, (M + 4095) // 4096))
+        ns = max(1, min(_FC_SPLITS, (M + 1023) // 1024))
         dW = torch.empty(N, K, device=dev)
         slab = self._scratch_f32(ns * N * K, dev)
         self._gemm(dy, x_act, slab, None, N, K, M, N, K, K, 1, 0, st, bbf=bf, ns=ns)

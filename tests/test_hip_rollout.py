@@ -224,3 +224,16 @@ def test_advantages_on_device_equal_host_path(golden, env_layout):
     a_host = algo._advantages(host.flatten(), host, nv, torch.device(DEV))
     a_dev = algo._advantages(dev.flatten_packed(), dev, nv, torch.device(DEV))
     assert a_dev.is_cuda and not a_host.is_cuda and torch.equal(a_dev.cpu(), a_host)
+
+
+def test_host_store_switch_and_pinned_batches(monkeypatch, tmp_path):
+    """KA_ROLLOUT_BUFFER=host keeps the reference's CPU store although add() receives device tensors."""
+    monkeypatch.setenv("KA_ROLLOUT_BUFFER", "host")
+    steps = synth_steps(2, 3, seed=77)
+    buf = KataGoRolloutBuffer(3, (50, 9, 9), A)
+    fill(buf, steps, DEV)
+    flat = buf.flatten()
+    assert not buf.is_device_resident and not flat["observations"].is_cuda and flat["legal_masks"].dtype == torch.bool
+    ref = KataGoRolloutBuffer(3, (50, 9, 9), A)
+    fill(ref, steps, "cpu")
+    assert all(same(flat[k], v) for k, v in ref.flatten().items())

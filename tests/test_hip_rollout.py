@@ -237,3 +237,20 @@ def test_host_store_switch_and_pinned_batches(monkeypatch, tmp_path):
     ref = KataGoRolloutBuffer(3, (50, 9, 9), A)
     fill(ref, steps, "cpu")
     assert all(same(flat[k], v) for k, v in ref.flatten().items())
+
+
+def test_advantages_legacy_flat_layout_on_device(golden):
+    """Rows that neither fill the (T, N) grid nor carry env ids: one chain, bootstrap from the mean next value."""
+    _, m, algo = make_algo(golden)
+    N = 4
+    steps = synth_steps(5, N, seed=61, env_layout=True, overrides=False)
+    for s in steps:
+        s.pop("env_ids")
+    host, dev = KataGoRolloutBuffer(N, (50, 9, 9), A), KataGoRolloutBuffer(N, (50, 9, 9), A)
+    fill(host, steps, "cpu"); fill(dev, steps, DEV)
+    if host.flatten()["rewards"].numel() == 5 * N:
+        pytest.skip("the random step sizes happened to fill the grid")
+    nv = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(DEV)
+    a_host = algo._advantages(host.flatten(), host, nv, torch.device(DEV))
+    a_dev = algo._advantages(dev.flatten_packed(), dev, nv, torch.device(DEV))
+    assert torch.allclose(a_dev.cpu(), a_host.cpu(), rtol=1e-6, atol=1e-6)

@@ -174,3 +174,27 @@ def test_fc_kernels_full_size():
     for i in range(4):
         both = halves[0][i] + halves[1][i]
         assert float((full[i] - both).abs().max()) <= 3e-5 * float(full[i].abs().max())
+
+
+def test_headline_model_eval_is_per_board_full_size():
+    """se_resnet 40x256, 4096 boards, bf16, eval mode: no tensor couples the boards, so permuting the batch permutes
+    the outputs bit for bit, and a board evaluated inside the big batch equals the same board in a batch of eight
+    (every conv / board / FC kernel of the forward at the headline shape, small-batch kernel selections included)."""
+    from keisei_amd.training.model_registry import build_model
+    torch.manual_seed(3)
+    m = build_model("se_resnet", dict(num_blocks=40, channels=256, se_reduction=16, global_pool_channels=128,
+                                      policy_channels=32, value_fc_size=256, score_fc_size=128, obs_channels=50)).to(DEV).eval()
+    m.configure_amp(True, torch.bfloat16, "cuda")
+    g = torch.Generator(device=DEV).manual_seed(4)
+    obs = (torch.rand(B, 50, 9, 9, device=DEV, generator=g) < 0.1).float()
+    perm = torch.randperm(B, device=DEV, generator=g)
+    with torch.no_grad():
+        a = m(obs)
+        b = m(obs[perm].contiguous())
+        small = m(obs[:8].contiguous())
+    for x, y in ((a.policy_logits, b.policy_logits), (a.value_logits, b.value_logits), (a.score_lead, b.score_lead)):
+        assert torch.isfinite(x).all() and torch.equal(x[perm], y)
+    # the 8-board batch runs narrower conv slabs, 16-wave GEMMs and the captured graph: same arithmetic per board,
+    # different summation orders only in the fp32 FC layers
+    assert float((small.policy_logits - a.policy_logits[:8]).abs().max()) <= 2e-2 * float(a.policy_logits[:8].abs().max())
+    assert float((small.value_logits - a.value_logits[:8]).abs().max()) <= 2e-2 * max(1.0, float(a.value_logits[:8].abs().max()))

@@ -198,3 +198,31 @@ def test_headline_model_eval_is_per_board_full_size():
     # different summation orders only in the fp32 FC layers
     assert float((small.policy_logits - a.policy_logits[:8]).abs().max()) <= 2e-2 * float(a.policy_logits[:8].abs().max())
     assert float((small.value_logits - a.value_logits[:8]).abs().max()) <= 2e-2 * max(1.0, float(a.value_logits[:8].abs().max()))
+
+
+def test_headline_model_backward_is_deterministic_and_linear_full_size():
+    """se_resnet 40x256, 4096 boards, bf16, train-mode BatchNorm: two forward+backward passes give bit-identical parameter
+    gradients (fixed-order reductions everywhere, two streams included), and doubling the output cotangents doubles every
+    gradient exactly (the backward is linear in them and a factor of two commutes with each bf16 / fp32 rounding)."""
+    from keisei_amd.training.model_registry import build_model
+    torch.manual_seed(5)
+    m = build_model("se_resnet", dict(num_blocks=40, channels=256, se_reduction=16, global_pool_channels=128,
+                                      policy_channels=32, value_fc_size=256, score_fc_size=128, obs_channels=50)).to(DEV).train()
+    m.configure_amp(True, torch.bfloat16, "cuda")
+    g = torch.Generator(device=DEV).manual_seed(6)
+    obs = (torch.rand(B, 50, 9, 9, device=DEV, generator=g) < 0.1).float()
+    cp = torch.randn(B, 9, 9, 139, device=DEV, generator=g) / B
+    cv, cs = torch.randn(B, 3, device=DEV, generator=g) / B, torch.randn(B, 1, device=DEV, generator=g) / B
+
+    def grads(scale):
+        m.zero_grad(set_to_none=True)
+        o = m(obs)
+        torch.autograd.backward([o.policy_logits, o.value_logits, o.score_lead], [scale * cp, scale * cv, scale * cs])
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    g1, g1b, g2 = grads(1.0), grads(1.0), grads(2.0)
+    assert all(torch.isfinite(v).all() for v in g1.values())
+    for n in g1:
+        assert torch.equal(g1[n], g1b[n]), n            # run-to-run deterministic
+        assert torch.equal(2 * g1[n], g2[n]), n         # linear in the cotangents, exactly
+    assert float(g1["blocks.0.conv1.weight"].abs().max()) > 0

@@ -226,3 +226,43 @@ def test_headline_model_backward_is_deterministic_and_linear_full_size():
         assert torch.equal(g1[n], g1b[n]), n            # run-to-run deterministic
         assert torch.equal(2 * g1[n], g2[n]), n         # linear in the cotangents, exactly
     assert float(g1["blocks.0.conv1.weight"].abs().max()) > 0
+
+
+def test_policy_loss_full_size_properties():
+    """4096 x 11259 logits: gradients vanish on illegal actions, sum to zero over each row (every term is a function of the
+    log-softmax), bool and packed masks agree bit for bit, and rows gathered through an index equal rows evaluated alone."""
+    A = 11259
+    g = torch.Generator(device=DEV).manual_seed(8)
+    logits = 3 * torch.randn(B, A, device=DEV, generator=g)
+    legal = torch.rand(B, A, device=DEV, generator=g) < 0.03
+    legal[:, 11] = True
+    actions = torch.full((B,), 11, dtype=torch.long, device=DEV)
+    old, adv = -7 + torch.randn(B, device=DEV, generator=g), torch.randn(B, device=DEV, generator=g)
+    bits = torch.empty(B, (A + 31) // 32, dtype=torch.int32, device=DEV)
+    _lib.call("ka_pack_mask_bits", legal, bits, B, A, st())
+    idx = torch.randperm(B, device=DEV, generator=g)
+
+    def run(masks, words, index):
+        dl = torch.empty(B, A, device=DEV)
+        nlp, rl, re = (torch.empty(B, device=DEV) for _ in range(3))
+        flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+        _lib.call("ka_policy_loss", logits, masks, actions, old, adv, index, dl, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B,
+                  B, A, words, st())
+        assert flags.cpu().tolist() == [0, 0]
+        return dl, nlp, rl, re
+
+    plain = run(legal, 0, None)
+    packed = run(bits, (A + 31) // 32, None)
+    for a, b in zip(plain, packed):
+        assert torch.equal(a, b)
+    dl = plain[0]
+    assert bool((dl[~legal] == 0).all())
+    assert float(dl.double().sum(1).abs().max()) <= 1e-6 * float(dl.abs().max()) * 100
+    # logits row b paired with the per-sample data of row idx[b]: compare with explicitly gathered per-sample data
+    gathered = run(bits, (A + 31) // 32, idx)
+    dl2 = torch.empty(B, A, device=DEV)
+    nlp, rl, re = (torch.empty(B, device=DEV) for _ in range(3))
+    flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+    _lib.call("ka_policy_loss", logits, legal[idx].contiguous(), actions[idx].contiguous(), old[idx].contiguous(),
+              adv[idx].contiguous(), None, dl2, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B, B, A, 0, st())
+    assert torch.equal(gathered[0], dl2) and torch.equal(gathered[1], nlp)

@@ -266,3 +266,32 @@ def test_policy_loss_full_size_properties():
     _lib.call("ka_policy_loss", logits, legal[idx].contiguous(), actions[idx].contiguous(), old[idx].contiguous(),
               adv[idx].contiguous(), None, dl2, nlp, rl, re, flags, None, 0.2, 1.0 / B, 0.01 / B, B, A, 0, st())
     assert torch.equal(gathered[0], dl2) and torch.equal(gathered[1], nlp)
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_gae_full_size_bit_exact(f64):
+    """The epoch grid of keisei-katago.toml (T = 512 steps x N = 128 environments), with terminations, NaN-sentinel
+    overrides and per-environment lengths: the one-launch scan equals the oracle's numpy recurrence bit for bit."""
+    import numpy as np
+
+    from oracle import keisei_oracle as orc
+    T, N = 512, 128
+    rng = np.random.default_rng(12)
+    dt = np.float64 if f64 else np.float32
+    r, v = rng.standard_normal((T, N)).astype(dt), rng.standard_normal((T, N)).astype(dt)
+    term = (rng.random((T, N)) < 0.02).astype(np.float32)
+    nv = rng.standard_normal(N).astype(dt)
+    ov = np.where(rng.random((T, N)) < 0.1, rng.standard_normal((T, N)), np.nan).astype(dt)
+    lengths = rng.integers(1, T + 1, N)
+    for use_ov, use_len in ((False, False), (True, False), (True, True)):
+        ref = orc.gae_grid(r, v, term, nv, 0.99, 0.95, override=ov if use_ov else None, lengths=lengths if use_len else None)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        adv = torch.empty(T, N, dtype=torch.float64 if f64 else torch.float32, device=DEV)
+        _lib.call("ka_gae", tt(r), tt(v), tt(term), tt(nv), tt(ov) if use_ov else None,
+                  tt(lengths.astype(np.int64)) if use_len else None, adv, T, N, 0.99, 0.95, int(f64), st())
+        got = adv.cpu().numpy()
+        if use_len:                       # cells past an environment's length are padding: compared on the valid part only
+            valid = np.arange(T)[:, None] < lengths[None, :]
+            assert np.array_equal(got[valid], ref[valid])
+        else:
+            assert np.array_equal(got, ref)

@@ -295,3 +295,40 @@ def test_gae_full_size_bit_exact(f64):
             assert np.array_equal(got[valid], ref[valid])
         else:
             assert np.array_equal(got, ref)
+
+
+def test_clip_adam_full_size():
+    """The 47 M parameters of se_resnet 40x256 (658 tensors from 16 to 589 824 elements): three fused clip+Adam steps
+    against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam run on the same device."""
+    from keisei_amd.training.model_registry import build_model
+    torch.manual_seed(9)
+    m = build_model("se_resnet", dict(num_blocks=40, channels=256, se_reduction=16, global_pool_channels=128,
+                                      policy_channels=32, value_fc_size=256, score_fc_size=128, obs_channels=50)).to(DEV)
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    opt = torch.optim.Adam(ref_params, lr=3e-4)
+    params = [p.detach().clone() for p in m.parameters()]
+    grads = [torch.empty_like(p) for p in params]
+    ms, vs = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    chunk = _lib.query("ka_adam_chunk")
+    recs, bt, bo = [], [], []
+    for i, p in enumerate(params):
+        recs += [p.data_ptr(), grads[i].data_ptr(), ms[i].data_ptr(), vs[i].data_ptr(), p.numel()]
+        for off in range(0, p.numel(), chunk):
+            bt.append(i); bo.append(off)
+    tab = torch.tensor(recs, dtype=torch.int64, device=DEV)
+    btd, bod = torch.tensor(bt, dtype=torch.int32, device=DEV), torch.tensor(bo, dtype=torch.int64, device=DEV)
+    partial = torch.empty(len(bt), dtype=torch.float64, device=DEV)
+    ctl, step, accn = torch.zeros(4, device=DEV), torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(10)
+    for s in range(3):
+        scale = (4.0, 0.002, 1.0)[s]                  # clipped hard, not clipped, in between
+        for i, p in enumerate(params):
+            grads[i].copy_(scale * torch.randn(p.shape, device=DEV, generator=g) / p.numel() ** 0.5)
+            ref_params[i].grad = grads[i].clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref_params, 1.0)
+        opt.step()
+        _lib.call("ka_clip_adam_step", tab, btd, bod, len(bt), partial, ctl, step, None, None, accn, 1.0, 3e-4, 0.9, 0.999, 1e-8, st())
+        assert abs(float(ctl[0]) - float(norm)) <= 1e-5 * float(norm)
+        worst = max(float((a - b.detach()).abs().max()) for a, b in zip(params, ref_params))
+        assert worst <= 2e-6, (s, worst)              # one update is <= lr = 3e-4 per element
+    assert float(step) == 3.0 and sum(p.numel() for p in params) > 47_000_000

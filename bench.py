@@ -301,8 +301,9 @@ def main() -> None:
             avg = sum(conv_ms) / len(conv_ms)
             ach = conv_flop / (avg * 1e-3) / 1e12
             traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
-            pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic.json"
-            if pmc.exists() and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
+            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"))       # the latest round's counter passes
+            pmc = pmcs[-1] if pmcs else None
+            if pmc is not None and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
                 recs = [v for k, v in json.loads(pmc.read_text())["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
                 rec = max(recs, key=lambda v: v["launches"]) if recs else None      # the tower instantiation
                 traffic = rec["hbm_bytes_per_launch"] if rec else None

@@ -248,6 +248,9 @@ class KataGoRolloutBuffer:
                     score_targets, env_ids, next_value_override) -> None:
         dev = self._device
         n = obs.shape[0]
+        if n == 0:           # the reference's guards fail on an empty step (max() of an empty tensor): same exception here
+            _check_step_inputs(dones.detach().cpu(), terminated.detach().cpu(), value_categories.detach().cpu(),
+                               score_targets.detach().cpu())
         col = lambda t, dt: t.detach().to(device=dev, dtype=dt).reshape(n).contiguous()  # noqa: E731 (no-op when canonical)
         obs_c = obs.detach().to(device=dev, dtype=torch.float32).reshape(n, self._obs_elems).contiguous()
         mask_c = legal_masks.detach().to(device=dev, dtype=torch.bool).reshape(n, self.action_space).contiguous()

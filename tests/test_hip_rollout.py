@@ -254,3 +254,14 @@ def test_advantages_legacy_flat_layout_on_device(golden):
     a_host = algo._advantages(host.flatten(), host, nv, torch.device(DEV))
     a_dev = algo._advantages(dev.flatten_packed(), dev, nv, torch.device(DEV))
     assert torch.allclose(a_dev.cpu(), a_host.cpu(), rtol=1e-6, atol=1e-6)
+
+
+def test_empty_step_raises_as_in_the_reference():
+    s = synth_steps(1, 3, seed=5)[0]
+    empty = {k: v[:0] for k, v in s.items()}
+    for where in (DEV, "cpu"):
+        buf = KataGoRolloutBuffer(3, (50, 9, 9), A)
+        fill(buf, [s], where)
+        with pytest.raises(RuntimeError, match="max"):
+            fill(buf, [empty], where)
+        assert buf.size == 1

@@ -92,7 +92,7 @@ int ka_bn_coeffs(const double* sums, double count, const double* count_dev, cons
                  float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
 int ka_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, float* scale, float* shift, int C, void* stream);
-/* the same for n layers in one launch: device table of n rows {gamma, beta, running_mean, running_var, scale, shift,
+/* the same for n layers in one launch (eval-mode nn.BatchNorm2d at se_resnet.py:51,53,111,121): device table of n rows {gamma, beta, running_mean, running_var, scale, shift,
  * C, eps as float bits} (8 x int64 each); max_c = largest C.  Rollout inference: 82 launches -> 1. */
 int ka_bn_eval_coeffs_multi(const long long* table, int n, int max_c, void* stream);
 /* backward: sums = [sum dz | sum dz*yhat]; dgamma/dbeta from the LOCAL sums, dy = k[0:C]*dz + k[C:2C] + k[2C:3C]*y
@@ -147,7 +147,8 @@ int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* 
  * *_bf16 flags mark bf16 operands/outputs; nsplit > 1 writes raw fp32 partial slabs (reduce with ka_reduce_slabs). */
 int ka_gemm(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
             int transA, int transB, int a_bf16, int b_bf16, int c_bf16, int relu, int accumulate, int nsplit, void* stream);
-/* Every FC weight / bias gradient of a backward pass in one launch: job j computes dW_j (N,K) = dY_j^T X_j and, when db_j
+/* Every FC weight / bias gradient of a backward pass in one launch (autograd's nn.Linear weight / bias backward for
+ * se_resnet.py:57-66 global_fc / se_fc1 / se_fc2 and :125-130 value / score heads): job j computes dW_j (N,K) = dY_j^T X_j and, when db_j
  * is non-zero, db_j (N) = column sums of dY_j (dY_j (M,N) fp32; X_j M rows of ldx floats or bf16).  table: device int64
  * [njobs][10] = {dY, X, dW, db, M, N, K, ldx, x_bf16, first workgroup of the job}; a job owns ceil(N/64) *
  * ceil((K + (db != 0)) / 64) consecutive workgroups, total_wgs = their sum.  No split-K: one fixed summation order. */

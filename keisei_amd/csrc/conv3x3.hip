@@ -521,23 +521,28 @@ __global__ void pack_conv3x3_multi_kernel(const long long* __restrict__ table) {
     void* __restrict__ dst = reinterpret_cast<void*>(t[1]);
     const int Co = (int)t[2], Ci = (int)t[3], Nout = (int)t[4], Kin = (int)t[5], mode = (int)t[6];
     const int KSG = Kin / CPK, NT = Nout / 16;
-    const size_t total = (size_t)9 * KSG * NT * 64;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // one thread per (ks, nt, lane): it produces the piece of ALL nine taps, so that its weight reads are runs of nine
+    // consecutive floats (forward pack: P16 such runs back to back = one contiguous stretch) instead of nine passes
+    // over the weights with a stride of nine
+    const size_t per_tap = (size_t)KSG * NT * 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_tap; i += (size_t)gridDim.x * blockDim.x) {
         const int lane = i & 63;
         size_t u = i >> 6;
-        const int nt = u % NT; u /= NT;
-        const int ks = u % KSG; const int tap = u / KSG;
+        const int nt = u % NT;
+        const int ks = u / NT;
         const int n = chan_of(nt, lane & 15, NT);
-        float f[P16];
+        float f[9][P16];
 #pragma unroll
         for (int e = 0; e < P16; ++e) {
             const int c = ks * CPK + (lane >> 4) * P16 + e;
-            float v = 0.f;
-            if (mode == 0) { if (n < Co && c < Ci) v = w[((size_t)n * Ci + c) * 9 + tap]; }
-            else           { if (c < Co && n < Ci) v = w[((size_t)c * Ci + n) * 9 + (8 - tap)]; }
-            f[e] = v;
+            const bool ok = mode == 0 ? (n < Co && c < Ci) : (c < Co && n < Ci);
+            const float* src = mode == 0 ? w + ((size_t)n * Ci + c) * 9 : w + ((size_t)c * Ci + n) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) f[tap][e] = ok ? src[mode == 0 ? tap : 8 - tap] : 0.f;
         }
-        reinterpret_cast<typename E::vec16*>(dst)[i] = E::pack(f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            reinterpret_cast<typename E::vec16*>(dst)[(size_t)tap * per_tap + i] = E::pack(f[tap]);
     }
 }
 

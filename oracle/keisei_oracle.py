@@ -129,6 +129,59 @@ def synth_state_dict(s: NetShape, salt: int = 0) -> Dict[str, torch.Tensor]:
     return out
 
 
+def _hash_uniform(n: int, salt: int) -> torch.Tensor:
+    """n doubles in [-1, 1): a counter-based integer hash (splitmix64 finaliser) of (salt, index).  Pure integer
+    arithmetic modulo 2^64, so every platform reproduces the same values bit for bit."""
+    with np.errstate(over="ignore"):
+        x = np.arange(n, dtype=np.uint64) + np.uint64((salt * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    u = (x >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))       # [0, 1)
+    return torch.from_numpy(2.0 * u - 1.0)
+
+
+def init_like_state_dict(s: NetShape, salt: int = 0) -> Dict[str, torch.Tensor]:
+    """Closed-form weights with the *statistics* of the reference's default initialisation (PyTorch
+    defaults, kaiming_uniform(a=sqrt 5) => U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for conv / linear weights and biases),
+    drawn from a counter-based hash instead of an RNG so that both sides of a parity test rebuild the 214 MB of the
+    40x256 model from (shape, salt) alone.  BatchNorm gets a non-trivial affine (gamma 1 +- 0.1, beta +- 0.05) and
+    running statistics (mean +- 0.1, var 1 +- 0.25).
+
+    Unlike ``synth_state_dict`` (sums of two sines of the flat index: every weight matrix is numerically rank 4, and a
+    40-block tower of them amplifies fp32 rounding into 50 % gradient differences between fp32 and fp64 runs of the
+    reference itself), these weights are full rank and the network is as well conditioned as a freshly initialised one."""
+    out: Dict[str, torch.Tensor] = {}
+    for k_idx, (key, shape) in enumerate(state_dict_spec(s).items()):
+        n = int(np.prod(shape)) if shape else 1
+        if key.endswith("num_batches_tracked"):
+            out[key] = torch.zeros((), dtype=torch.int64)
+            continue
+        u = _hash_uniform(n, 1000 * salt + k_idx + 1)
+        if key.endswith("running_var"):
+            v = 1.0 + 0.25 * u
+        elif key.endswith("running_mean"):
+            v = 0.1 * u
+        elif ".bn" in key or key.startswith(("input_bn", "policy_bn1")):
+            v = (1.0 + 0.1 * u) if key.endswith("weight") else 0.05 * u
+        elif key.endswith("bias"):
+            w_shape = state_dict_spec(s)[key[:-4] + "weight"]
+            v = u / math.sqrt(int(np.prod(w_shape[1:])))
+        else:
+            v = u / math.sqrt(int(np.prod(shape[1:])))
+        out[key] = v.to(torch.float32).reshape(shape)
+    return out
+
+
+def closed_form_cotangents(batch: int) -> tuple:
+    """Deterministic output cotangents (policy (B,9,9,139), value (B,3), score (B,1)) for gradient fixtures: nothing to
+    store, both sides rebuild them."""
+    cp = _hash_uniform(batch * N_ACTIONS, 7001).to(torch.float32).reshape(batch, 9, 9, N_MOVE_TYPES)
+    cv = _hash_uniform(batch * 3, 7002).to(torch.float32).reshape(batch, 3)
+    cs = _hash_uniform(batch, 7003).to(torch.float32).reshape(batch, 1)
+    return cp, cv, cs
+
+
 def closed_form_fill(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Generic closed-form weights for any state_dict (used for the scalar-contract models,
     whose policy_fc is too large to commit): float tensors get amp*sin(.), norm scales ~1,
@@ -219,6 +272,30 @@ def seresnet_forward(sd, obs: torch.Tensor, num_blocks: int, train: bool,
     s = torch.relu(F.linear(pool, sd["score_fc1.weight"], sd["score_fc1.bias"]))
     s = F.linear(s, sd["score_fc2.weight"], sd["score_fc2.bias"])
     return policy, v, s
+
+
+def relu_margin(sd, obs: torch.Tensor, num_blocks: int) -> float:
+    """Smallest non-zero |ReLU input| of a train-mode fp64 forward: how far the batch is from a ReLU knife edge.  Two
+    fp32 implementations agree on every ReLU mask (and hence on gradients to ~1e-6) when this is well above their
+    rounding noise (~1e-6 for O(1) activations); fixtures and smoke() pick their batch by it."""
+    seen = {"min": float("inf")}
+    real = torch.relu
+
+    def rec(x):
+        a = x.detach().abs()
+        a = a[a > 0]
+        if a.numel():
+            seen["min"] = min(seen["min"], float(a.min()))
+        return real(x)
+
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    torch.relu = rec
+    try:
+        with torch.no_grad():
+            seresnet_forward(sd64, obs.double(), num_blocks, train=True, momentum=0.0)
+    finally:
+        torch.relu = real
+    return seen["min"]
 
 
 def seresnet_policy_bf16_storage(sd, obs: torch.Tensor, num_blocks: int, train: bool) -> torch.Tensor:

@@ -73,84 +73,150 @@ def test_running_stats_update_like_reference(golden):
             assert int(got[k]) == int(ref[k]) == 1, k
 
 
-# Gradient tolerances of the mid-size fp32 models.  The fixture batch is 2 boards with batch-statistics BatchNorm, and
-# among its ~290k ReLU inputs a few lie within 1e-5 of zero -- inside the fp32 rounding noise of a K=2304 convolution
-# (measured: changing only the summation order of the conv, 4 K-chunks instead of 2, moves y by 1e-5 relative, flips
-# ONE output-ReLU mask element of block 2 and with it moves gradient norms by up to 1.1 % and single elements by up to
-# 5.5 %; tools/debug_kc.py reproduces it).  The reference's own CPU fp32 result sits on the same knife edge, so these
-# bounds admit a couple of such flips; formula-level parity is held to 5e-3 by the tiny-model tests above and to
-# 2e-5 by the per-kernel tests in test_hip_kernels.py.
-GRAD_NORM_TOL = 2e-2
-GRAD_ELEM_TOL = 8e-2
+def _cots(B):
+    return tuple(t.to(DEV) for t in orc.closed_form_cotangents(B))
+
+
+def _backward(o, B):
+    cp, cv, cs = _cots(B)
+    ((o.policy_logits * cp).sum() / B + (o.value_logits * cv).sum() + (o.score_lead * cs).sum()).backward()
+
+
+def _grad_errors(g, tag, m):
+    """(worst relative norm error, worst relative L2 over the stored tensors / slices, their median) against the
+    reference's fp64 gradients."""
+    names = list(g.np(tag + "grad_names"))
+    norms = dict(zip(names, g.np(tag + "grad_norms64")))
+    grads = dict((n, p.grad) for n, p in m.named_parameters())
+    worst_n, l2 = 0.0, []
+    for n in names:
+        assert grads[n] is not None, n
+        worst_n = max(worst_n, abs(float(grads[n].double().norm()) - norms[n]) / (norms[n] + 1e-30))
+        for key, got in ((f"{tag}grad64.{n}", grads[n]), (f"{tag}grad64.{n}[:2]", grads[n][:2])):
+            if key in g:
+                ref = g[key].double()
+                l2.append(float((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)))
+    l2.sort()
+    return worst_n, l2[-1], l2[len(l2) // 2]
+
+
+def _build(shape, amp):
+    m = SEResNetModel(SEResNetParams(**shape.__dict__))
+    m.load_state_dict(orc.init_like_state_dict(shape), strict=True)
+    m.to(DEV)
+    if amp:
+        m.configure_amp(True, torch.bfloat16, "cuda")
+    freeze_bn(m)
+    return m
+
+
+# fp32 mode against the reference (g2_model_mid16: 16 boards = 8 randn + 8 board-like, init-like closed-form weights,
+# batch picked among 200 seeds so that no ReLU input lies within 2.4e-6 of zero -- the reference's own fp32 gradients
+# are then 1.2e-6 from its fp64 ones, i.e. no mask element sits on a knife edge).  Gradients are compared with the fp64
+# run of the reference: every tensor's norm, every tensor of <= 20 000 elements in full, two output channels of every
+# 3x3 convolution.  Measured on MI355X: norms 9.4e-7 / 6.0e-7, relative L2 worst 2.3e-6 / 2.9e-6 (6x128 / 3x256).
+MID_GRAD_TOL = 5e-5
 
 
 @pytest.mark.parametrize("tag,shape", [("s6x128.", orc.NetShape(6, 128)), ("s3x256.", orc.NetShape(3, 256))])
 def test_mid_models_fp32(golden, tag, shape):
-    g = golden("g2_model_mid")
-    m = SEResNetModel(SEResNetParams(**shape.__dict__))
-    m.load_state_dict(orc.synth_state_dict(shape), strict=True)
-    m.to(DEV)
+    g = golden("g2_model_mid16")
+    m = _build(shape, False)
     obs = g[tag + "obs"].to(DEV)
+    B = obs.shape[0]
     m.eval()
     with torch.no_grad():
         o = m(obs)
     assert torch.allclose(o.policy_logits.cpu(), g[tag + "eval.policy"], rtol=1e-4, atol=5e-5)
     assert torch.allclose(o.value_logits.cpu(), g[tag + "eval.value"], rtol=1e-4, atol=5e-5)
-    m.train(); freeze_bn(m)
+    assert torch.allclose(o.score_lead.cpu(), g[tag + "eval.score"], rtol=1e-4, atol=5e-5)
+    m.train()
     o = m(obs)
-    assert torch.allclose(o.policy_logits.cpu(), g[tag + "train.policy"], rtol=2e-4, atol=1e-4)
-    assert torch.allclose(o.score_lead.cpu(), g[tag + "train.score"], rtol=2e-4, atol=1e-4)
+    assert torch.allclose(o.policy_logits.cpu(), g[tag + "train.policy"], rtol=1e-4, atol=5e-5)
+    assert torch.allclose(o.value_logits.cpu(), g[tag + "train.value"], rtol=1e-4, atol=5e-5)
+    assert torch.allclose(o.score_lead.cpu(), g[tag + "train.score"], rtol=1e-4, atol=5e-5)
+    _backward(o, B)
+    worst_n, worst_l2, med_l2 = _grad_errors(g, tag, m)
+    print(f"{tag} fp32 gradients vs reference fp64: norm {worst_n:.2e}, rel L2 worst {worst_l2:.2e} median {med_l2:.2e}")
+    assert worst_n <= MID_GRAD_TOL and worst_l2 <= MID_GRAD_TOL, (worst_n, worst_l2)
+
+
+def test_headline_model_fp32(golden):
+    """se_resnet 40x256 (BASELINE configs[2], keisei-katago.toml:15-23) in the fp32 mode against the reference on 16
+    boards: outputs at the stated rtol 1e-4 / atol 5e-5 (the reference's own fp32 forward is 7.2e-6 from its fp64
+    forward), gradients of all 576 tensors against the reference's fp64 run.  27 M ReLU inputs: a few lie within fp32
+    rounding of zero, two fp32 implementations take different sides there, and the reference's own fp32 gradients are
+    up to 8.2e-3 (median 2.3e-3) from its fp64 gradients (recorded per tensor in the fixture).  The HIP path is held
+    to that yardstick: worst <= 2.5 x the reference's worst, median <= 2.5 x its median, norms within 1 %."""
+    g = golden("g2_model_full")
+    shape = orc.NetShape()
+    m = _build(shape, False)
+    obs = g["obs"].to(DEV)
     B = obs.shape[0]
-    loss = ((o.policy_logits * g[tag + "cot.policy"].to(DEV)).sum() / B + (o.value_logits * g[tag + "cot.value"].to(DEV)).sum()
-            + (o.score_lead * g[tag + "cot.score"].to(DEV)).sum())
-    loss.backward()
-    names = list(g.np(tag + "grad_names"))
-    norms = dict(zip(names, g.np(tag + "grad_norms")))
-    grads = dict((n, p.grad) for n, p in m.named_parameters())
-    for n in names:
-        got = float(grads[n].double().norm())
-        assert abs(got - norms[n]) <= GRAD_NORM_TOL * norms[n] + 1e-6, (n, got, norms[n])
-    for n in ("input_bn.weight", "blocks.0.bn1.bias", "blocks.1.se_fc1.weight", "policy_conv1.weight",
-              "value_fc2.weight", "score_fc2.bias"):
-        ref = g[f"{tag}grad.{n}"]
-        err = float((grads[n].cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-9)
-        assert err < GRAD_ELEM_TOL, (n, err)
-    for n in ("blocks.0.conv1.weight", "input_conv.weight"):
-        ref = g[f"{tag}grad.{n}[:4]"]
-        err = float((grads[n][:4].cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-9)
-        assert err < GRAD_ELEM_TOL, (n, err)
+    m.eval()
+    with torch.no_grad():
+        o = m(obs)
+    for got, key in ((o.policy_logits, "eval.policy"), (o.value_logits, "eval.value"), (o.score_lead, "eval.score")):
+        assert torch.allclose(got.cpu(), g[key], rtol=1e-4, atol=5e-5), key
+    m.train()
+    o = m(obs)
+    for got, key in ((o.policy_logits, "train.policy"), (o.value_logits, "train.value"), (o.score_lead, "train.score")):
+        d = float((got.detach().cpu() - g[key]).abs().max())
+        print(f"40x256 fp32 {key}: max abs diff {d:.2e} (|ref|max {float(g[key].abs().max()):.3f})")
+        assert torch.allclose(got.detach().cpu(), g[key], rtol=1e-4, atol=5e-5), key
+    _backward(o, B)
+    worst_n, worst_l2, med_l2 = _grad_errors(g, "", m)
+    ref = g.np("grad_rel32v64")
+    print(f"40x256 fp32 gradients vs reference fp64: norm {worst_n:.2e}, rel L2 worst {worst_l2:.2e} median {med_l2:.2e} "
+          f"(reference fp32 vs fp64: worst {ref.max():.2e} median {float(sorted(ref)[len(ref) // 2]):.2e})")
+    assert worst_n <= 1e-2
+    assert worst_l2 <= 2.5 * float(ref.max()) and med_l2 <= 2.5 * float(sorted(ref)[len(ref) // 2])
 
 
-@pytest.mark.parametrize("tag,shape", [("s6x128.", orc.NetShape(6, 128)), ("s3x256.", orc.NetShape(3, 256))])
-def test_mid_models_bf16_bound(golden, tag, shape):
-    """bf16 mode (bf16 activations + bf16 MFMA, fp32 accumulate).  Stated tolerance: within 5 % of
-    |logit|max of the CPU emulation that rounds to bf16 at the same storage points
-    (oracle.seresnet_policy_bf16_storage), and no further from the fp32 reference than that
-    emulation is (x1.25 + 1 %).  The distance of bf16 storage from fp32 is inherent and
-    input-dependent (SURVEY 8d measured 1-5 % for the reference's own CPU bf16 autocast)."""
-    g = golden("g2_model_mid")
-    sd = orc.synth_state_dict(shape)
-    m = SEResNetModel(SEResNetParams(**shape.__dict__))
-    m.load_state_dict(sd, strict=True)
-    m.to(DEV)
-    m.configure_amp(True, torch.bfloat16, "cuda")
-    obs = g[tag + "obs"]
-    freeze_bn(m)
+# bf16 mode (the throughput mode the bench runs): bf16 activations and conv operands, fp32 accumulation / statistics /
+# FC layers.  The comparison is against the reference's fp32 outputs and fp64 gradients, so it includes the inherent
+# distance of bf16 storage.  Yardstick: the reference's OWN bf16 mode (CPU autocast, katago_ppo.py:23-24), recorded in
+# the fixtures -- distance from its fp64 run (policy eval / train as a fraction of |logit|max; gradient relative L2
+# worst / median; worst norm ratio):
+#     6x128   0.002 / 0.021;  0.295 / 0.152;  0.057        this build, measured on MI355X:  0.0056 / 0.0169;  0.369 / 0.146;  0.169
+#     3x256   0.001 / 0.011;  0.166 / 0.121;  0.049                                        0.0036 / 0.0099;  0.170 / 0.104;  0.050
+#     40x256  0.005 / 0.037;  0.682 / 0.300;  0.195                                        0.0123 / 0.0387;  0.468 / 0.282;  0.208
+# i.e. the same class in train mode and for gradients; in eval mode 2.5-3x further (the residual stream x is STORED in
+# bf16 here, the reference keeps it in fp32 and only casts conv inputs).  The bounds below are those measurements,
+# frozen with ~1.4x headroom (the kernels are deterministic; the headroom is for future kernel changes).
+BF16_BOUNDS = {
+    "s6x128.": dict(eval=0.009, train=0.030, ratio=0.25, l2=0.50, med=0.20),
+    "s3x256.": dict(eval=0.006, train=0.020, ratio=0.10, l2=0.25, med=0.15),
+    "": dict(eval=0.020, train=0.060, ratio=0.30, l2=0.65, med=0.38),
+}
+
+
+@pytest.mark.parametrize("tag,shape,fixture", [("s6x128.", orc.NetShape(6, 128), "g2_model_mid16"),
+                                               ("s3x256.", orc.NetShape(3, 256), "g2_model_mid16"),
+                                               ("", orc.NetShape(), "g2_model_full")])
+def test_models_bf16_bound(golden, tag, shape, fixture):
+    g = golden(fixture)
+    bound = BF16_BOUNDS[tag]
+    m = _build(shape, True)
+    obs = g[tag + "obs"].to(DEV)
+    B = obs.shape[0]
     for train in (False, True):
         m.train(train)
         with torch.no_grad():
-            got = m(obs.to(DEV)).policy_logits.float().cpu()
+            o = m(obs)
         ref = g[tag + ("train.policy" if train else "eval.policy")]
-        emu = orc.seresnet_policy_bf16_storage(sd, obs, shape.num_blocks, train)
-        mx = float(ref.abs().max())
-        e_hip, e_emu, e_he = (float((a - b).abs().max()) / mx for a, b in ((got, ref), (emu, ref), (got, emu)))
-        print(f"{tag} train={train}: hip-vs-fp32 {e_hip:.4f}  emulation-vs-fp32 {e_emu:.4f}  hip-vs-emulation {e_he:.4f}")
-        assert e_he < 0.05
-        assert e_hip < 1.25 * e_emu + 0.01
+        e = float((o.policy_logits.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+        refv = g[tag + ("train.value" if train else "eval.value")]
+        ev = float((o.value_logits.float().cpu() - refv).abs().max())
+        print(f"{tag or '40x256.'} bf16 train={train}: policy max diff / |logit|max {e:.4f}, value logits max diff {ev:.4f}")
+        assert e <= bound["train" if train else "eval"]
     m.train()
-    o = m(obs.to(DEV))
-    (o.policy_logits.sum() + o.value_logits.sum() + o.score_lead.sum()).backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    o = m(obs)
+    _backward(o, B)
+    worst_n, worst_l2, med_l2 = _grad_errors(g, tag, m)
+    print(f"{tag or '40x256.'} bf16 gradients vs reference fp64: norm ratio off by {worst_n:.3f}, rel L2 worst {worst_l2:.3f} "
+          f"median {med_l2:.3f}")
+    assert worst_n <= bound["ratio"] and worst_l2 <= bound["l2"] and med_l2 <= bound["med"]
 
 
 def test_standalone_block_matches_reference(golden):

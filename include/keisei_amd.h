@@ -178,7 +178,8 @@ int ka_rows_bn_bwd(float* dr, const float* in, const float* p0, const float* p1,
  *   legal actions -- per-sample terms AND dL/dlogits in one pass over the logits.  Per-sample inputs (legal,
  *   actions, old_lp, adv) are rows of the epoch dataset addressed through idx (NULL = identity).
  *   w_policy = lambda_policy/B, w_entropy = entropy_coeff/B; gscale = optional device loss scale (GradScaler).
- *   flags[0] |= NaN in raw logits, flags[1] |= a sample without legal action (the reference's two guards).
+ *   flags[0] |= NaN in raw logits, flags[1] |= 1: a sample without legal action (the reference's two guards,
+ *   katago_ppo.py:861-871), flags[1] |= 2: an action id outside [0, A) (the reference's gather traps on the device).
  *   legal: bool rows (S,A) when legal_words == 0, else packed rows (S,legal_words) uint32 with bit j of word w = action
  *   32 w + j and legal_words == ka_mask_words(A) -- the device rollout store's column (ka_rollout_append).
  * ka_value_loss: W/D/L cross-entropy (ignore_index -1, all-ignored -> 0), score MSE, their gradients, the mean

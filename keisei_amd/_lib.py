@@ -126,6 +126,31 @@ def available() -> bool:
         return False
 
 
+# KA_CHECK_ARGS=1 (the GPU test-suite sets it): every tensor handed to the C ABI must live on a GPU and be contiguous,
+# and all tensors of one call must share one device, which must be the CURRENT device (launches go to the current
+# device's stream).  The C ABI itself sees only raw pointers, so this is the last place where a host tensor, a strided
+# view or a tensor of another card can be caught instead of being misread.  Off by default: ~1000 launches per step.
+_CHECK = os.environ.get("KA_CHECK_ARGS", "0") == "1"
+
+
+def _check_tensors(name: str, args) -> None:
+    dev = None
+    for i, a in enumerate(args):
+        if not isinstance(a, torch.Tensor):
+            continue
+        if not a.is_cuda:
+            raise KeiseiHipError(f"{name}: argument {i} is a {a.device} tensor (the C ABI takes device pointers)")
+        if not a.is_contiguous():
+            raise KeiseiHipError(f"{name}: argument {i} is not contiguous (shape {tuple(a.shape)}, strides {a.stride()})")
+        if dev is None:
+            dev = a.device
+        elif a.device != dev:
+            raise KeiseiHipError(f"{name}: tensors on different devices ({dev} and {a.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise KeiseiHipError(f"{name}: tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()} "
+                             "(wrap the call in torch.cuda.device(tensor.device))")
+
+
 def _ptr(x):
     if x is None:
         return None
@@ -145,7 +170,19 @@ def call(name: str, *args) -> None:
     if len(args) != len(sig):
         raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
     conv = [(_ptr(a) if c == "p" else a) for c, a in zip(sig, args)]
-    rc = getattr(lib, name)(*conv)
+    # launches go to the CURRENT device (and set per-device kernel attributes there): a model that lives on another
+    # card than the current one (the reference places league opponents on a second GPU, katago_loop.py:371-422) is
+    # launched under that card's device guard
+    dev = next((a.device.index for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            if _CHECK:
+                _check_tensors(name, args)
+            rc = getattr(lib, name)(*conv)
+    else:
+        if _CHECK:
+            _check_tensors(name, args)
+        rc = getattr(lib, name)(*conv)
     if rc != 0:
         raise KeiseiHipError(f"{name} failed ({rc}): {lib.ka_last_error().decode()}")
 

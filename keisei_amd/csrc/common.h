@@ -26,6 +26,23 @@ void ka_set_error(const char* fmt, ...);
 int ka_check_launch(const char* what);
 #define KA_REQUIRE(cond, ...) do { if (!(cond)) { ka_set_error(__VA_ARGS__); return KA_ERR_ARG; } } while (0)
 
+// Kernels that need more than 64 KiB of dynamic LDS: hipFuncAttributeMaxDynamicSharedMemorySize is a per-device
+// property of the function, so it is set once per (kernel instantiation, device) -- `done` is that instantiation's
+// bit mask of devices already configured (the only state the library keeps; written once per device, thread-safe).
+#include <atomic>
+inline int ka_big_lds_once(const void* func, std::atomic<unsigned long long>& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { ka_set_error("%s: hipGetDevice failed", what); return KA_ERR_HIP; }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return KA_OK;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        ka_set_error("%s: hipFuncSetAttribute failed on device %d", what, dev);
+        return KA_ERR_HIP;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return KA_OK;
+}
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950.

@@ -42,7 +42,9 @@ constexpr int kNB = 2;                       // boards per workgroup in the pair
 // every tap -- conflict-free ds_read_b128, where the natural 11-wide image costs a 2-way conflict on every read.
 constexpr int kPW = 17;                      // squares per padded board row
 constexpr int kBoardStride = 193;            // squares between the two boards
-constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380 (two boards); a single-board image is 11 * kPW = 187
+constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380 (two boards)
+// single-board image: the squares any tap of any board square can address are 0 .. 10 * kPW + 10
+constexpr int kImgSquares1 = 10 * kPW + 11;            // 181
 __device__ __forceinline__ int lds_square(int b, int p) { return b * kBoardStride + (p / 9 + 1) * kPW + (p % 9) + 1; }
 constexpr int kMTW = 6;                      // row tiles per wave: one board, 81 squares padded to 96 rows
 
@@ -86,7 +88,7 @@ struct ConvArgs {
     unsigned long long* stamps;   // diagnostic only: [workgroup][8] s_memtime at phase boundaries (null in production)
 };
 
-unsigned long long* g_stamps = nullptr;
+std::atomic<unsigned long long*> g_stamps{nullptr};   // diagnostic only (ka_debug_conv_stamps); null in production
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -113,7 +115,7 @@ template <typename T, int NTW, int WM>
 __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     constexpr int kThreads = 256 * WM;
     constexpr int kRows = WM * KA_BOARD;         // staged squares
-    constexpr int kImgSquares = WM == 2 ? kLdsSquares : 11 * kPW;
+    constexpr int kImgSquares = WM == 2 ? kLdsSquares : kImgSquares1;
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int ESZ = E::kSize, P16 = E::kPer16, CPK = 4 * P16;   // channels per k-step
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     for (int i = tid; i < kImgSquares * cpr; i += kThreads) {
         const int idx = i / cpr, j = i - idx * cpr;
         const int pp = idx >= kBoardStride ? idx - kBoardStride : idx, yy = pp / kPW, xx = pp - yy * kPW;
-        const bool interior = yy >= 1 && yy <= 9 && xx >= 1 && xx <= 9 && pp < 11 * kPW;
+        const bool interior = yy >= 1 && yy <= 9 && xx >= 1 && xx <= 9;
         if (!interior) *reinterpret_cast<uint4*>(smem + idx * stride + j * 16) = uint4{0, 0, 0, 0};
     }
 
@@ -550,17 +552,10 @@ template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
-    const size_t lds = (size_t)(WM == 2 ? kLdsSquares : 11 * kPW) * (a.KC * E::kSize + 32);
+    const size_t lds = (size_t)(WM == 2 ? kLdsSquares : kImgSquares1) * (a.KC * E::kSize + 32);
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            ka_set_error("conv3x3: hipFuncSetAttribute failed");
-            return KA_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation: devices already configured
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM>), attr_done, "conv3x3")) return rc;
     dim3 grid((a.B + WM - 1) / WM, (a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM>), grid, dim3(256 * WM), lds, st, a);
     return ka_check_launch("conv3x3");
@@ -575,7 +570,7 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
     int wm = 1;
     if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }   // experiments
-    const int img_squares = wm == 2 ? kLdsSquares : 11 * kPW;
+    const int img_squares = wm == 2 ? kLdsSquares : kImgSquares1;
     // LDS chunk: the largest divisor of Cin (in k-steps) whose 16-byte pieces tile the 256 staging threads of a board
     // and whose image fits: squares x (KC*size + 32) <= 150 KiB
     int kc = 0;
@@ -619,7 +614,7 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
                               const float* in_shift, const float* in_bias, int relu, float* bsum, float* sqpart,
                               int B, int Cin, int Cout, int dtype, void* stream) {
     ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu,
-               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, g_stamps};
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, g_stamps.load()};
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -641,13 +636,13 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
     KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused: bf16 only");
     KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused: epilogue tensors");
     ConvArgs a{in, wpack, out, k, k + Cin, nullptr, bsum, nullptr, B, Cin, Cout, 0, 0,
-               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps};
+               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps.load()};
     return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
 }
 
 // diagnostic: stamps != null makes every conv3x3 workgroup record 4 s_memtime values (100 MHz ticks are NOT used:
 // s_memtime counts shader clocks); pass null to switch off
-extern "C" int ka_debug_conv_stamps(unsigned long long* stamps) { g_stamps = stamps; return KA_OK; }
+extern "C" int ka_debug_conv_stamps(unsigned long long* stamps) { g_stamps.store(stamps); return KA_OK; }
 
 extern "C" int ka_conv3x3_sqpart_rows(int B) { return B; }
 

@@ -483,15 +483,8 @@ extern "C" int ka_fc_chain(const float* x, const float* in_scale, const float* i
     const int T1 = H / 16, ksplit = T1 >= 8 ? 1 : 8 / T1;
     const size_t lds = (size_t)(16 * (K1 + 4) + 16 * (H + 4) + (ksplit > 1 ? ksplit * 16 * H : 0)) * sizeof(float);
     KA_REQUIRE(lds <= 160 * 1024, "fc_chain: LDS %zu B", lds);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) {
-            ka_set_error("fc_chain: hipFuncSetAttribute failed");
-            return KA_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&fc_chain_kernel), attr_done, "fc_chain")) return rc;
     ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2};
     hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("fc_chain");

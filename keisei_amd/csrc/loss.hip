@@ -30,7 +30,7 @@ struct PolicyArgs {
     float* new_lp;            // (B)
     float* rowloss;           // (B)  -min(surr1,surr2)
     float* rowent;            // (B)
-    int* flags;               // [0]=NaN in logits, [1]=zero legal actions
+    int* flags;               // [0]=NaN in logits, [1] bit 0 = zero legal actions, bit 1 = action id outside [0, A)
     const float* gscale;      // device scalar: loss scale (GradScaler) or null (=1)
     float clip_eps, w_policy, w_entropy;   // w_* already divided by B
     int A, legal_words;
@@ -92,7 +92,11 @@ __global__ __launch_bounds__(kPolThreads) void policy_loss_kernel(PolicyArgs a) 
     t = block_reduce(t, red, false);
     const float lse = mx + logf(s);
     const float H = lse - t / s;
-    const long long act = a.actions[src];
+    // an action id outside [0, A) (the reference's gather would trap on the device) is flagged and read as action 0
+    const long long act_raw = a.actions[src];
+    const bool act_ok = act_raw >= 0 && act_raw < a.A;
+    if (!act_ok && tid == 0) atomicOr(&a.flags[1], 2);
+    const long long act = act_ok ? act_raw : 0;
     const float nlp = msk[act] ? row[act] - lse : -INFINITY;
     const float adv = a.adv[src];
     const float ratio = expf(nlp - a.old_lp[src]);

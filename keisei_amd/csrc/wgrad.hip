@@ -399,15 +399,8 @@ template <typename T, int TN, bool FUSED>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NBUF = (sizeof(T) == 2 && TN == 128) ? 3 : (sizeof(T) == 2 ? 2 : 1);   // as in the kernel
     const size_t lds = (size_t)NBUF * (WG<T, TN>::KROWS * WG<T, TN>::SY + 11 * WG<T, TN>::PW * WG<T, TN>::SX);
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TN, FUSED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            ka_set_error("wgrad: hipFuncSetAttribute failed");
-            return KA_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation: devices already configured
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_kernel<T, TN, FUSED>), attr_done, "wgrad")) return rc;
     hipLaunchKernelGGL((wgrad_kernel<T, TN, FUSED>), grid, dim3(TN * 4), lds, st, a);
     return ka_check_launch("wgrad");
 }

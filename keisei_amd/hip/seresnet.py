@@ -48,20 +48,18 @@ _FC_SPLITS = int(os.environ.get("KA_FC_SPLITS", "256"))
 class SEResNetEngine:
     def __init__(self, model: nn.Module) -> None:
         self.model = model
-        self._packs: Dict[tuple, tuple] = {}
-        self._pack_key = None
+        self._pack_sets: Dict[tuple, dict] = {}     # (dtype, device, parameter storage) -> pack buffers + job table
         self._scratch: Optional[torch.Tensor] = None
         self._redws: Optional[torch.Tensor] = None
         self._side = None
         self._pack_tkey = None
         self._graphs = {}             # (batch, dtype, parameter storage) -> captured eval forward (rollout inference path)
         self._graph_lock = threading.Lock()
-        self._pack_table = None
-        self._pack_max = 0
         self._wslab: Optional[torch.Tensor] = None
         self._fc_jobs = None          # open list of deferred FC weight-gradient jobs during a backward pass
         self._row_ring = None
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
+        self._evalc_sets = {}
         self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
         self._in_forward = False
@@ -105,8 +103,6 @@ class SEResNetEngine:
 
     def _wgrad_launch(self, side, main, inputs, *args) -> None:
         """ka_conv3x3_wgrad on the side stream, ordered after everything already queued on the main stream."""
-        if os.environ.get("KA_DEBUG_SKIP_WGRAD"):        # timing experiments only: gradients are garbage
-            return
         if side is None:
             self._timed("wgrad", "ka_conv3x3_wgrad", *args, _lib.stream_ptr(main.device))
             return
@@ -131,17 +127,19 @@ class SEResNetEngine:
             yield f"blocks.{i}.conv2", blk.conv2
 
     def _get_packs(self, T: torch.dtype, device) -> Dict[str, tuple]:
-        """fragment-ordered weight copies: name -> (forward pack, dgrad pack | None)."""
+        """fragment-ordered weight copies: name -> (forward pack, dgrad pack | None).
+
+        One set of pack buffers (plus its device-side job table) per (dtype, device, parameter storage), kept for the
+        life of the engine: a captured eval graph reads the buffers it was captured with, so alternating dtypes (an fp32
+        eval between two bf16 ones) must refresh each set in place and never free or reallocate one."""
         convs = list(self._conv_layers())
-        key = (T, self.weights_epoch, sum(c.weight._version for _, c in convs), convs[0][1].weight.data_ptr())
-        if key == self._pack_key:
-            return self._packs
-        code, st = _lib.dtype_code(T), _lib.stream_ptr(device)
-        cpk = 32 if T == torch.bfloat16 else 16
-        # pack buffers and the device-side job table are built once per (dtype, parameter storage); after an optimiser
-        # step only the single multi-layer pack launch is repeated
         tkey = (T, str(device), tuple(c.weight.data_ptr() for _, c in convs))
-        if tkey != self._pack_tkey:
+        ent = self._pack_sets.get(tkey)
+        if ent is None:
+            if len(self._pack_sets) >= 4:            # parameters were re-allocated repeatedly: drop stale sets AND the
+                self._pack_sets.clear()              # graphs that read them
+                self._graphs.clear()
+            cpk = 32 if T == torch.bfloat16 else 16
             packs, jobs, mx = {}, [], 0
             for name, conv in convs:
                 w = conv.weight
@@ -156,13 +154,16 @@ class SEResNetEngine:
                     dg = torch.empty(nd * 16, dtype=torch.uint8, device=device)
                     jobs.append([w.data_ptr(), dg.data_ptr(), co, ci, ci, co, 1, 0]); mx = max(mx, nd)
                 packs[name] = (fwd, dg)
-            self._packs = packs
-            self._pack_table = torch.tensor(jobs, dtype=torch.int64).to(device)
-            self._pack_max, self._pack_tkey = mx, tkey
-        _call("ka_pack_conv3x3_multi", self._pack_table, self._pack_table.shape[0], self._pack_max, code, st)
-        packs = self._packs
-        self._packs, self._pack_key = packs, key
-        return packs
+            ent = {"packs": packs, "table": torch.tensor(jobs, dtype=torch.int64).to(device), "max": mx, "key": None}
+            self._pack_sets[tkey] = ent
+        self._pack_tkey = tkey
+        key = (self.weights_epoch, sum(c.weight._version for _, c in convs))
+        if key != ent["key"]:
+            # after an optimiser step only the single multi-layer pack launch is repeated
+            _call("ka_pack_conv3x3_multi", ent["table"], ent["table"].shape[0], ent["max"], _lib.dtype_code(T),
+                  _lib.stream_ptr(device))
+            ent["key"] = key
+        return ent["packs"]
 
     def _eval_coeffs_all(self, device, st):
         """Eval-mode scale/shift of EVERY BatchNorm layer from the live running statistics in one launch (the rollout
@@ -175,7 +176,11 @@ class SEResNetEngine:
             return None
         key = (str(device), tuple((b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
                                    float(b.eps)) for b in bns))
-        if self._evalc is None or self._evalc[0] != key:
+        ent = self._evalc_sets.get(key)
+        if ent is None:
+            if len(self._evalc_sets) >= 4:
+                self._evalc_sets.clear()
+                self._graphs.clear()                 # captured graphs read the coefficient buffers of their set
             mx = max(b.num_features for b in bns)
             out = torch.empty(len(bns), 2, mx, device=device)
             rows, views = [], {}
@@ -186,7 +191,9 @@ class SEResNetEngine:
                 rows.append([b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
                              sc.data_ptr(), sh.data_ptr(), C, eps_bits])
                 views[id(b)] = (sc, sh)
-            self._evalc = (key, torch.tensor(rows, dtype=torch.int64).to(device), views, mx, out)
+            ent = (key, torch.tensor(rows, dtype=torch.int64).to(device), views, mx, out)
+            self._evalc_sets[key] = ent
+        self._evalc = ent
         _, table, views, mx, _ = self._evalc
         _call("ka_bn_eval_coeffs_multi", table, table.shape[0], mx, st)
         return views

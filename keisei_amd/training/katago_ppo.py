@@ -384,6 +384,8 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
         self.warmup_entropy = warmup_entropy
         self.current_entropy_coeff = params.lambda_entropy
         self._hip_state: dict[str, Any] = {}
+        self.last_update_path: str | None = None       # "fused" | "generic": which step implementation update() took
+        self._warned_generic: set[str] = set()
 
     # ------------------------------------------------------------------ small helpers
     def get_entropy_coeff(self, epoch: int) -> float:
@@ -581,9 +583,19 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                 advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
         batch = min(self.params.batch_size, total)
 
-        if self._fused_path_available(device, value_adapter):
-            metrics = self._update_fused(data, advantages, total, batch, device, value_adapter, heartbeat_fn)
+        blocker = self._fused_path_blocker(device, value_adapter)
+        if blocker is None:
+            self.last_update_path = "fused"
+            with torch.cuda.device(device):
+                metrics = self._update_fused(data, advantages, total, batch, device, value_adapter, heartbeat_fn)
         else:
+            if device.type == "cuda":
+                if os.environ.get("KEISEI_AMD_STRICT", "0") == "1":
+                    raise _lib.KeiseiHipError(f"update() cannot take the fused HIP step: {blocker} (KEISEI_AMD_STRICT=1)")
+                if blocker not in self._warned_generic:
+                    self._warned_generic.add(blocker)
+                    _log.warning("update() on %s runs the generic torch-op step, not the fused HIP step: %s", device, blocker)
+            self.last_update_path = "generic"
             metrics = self._update_generic(data, advantages, total, batch, device, value_adapter, heartbeat_fn)
         buffer.clear()
         self.forward_model.train()
@@ -687,12 +699,25 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
             eng.notify_weights_updated()
 
     # ---- fused HIP path -----------------------------------------------------------------
-    def _fused_path_available(self, device, value_adapter) -> bool:
-        if device.type != "cuda" or not isinstance(self.model, SEResNetModel):
-            return False
+    def _fused_path_blocker(self, device, value_adapter) -> str | None:
+        """None when ``update()`` can run as the fused HIP step; otherwise the reason it cannot.  The fused step covers
+        what the reference's training loop uses (katago_loop.py:552-559: an SEResNetModel, a plain single-group Adam,
+        and either no adapter or a MultiHeadValueAdapter).  Anything else needs user Python inside the step (a custom
+        adapter's ``compute_value_loss``, another optimiser's ``step``) and runs the reference's statement sequence on
+        torch ops -- explicitly: logged once per reason, visible as ``last_update_path``, and refused when
+        ``KEISEI_AMD_STRICT=1``."""
+        if device.type != "cuda":
+            return "model is not on a GPU"
+        if not isinstance(self.model, SEResNetModel):
+            return f"model is {type(self.model).__name__}, not SEResNetModel"
         if value_adapter is not None and type(value_adapter) is not MultiHeadValueAdapter:
-            return False
-        return self._fused_optimizer_ok()
+            return f"value adapter {type(value_adapter).__name__} is not MultiHeadValueAdapter (its loss is user Python)"
+        if not self._fused_optimizer_ok():
+            return "optimizer is not a plain single-group fp32 torch.optim.Adam (weight decay / amsgrad / param groups)"
+        return None
+
+    def _fused_path_available(self, device, value_adapter) -> bool:
+        return self._fused_path_blocker(device, value_adapter) is None
 
     def _fused_begin(self, dataset: dict, device, value_adapter) -> dict:
         """Device-side state of one fused update: epoch dataset tensors (already on `device`), loss weights,
@@ -766,7 +791,9 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
             self.scaler._scale.copy_(scaler_t[0]); self.scaler._growth_tracker.copy_(scaler_t[1].to(torch.int32))
         if fl[0]:
             raise RuntimeError("NaN in raw policy logits from model forward pass")
-        if fl[1]:
+        if int(fl[1]) & 2:
+            raise RuntimeError("update(): an action index lies outside [0, action_space) (index out of bounds in gather)")
+        if int(fl[1]) & 1:
             raise RuntimeError("Batch contains samples with zero legal actions in update(). "
                                "Check that terminal-state masks are not stored in the buffer.")
         d = max(fs["n_updates"], 1)
@@ -790,10 +817,15 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                 masks = data["legal_masks"].pin_memory().to(device, non_blocking=True)
             torch.cuda.current_stream(device).wait_stream(side)
             words, n_actions = 0, masks.shape[1]
-        dataset = {"obs": obs, "masks": masks, "mask_words": words, "n_actions": n_actions,
-                   "actions": move(data["actions"]), "old_lp": move(data["log_probs"].float()),
-                   "adv": move(advantages.float()), "cats": move(data["value_categories"]),
-                   "score_t": move(data["score_targets"].float())}
+        # the kernels read raw pointers: fix every column's dtype and layout here (a caller's int32 actions or
+        # non-bool masks would otherwise be misread, not rejected)
+        col = lambda t, dt: move(t.to(dt)).contiguous()  # noqa: E731
+        if words == 0 and masks.dtype != torch.bool:
+            masks = masks.to(torch.bool)
+        dataset = {"obs": obs.float().contiguous(), "masks": masks.contiguous(), "mask_words": words, "n_actions": n_actions,
+                   "actions": col(data["actions"], torch.int64), "old_lp": col(data["log_probs"], torch.float32),
+                   "adv": col(advantages, torch.float32), "cats": col(data["value_categories"], torch.int64),
+                   "score_t": col(data["score_targets"], torch.float32)}
         fs = self._fused_begin(dataset, device, value_adapter)
         for _ in range(p.epochs_per_batch):
             perm = torch.randperm(total, device=device)

@@ -1,6 +1,9 @@
 """pytest config: registers the `gpu` marker; GPU tests are skipped when no GPU is visible."""
+import os
 import sys
 from pathlib import Path
+
+os.environ.setdefault("KA_CHECK_ARGS", "1")     # every tensor handed to the C ABI: on the current GPU, contiguous (keisei_amd/_lib.py)
 
 import numpy as np
 import pytest

@@ -312,6 +312,35 @@ def test_eval_graph_matches_eager_and_tracks_weights(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_eval_graphs_survive_alternating_dtypes(monkeypatch):
+    """a captured eval graph reads the weight-pack / BatchNorm-coefficient buffers it was captured with.  A
+    bf16 eval, then an fp32 eval (which builds its own pack set), then bf16 again must replay the first graph against
+    LIVE buffers: packs are kept per (dtype, parameter storage), never freed while the engine lives."""
+    torch.manual_seed(4)
+    m = SEResNetModel(SEResNetParams(num_blocks=2, channels=32, se_reduction=8, global_pool_channels=16,
+                                     policy_channels=8, value_fc_size=32, score_fc_size=16, obs_channels=50)).to(DEV).eval()
+    obs = torch.randn(5, 50, 9, 9, device=DEV)
+
+    def run(bf16, graph):
+        monkeypatch.setenv("KA_EVAL_GRAPH", "1" if graph else "0")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            o = m(obs)
+        return o.policy_logits.float().clone()
+
+    eager16, eager32 = run(True, False), run(False, False)
+    a = run(True, True)             # capture bf16
+    b = run(False, True)            # capture fp32: a second pack set
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]   # recycle whatever the allocator had freed
+    c = run(True, True)             # replay bf16
+    d = run(False, True)            # replay fp32
+    del junk
+    assert torch.equal(a, eager16) and torch.equal(c, eager16)
+    assert torch.equal(b, eager32) and torch.equal(d, eager32)
+    with torch.no_grad():
+        m.blocks[1].conv2.weight.mul_(0.5)
+    assert torch.equal(run(True, True), run(True, False)) and torch.equal(run(False, True), run(False, False))
+
+
 @pytest.mark.parametrize("amp", [False, True])
 @pytest.mark.parametrize("channels,se_red,gpc,pol", [(96, 8, 24, 8), (48, 4, 20, 12)])
 def test_unusual_channel_counts(channels, se_red, gpc, pol, amp):

@@ -115,3 +115,57 @@ def test_select_actions_on_gpu(golden):
     assert torch.allclose(values.cpu(), orc.scalar_value_blended(ref_v, ref_s, 0.1), rtol=1e-4, atol=1e-5)
     with pytest.raises(RuntimeError, match="zero legal actions"):
         algo.select_actions(obs, torch.zeros_like(legal))
+
+
+class _CustomAdapter(MultiHeadValueAdapter):
+    """A user subclass: its compute_value_loss is arbitrary Python, so it cannot be folded into the fused loss kernel."""
+
+
+def test_update_path_is_explicit(golden, monkeypatch, caplog):
+    """Which step implementation update() takes on the GPU is observable and never silent: the
+    reference's production configuration and the no-adapter form take the fused HIP step; a custom adapter, or an
+    optimiser the fused clip+Adam kernel does not implement, takes the generic torch-op step with ONE warning that names
+    the reason, and KEISEI_AMD_STRICT=1 turns that into an error."""
+    from keisei_amd._lib import KeiseiHipError
+
+    for adapter, path in ((MultiHeadValueAdapter(1.5, 0.1, 0.1), "fused"), (None, "fused"), (_CustomAdapter(1.5, 0.1, 0.1), "generic")):
+        g, m, algo, buf = make(golden)
+        replay_perms(monkeypatch, g)
+        with caplog.at_level("WARNING", logger="keisei_amd.training.katago_ppo"):
+            caplog.clear()
+            algo.update(buf, g["next_values"].to(DEV), value_adapter=adapter)
+        assert algo.last_update_path == path, (type(adapter).__name__, algo.last_update_path)
+        warned = [r for r in caplog.records if "generic torch-op step" in r.getMessage()]
+        assert len(warned) == (1 if path == "generic" else 0)
+        if path == "generic":
+            assert "_CustomAdapter" in warned[0].getMessage()
+    # weight decay: not what the fused Adam implements
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    algo.optimizer.param_groups[0]["weight_decay"] = 0.01
+    algo.update(buf, g["next_values"].to(DEV), value_adapter=MultiHeadValueAdapter(1.5, 0.1, 0.1))
+    assert algo.last_update_path == "generic"
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    monkeypatch.setenv("KEISEI_AMD_STRICT", "1")
+    with pytest.raises(KeiseiHipError, match="cannot take the fused HIP step"):
+        algo.update(buf, g["next_values"].to(DEV), value_adapter=_CustomAdapter(1.5, 0.1, 0.1))
+
+
+def test_scalar_adapter_raises_like_the_reference(golden, monkeypatch):
+    """update() hands the adapter returns=None (katago_ppo.py:899), which ScalarValueAdapter rejects (value_adapter.py:57)."""
+    from keisei_amd.training.value_adapter import ScalarValueAdapter
+
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    with pytest.raises(ValueError, match="requires returns"):
+        algo.update(buf, g["next_values"].to(DEV), value_adapter=ScalarValueAdapter())
+
+
+def test_out_of_range_action_is_flagged(golden, monkeypatch):
+    g, m, algo, buf = make(golden)
+    replay_perms(monkeypatch, g)
+    buf._storage["actions"][5] = 11259                   # one past the last action
+    with pytest.raises(RuntimeError, match="outside \\[0, action_space\\)"):
+        algo.update(buf, g["next_values"].to(DEV), value_adapter=MultiHeadValueAdapter(1.5, 0.1, 0.1))
+    assert float(algo._hip_state["step_dev"]) < 4.0      # the offending minibatch and everything after it was vetoed

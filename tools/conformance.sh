@@ -9,6 +9,7 @@ set -u
 REF=${KEISEI_REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
 export PYTHONDONTWRITEBYTECODE=1
+export KEISEI_CONFORMANCE=1
 export PYTHONPATH="$HERE/conformance:$HERE/..${PYTHONPATH:+:$PYTHONPATH}"
 FILES=(
   tests/test_gae.py tests/test_gae_batched.py tests/test_value_adapter.py tests/test_se_resnet.py

@@ -42,6 +42,15 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_id() -> str:
+    """sha256[:16] over the HIP sources the library is built from: ties a counter profile under profiles/ to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "keisei_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_per_sample(nb, C, P, n_params, B, act_bytes):
     """SURVEY 8d contract figure, scaled to the activation storage actually used (4 -> act_bytes)."""
     act = act_bytes * 81 * C * (23 * nb + 10) + 4 * 81 * (100 + 556 + 4 * P)
@@ -176,9 +185,90 @@ def cpu_baseline(shape, seconds_budget=25.0):
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline step {len(times)}: {times[-1]:.1f} s (minibatch {Bc})", file=sys.stderr, flush=True)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(Bc / med, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+    return {"value": round(Bc / med, 2), "unit": "samples/s", "cores": threads, "host_cores_total": os.cpu_count(),
+            "host_cores_available_to_this_process": avail, "kind": "port",
             "sample": f"oracle ppo_minibatch_step (fp32 CPU PyTorch restatement of the reference), se_resnet {nb}x{C}, "
                       f"minibatch {Bc}, median of {len(times)} step(s) (~{sum(times):.0f} s of CPU work) after a probe step"}
+
+
+def run_workload(args, dtype, steps, warmup, device, rank, world, dev_index, events_steps):
+    """Build the model + synthetic epoch, run `warmup` untimed and `steps` timed minibatch steps of the product path
+    (barrier + synchronize on both sides, MAX over ranks), then -- OUTSIDE the timed region -- `events_steps` more steps
+    with a HIP event pair around every conv3x3 / wgrad launch on its launch stream (per-launch durations for the
+    roofline; VERDICT r1: the timed region itself carries no event records)."""
+    from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams
+    from keisei_amd.training.model_registry import build_model
+    from keisei_amd.training.value_adapter import MultiHeadValueAdapter
+
+    nb, C, Rr, G, P, V, S, T, N, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(1234 + rank)
+    model = build_model("se_resnet", dict(num_blocks=nb, channels=C, se_reduction=Rr, global_pool_channels=G,
+                                          policy_channels=P, value_fc_size=V, score_fc_size=S, obs_channels=50))
+    model.to(device)
+    n_params = sum(p.numel() for p in model.parameters())
+    fwd_model = model
+    if world > 1 or dist.is_initialized():
+        fwd_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        fwd_model = torch.nn.parallel.DistributedDataParallel(fwd_model, device_ids=[dev_index], gradient_as_bucket_view=True)
+        model = fwd_model.module
+    pp = KataGoPPOParams(batch_size=B, use_amp=(dtype == "bf16"), lambda_score=0.1, score_blend_alpha=0.1,
+                         compile_mode="default")        # keisei-katago.toml:33-49 (compile_mode accepted, unused)
+    algo = KataGoPPOAlgorithm(pp, model, forward_model=fwd_model)
+    adapter = MultiHeadValueAdapter(pp.lambda_value, pp.lambda_score, pp.score_blend_alpha)
+    assert algo._fused_path_available(device, adapter), "fused HIP path unavailable"
+    total = T * N
+    data = synth_dataset(total, 1234 + rank, device)
+    fs = algo._fused_begin(data, device, adapter)
+    fwd_model.train()
+    perm = torch.randperm(total, device=device)
+    nmb = max(1, total // B)
+
+    def one_step(i):
+        lo = (i % nmb) * B
+        algo._fused_step(fs, perm[lo:lo + B], device)
+
+    print(f"[bench] rank {rank}: {dtype} model + dataset ready, {warmup} warm-up + {steps} timed steps", file=sys.stderr, flush=True)
+    for i in range(warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if os.environ.get("KA_HOST_TIMING"):
+        fs["host_ms"] = {}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(warmup + i)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if fs.get("host_ms") is not None:
+        print(f"[bench] host enqueue ms/step: total {1e3 * t_enq / steps:.1f} " +
+              " ".join(f"{k} {v / steps:.1f}" for k, v in fs["host_ms"].items()), file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    # ---- per-launch durations: a separate pass, after the timed region
+    engine = model._hip_engine
+    events, ev_elapsed = None, None
+    if events_steps > 0:
+        engine.kernel_events = {"conv3x3": [], "wgrad": [], "conv3x3_fwd": []}
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(events_steps):
+            one_step(warmup + steps + i)
+        torch.cuda.synchronize()
+        ev_elapsed = time.perf_counter() - t1
+        events, engine.kernel_events = engine.kernel_events, None
+    metrics = algo._fused_end(fs)
+    return {"elapsed": elapsed, "metrics": metrics, "events": events, "events_elapsed": ev_elapsed, "events_steps": events_steps,
+            "B": B, "n_params": n_params, "algo": algo, "adapter": adapter, "model": model, "shape": (nb, C, Rr, G, P, V, S, T, N),
+            "fs": fs}
 
 
 def main() -> None:
@@ -194,6 +284,10 @@ def main() -> None:
                     help="also time one KataGoPPOAlgorithm.update() from a host rollout buffer (GAE, H2D, gather included)")
     ap.add_argument("--sl-epoch", action="store_true", help="also time one SLTrainer.train_epoch() over synthetic shards")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32-mode (parity numerics) run of the same workload")
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="initialise the process group (RCCL when the backend is nccl) even for one rank, wrap the model as the "
+                         "N > 1 bench does, run ONE step with its collectives, print the collective counts and exit")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,128 +299,119 @@ def main() -> None:
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.dist_dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams
-    from keisei_amd.training.model_registry import build_model
-    from keisei_amd.training.value_adapter import MultiHeadValueAdapter
-    from keisei_amd.hip import seresnet as eng_mod
+    if args.dist_dry_run:
+        counts = {"syncbn": 0, "gradient": 0, "other": 0}
+        real = dist.all_reduce
 
-    nb, C, Rr, G, P, V, S, T, N, B = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
-    torch.manual_seed(1234 + rank)
-    model = build_model("se_resnet", dict(num_blocks=nb, channels=C, se_reduction=Rr, global_pool_channels=G,
-                                          policy_channels=P, value_fc_size=V, score_fc_size=S, obs_channels=50))
-    model.to(device)
-    n_params = sum(p.numel() for p in model.parameters())
-    fwd_model = model
-    if world > 1:
-        fwd_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        fwd_model = torch.nn.parallel.DistributedDataParallel(fwd_model, device_ids=[dev_index], gradient_as_bucket_view=True)
-        model = fwd_model.module
-    pp = KataGoPPOParams(batch_size=B, use_amp=(args.dtype == "bf16"), lambda_score=0.1, score_blend_alpha=0.1,
-                         compile_mode="default")        # keisei-katago.toml:33-49 (compile_mode accepted, unused)
-    algo = KataGoPPOAlgorithm(pp, model, forward_model=fwd_model)
-    adapter = MultiHeadValueAdapter(pp.lambda_value, pp.lambda_score, pp.score_blend_alpha)
-    assert algo._fused_path_available(device, adapter), "fused HIP path unavailable"
+        def counting(t, *a, **k):
+            kind = "syncbn" if t.dtype == torch.float64 else ("gradient" if t.dtype == torch.float32 and t.numel() > 1 else "other")
+            counts[kind] += 1
+            return real(t, *a, **k)
+
+        res = run_workload(args, args.dtype, 0, 1, device, rank, world, dev_index, 0)       # allocator / first-launch warm-up
+        dist.all_reduce = counting
+        res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
+        dist.all_reduce = real
+        torch.cuda.synchronize()
+        m = res["algo"]._fused_end(res["fs"])
+        if rank == 0:
+            print(json.dumps({"dist_dry_run": True, "backend": backend, "world": world, "collectives_per_step": counts,
+                              "overlapped_gradient_exchange": res["fs"]["reducer"] is not None,
+                              "train_metrics": {k: round(v, 5) for k, v in m.items()}}), flush=True)
+        dist.destroy_process_group()
+        return
+
+    ev_steps = 0 if args.no_kernel_events else min(args.steps, 4)
+    res = run_workload(args, args.dtype, args.steps, args.warmup, device, rank, world, dev_index, ev_steps)
+    elapsed, metrics, B, n_params = res["elapsed"], res["metrics"], res["B"], res["n_params"]
+    nb, C, Rr, G, P, V, S, T, N = res["shape"]
     total = T * N
-    data = synth_dataset(total, 1234 + rank, device)
-    fs = algo._fused_begin(data, device, adapter)
-    fwd_model.train()
-    perm = torch.randperm(total, device=device)
-    nmb = total // B
-
-    def one_step(i):
-        lo = (i % nmb) * B
-        algo._fused_step(fs, perm[lo:lo + B], device)
-
-    print(f"[bench] rank {rank}: model + dataset ready, running {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    engine = model._hip_engine
-    if not args.no_kernel_events:
-        engine.kernel_events = {"conv3x3": [], "wgrad": [], "conv3x3_fwd": []}
-    torch.cuda.synchronize()
-    if os.environ.get("KA_HOST_TIMING"):
-        fs["host_ms"] = {}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if fs.get("host_ms") is not None:
-        print(f"[bench] host enqueue ms/step: total {1e3 * t_enq / args.steps:.1f} " +
-              " ".join(f"{k} {v / args.steps:.1f}" for k, v in fs["host_ms"].items()), file=sys.stderr, flush=True)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    metrics = algo._fused_end(fs)
-    timed_events = getattr(engine, "kernel_events", None)
-    engine.kernel_events = None                  # the per-launch events belong to the timed region only
     whole = None
     if args.whole_update and rank == 0:
-        whole = whole_update_rate(algo, adapter, T, N, device)
+        whole = whole_update_rate(res["algo"], res["adapter"], T, N, device)
     sl = None
     if args.sl_epoch and rank == 0:
+        from keisei_amd.training.model_registry import build_model
         sl = sl_epoch_rate(lambda: build_model("se_resnet", dict(num_blocks=nb, channels=C, se_reduction=Rr, global_pool_channels=G,
                                                                    policy_channels=P, value_fc_size=V, score_fc_size=S,
                                                                    obs_channels=50)).to(device), 4 * B, B, args.dtype == "bf16")
+    # secondary: the same workload in the fp32 (parity numerics) mode, SURVEY 8d config #3 "use_amp=true AND an fp32 run"
+    fp32 = None
+    if world == 1 and args.dtype == "bf16" and not args.no_fp32:
+        del res["algo"], res["fs"], res["model"]
+        torch.cuda.empty_cache()
+        r32 = run_workload(args, "f32", 3, 1, device, rank, world, dev_index, 0 if args.no_kernel_events else 1)
+        conv_flop = 2.0 * B * 81 * 9 * C * C
+        fp32 = {"samples_per_s": round(B * 3 / r32["elapsed"], 1), "ms_per_step": round(1e3 * r32["elapsed"] / 3, 2), "steps": 3,
+                "warmup": 1, "numerics": "fp32 activations, exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the mode the fp32 parity tests run"}
+        if r32["events"] and r32["events"]["conv3x3"]:
+            ms = [a.elapsed_time(b) for a, b in r32["events"]["conv3x3"]]
+            avg = sum(ms) / len(ms)
+            fp32["conv3x3_avg_launch_ms"] = round(avg, 3)
+            fp32["conv_frac_of_157TF"] = round(conv_flop / (avg * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)
+        del r32
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         act_bytes = 2 if args.dtype == "bf16" else 4
         bps = algorithmic_bytes_per_sample(nb, C, P, n_params, B, act_bytes)
+        bps32 = algorithmic_bytes_per_sample(nb, C, P, n_params, B, 4)
         flops = train_flops_per_sample(nb, C, G, C // Rr, P, V, S)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         roof = None
         extra = {}
-        ev = timed_events
+        ev = res["events"]
         if ev and ev["conv3x3"]:
             conv_ms = [a.elapsed_time(b) for a, b in ev["conv3x3"]]
             conv_flop = 2.0 * B * 81 * 9 * C * C
             avg = sum(conv_ms) / len(conv_ms)
             ach = conv_flop / (avg * 1e-3) / 1e12
-            traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
-            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"))       # the latest round's counter passes
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload -- only when that profile
+            # was taken on THIS build of the kernels (source hash recorded by tools/pmc_traffic.py); otherwise null
+            traffic, traffic_note = None, None
+            pmcs = sorted((ROOT / "profiles").glob("r*_pmc_hbm_traffic.json"))
             pmc = pmcs[-1] if pmcs else None
             if pmc is not None and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
-                recs = [v for k, v in json.loads(pmc.read_text())["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
-                rec = max(recs, key=lambda v: v["launches"]) if recs else None      # the tower instantiation
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
+                prof = json.loads(pmc.read_text())
+                if prof.get("kernel_source_sha16") == kernel_source_id():
+                    recs = [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
+                    rec = max(recs, key=lambda v: v["launches"]) if recs else None      # the tower instantiation
+                    traffic = rec["hbm_bytes_per_launch"] if rec else None
+                    traffic_note = f"{pmc.name} (same kernel sources)"
+                else:
+                    traffic_note = (f"{pmc.name} was collected on kernel sources {prof.get('kernel_source_sha16')}, this build is "
+                                    f"{kernel_source_id()}: not reported")
+            ev_ms_step = 1e3 * res["events_elapsed"] / res["events_steps"]
             roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv; forward + data-gradient launches, the "
                                                "latter with fused BatchNorm-backward passes and concurrent with wgrad on a 2nd stream)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
-                    "flop_per_launch": conv_flop}
+                    "traffic": traffic, "traffic_source": traffic_note, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
+                    "flop_per_launch": conv_flop,
+                    "launch_timing": f"HIP event pair per launch on its launch stream, {res['events_steps']} step(s) run right after "
+                                     f"the timed region ({ev_ms_step:.2f} ms/step with the events vs {ms_step:.2f} without)"}
             fwd_ms = [a.elapsed_time(b) for a, b in ev.get("conv3x3_fwd", [])]
             if fwd_ms:
                 favg = sum(fwd_ms) / len(fwd_ms)
                 extra["conv3x3_forward_launches_only"] = {"avg_launch_ms": round(favg, 4), "launches_timed": len(fwd_ms),
                                                           "achieved_tflops": round(conv_flop / (favg * 1e-3) / 1e12, 1)}
-            if ev["wgrad"]:
-                w_ms = [a.elapsed_time(b) for a, b in ev["wgrad"]]
+            w_ms = [a.elapsed_time(b) for a, b in ev["wgrad"]]
+            if w_ms:
                 wavg = sum(w_ms) / len(w_ms)
                 extra["wgrad_kernel"] = {"avg_launch_ms": round(wavg, 4), "achieved_tflops": round(conv_flop / (wavg * 1e-3) / 1e12, 1),
                                          "launches_timed": len(w_ms)}
-            extra["conv_share_of_step"] = round((sum(conv_ms) + sum(w_ms if ev["wgrad"] else [])) / (elapsed * 1e3), 3)
             # all MFMA launches (conv + wgrad, which overlap on two streams) over the whole timed region, every phase included
-            n_mfma = len(conv_ms) + (len(w_ms) if ev["wgrad"] else 0)
-            extra["mfma_step_average"] = {"launches": n_mfma, "achieved_tflops": round(n_mfma * conv_flop / elapsed / 1e12, 1),
-                                          "frac": round(n_mfma * conv_flop / elapsed / 1e12 / peak, 4)}
+            n_mfma = (len(conv_ms) + len(w_ms)) // res["events_steps"]
+            extra["mfma_step_average"] = {"launches_per_step": n_mfma, "achieved_tflops": round(n_mfma * conv_flop / (elapsed / args.steps) / 1e12, 1),
+                                          "frac": round(n_mfma * conv_flop / (elapsed / args.steps) / 1e12 / peak, 4)}
         out = {
             "metric": "PPO samples/sec, se_resnet 40x256 on 50x9x9" if args.workload == "40x256" else f"PPO samples/sec, se_resnet {args.workload}",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,12 +424,17 @@ def main() -> None:
             "roofline": roof,
             "hbm_roofline": {"algorithmic_bytes_per_sample": round(bps), "activation_storage_bytes": act_bytes,
                              "achieved_GBps": round(value / world * bps / 1e9, 1), "peak_GBps": PEAK_HBM_GBS,
-                             "frac": round(value / world * bps / 1e9 / PEAK_HBM_GBS, 4)},
+                             "frac": round(value / world * bps / 1e9 / PEAK_HBM_GBS, 4),
+                             "frac_on_fp32_contract_bytes": round(value / world * bps32 / 1e9 / PEAK_HBM_GBS, 4),
+                             "fp32_contract_bytes_per_sample": round(bps32)},
             "model_tflops": {"train_flop_per_sample": flops, "achieved": round(value / world * flops / 1e12, 1), "peak": peak,
                              "frac": round(value / world * flops / 1e12 / peak, 4)},
             "train_metrics": {k: round(v, 5) for k, v in metrics.items()},
+            "kernel_source_sha16": kernel_source_id(),
         }
         out.update(extra)
+        if fp32 is not None:
+            out["fp32_mode"] = fp32
         if whole is not None:
             out["whole_update"] = whole
         if sl is not None:

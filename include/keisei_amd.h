@@ -101,6 +101,11 @@ int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums,
 int ka_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const double* count_dev,
                      const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k,
                      int C, int train, void* stream);
+/* SyncBatchNorm (katago_loop.py:495-496; torch's SyncBatchNorm all_gathers (mean, invstd, count) forward and all_reduces
+ * (sum_dy, sum_dy_xmu) backward): sums[0:2C] as above from the two row sets, sums[2C] = count -- ONE vector for the caller's
+ * single all-reduce per layer and direction; local_copy (optional, [2C+1]) keeps the un-reduced values (dgamma / dbeta). */
+int ka_sync_reduce(const float* p1, int rows1, const float* p2, int rows2, int C, double count, double* sums,
+                   double* local_copy, double* part, void* stream);
 /* One launch less per BatchNorm layer when no cross-rank reduction sits between the two steps: ka_bn_reduce /
  * ka_pair_reduce with sums == NULL stop after their first stage, and these read the partials in `part` directly. */
 int ka_bn_coeffs_parts(const double* part, double count, const float* gamma, const float* beta, float* running_mean,

@@ -30,6 +30,7 @@ _SIGS = {
     "ka_bn_reduce": "p i p i i pp p",
     "ka_reduce_workspace_doubles": "i",
     "ka_pair_reduce": "pp ii pp p",
+    "ka_sync_reduce": "p i p i i d ppp p",
     "ka_bn_coeffs": "p d p pppp p ff pppp i p",
     "ka_bn_coeffs_parts": "p d pppp p ff pppp i p",
     "ka_bn_bwd_coeffs_parts": "p d ppp ppp i i p",

@@ -135,6 +135,22 @@ __global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* _
     sums[c] = s;
 }
 
+// SyncBatchNorm form of stage 2: the vector that travels through the cross-rank all-reduce is [2C sums | element count],
+// so the count is written here (no separate fill launch, no host-side scalar store), and the backward keeps an
+// un-reduced copy of the local sums (dgamma / dbeta are per-rank) without a clone launch.
+__global__ void colsum2_stage2_sync_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                           double* __restrict__ local_copy, double count, int C2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > C2) return;
+    double s = count;
+    if (c < C2) {
+        s = 0.0;
+        for (int k = 0; k < kRedSlices; ++k) s += part[(size_t)k * C2 + c];
+    }
+    sums[c] = s;
+    if (local_copy) local_copy[c] = s;
+}
+
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
 // `sums` is either the reduced [2C] vector (nparts == 1) or the stage-1 partials [nparts][2C], summed here in slice order
@@ -870,6 +886,19 @@ extern "C" int ka_bn_reduce(const float* bsum, int B, const float* sqpart, int R
 extern "C" int ka_pair_reduce(const float* p1, const float* p2, int B, int C, double* sums, double* part, void* stream) {
     KA_REQUIRE(p1 && p2 && part, "pair_reduce: null tensor");
     return colsum2(p1, B, p2, B, C, sums, part, static_cast<hipStream_t>(stream), "pair_reduce");
+}
+
+// SyncBatchNorm: sums[0:2C] as ka_bn_reduce / ka_pair_reduce, sums[2C] = count (this rank's element count); the caller
+// all-reduces the 2C+1 doubles and hands sums + 2C to the coefficient kernels as count_dev.  local_copy (optional,
+// [2C+1]) receives the same values and stays un-reduced.
+extern "C" int ka_sync_reduce(const float* p1, int rows1, const float* p2, int rows2, int C, double count, double* sums,
+                              double* local_copy, double* part, void* stream) {
+    KA_REQUIRE(p1 && p2 && sums && part && count > 0, "sync_reduce: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum2_stage1_kernel, dim3((C + 63) / 64, kRedSlices), dim3(256), 0, st, p1, rows1, p2, rows2, C, part);
+    hipLaunchKernelGGL(colsum2_stage2_sync_kernel, dim3((2 * C + 1 + 127) / 128), dim3(128), 0, st, part, sums, local_copy,
+                       count, 2 * C);
+    return ka_check_launch("sync_reduce");
 }
 
 extern "C" int ka_bn_coeffs(const double* sums, double count, const double* count_dev, const float* gamma,

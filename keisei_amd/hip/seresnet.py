@@ -65,6 +65,7 @@ class SEResNetEngine:
         self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
+        self.grad_reducer = None        # OverlappedGradReducer while a fused DDP step runs (hip/grad_reducer.py)
 
     # ------------------------------------------------------------------ helpers
     def _timed(self, kind: str, name: str, *args) -> None:
@@ -200,8 +201,9 @@ class SEResNetEngine:
 
     @staticmethod
     def _sync_group(bn: nn.Module):
-        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return True
+        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+            # KA_FORCE_COLLECTIVES=1: a world of one rank still issues every collective (the RCCL rehearsal on one GPU)
+            return dist.get_world_size() > 1 or os.environ.get("KA_FORCE_COLLECTIVES", "0") == "1"
         return False
 
     def _bn_forward(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
@@ -216,9 +218,10 @@ class SEResNetEngine:
         sync = self._sync_group(bn)
         ws = self._red_ws(C, device)
         if sync:
+            # [sum y | sum y^2 | count] in ONE vector = one all-reduce per layer (the count rides along, written by the
+            # reduce kernel itself); the dependency chain conv -> statistics -> next conv forbids merging layers
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
-            _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, sums, ws, st)
-            sums[2 * C] = float(count)
+            _call("ka_sync_reduce", bsum, rows_b, sq, rows_s, C, float(count), sums, None, ws, st)
             dist.all_reduce(sums)
             count_t = sums[2 * C:]
         else:
@@ -297,7 +300,7 @@ class SEResNetEngine:
         """One grouped launch for every deferred FC weight / bias gradient of this backward pass."""
         jobs, self._fc_jobs = self._fc_jobs, None
         if not jobs:
-            return
+            return None
         total = sum(N * K + (N if bname is not None else 0) for (_, _, _, _, _, N, K, _, bname, _) in jobs)
         flat = torch.empty(total, device=device)
         rows, off, wg = [], 0, 0
@@ -313,6 +316,7 @@ class SEResNetEngine:
             wg += ((N + 63) // 64) * ((K + (1 if bname is not None else 0) + 63) // 64)
         table = self._upload_rows(rows, device)
         _call("ka_gemm_grouped_wgrad", table, len(jobs), wg, st)
+        return flat
 
     def _linear_bwd(self, dy, x, lin: nn.Linear, grads, wname, bname, st, need_dx=True, x_bf16=0, dx_out=None, acc_dx=0,
                     defer=True):
@@ -504,9 +508,8 @@ class SEResNetEngine:
         ws = self._red_ws(C, dev)
         if train and self._sync_group(bn):
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-            _call("ka_pair_reduce", s1p, s2p, rows, C, sums, ws, st)
-            gsums = sums.clone()
-            gsums[2 * C] = float(count)
+            gsums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+            _call("ka_sync_reduce", s1p, rows, s2p, rows, C, float(count), gsums, sums, ws, st)
             dist.all_reduce(gsums)
             _call("ka_bn_bwd_coeffs", sums, gsums, float(count), gsums[2 * C:], bn.weight, mu, istd, dgam, dbet, k, C,
                   1 if train else 0, st)
@@ -587,6 +590,39 @@ class SEResNetEngine:
         if not self.overlap_wgrad:
             side = None
 
+        # gradient exchange driven from inside the pass (hip/grad_reducer.py): conv weight gradients are written straight
+        # into flat bucket buffers whose all-reduce is issued as soon as the bucket's last wgrad kernel is queued
+        red = self.grad_reducer
+        per_block = 2 * 9 * C * C
+        blocks_per_bucket = max(1, red.bucket_bytes // (4 * per_block)) if red is not None else 0
+        bucket, bucket_off, bucket_left = None, 0, 0
+
+        def conv_grad(like, i, last):
+            """dW tensor of a tower convolution of block i (`last`: second and final one of the block)"""
+            nonlocal bucket, bucket_off, bucket_left
+            if red is None:
+                return torch.empty_like(like)
+            if bucket is None:
+                bucket_left = min(blocks_per_bucket, i + 1)
+                bucket = torch.empty(bucket_left * per_block, device=dev)
+                bucket_off = 0
+            n = like.numel()
+            view = bucket[bucket_off:bucket_off + n].view_as(like)
+            bucket_off += n
+            return view
+
+        def conv_grads_done(i):
+            """both weight gradients of block i are queued: close the bucket when it is full"""
+            nonlocal bucket, bucket_left
+            if red is None:
+                return
+            bucket_left -= 1
+            if bucket_left == 0:
+                ev = torch.cuda.Event()
+                ev.record(side if side is not None else main)
+                red.launch(bucket, f"conv[{i}:{i + bucket.numel() // per_block}]", ev)
+                bucket = None
+
         # ---- tower, last block first
         for i in range(len(sv.blocks) - 1, -1, -1):
             blk = m.blocks[i]
@@ -620,7 +656,7 @@ class SEResNetEngine:
                 ep1 = torch.empty(rows, C, device=dev); ep2 = torch.empty(rows, C, device=dev)
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dz, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
                             y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
-                dW2 = torch.empty_like(blk.conv2.weight)
+                dW2 = conv_grad(blk.conv2.weight, i, False)
                 self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
                 dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
@@ -631,15 +667,16 @@ class SEResNetEngine:
                 dy1, dxc = new_act(), new_act()
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dh, y1, k1, dy1, packs[pre + "conv1"][1], dxc, None,
                             None, None, None, None, None, None, None, B, C, C, code, st)
-                dW1 = torch.empty_like(blk.conv1.weight)
+                dW1 = conv_grad(blk.conv1.weight, i, True)
                 self._wgrad_launch(side, main, (dy1, dW1), dy1, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
                 grads[pre + "conv1.weight"] = dW1
+                conv_grads_done(i)
                 dx = new_act()
             else:
                 _call("ka_bn_bwd_apply", dz, y2, k2, dz, B, C, code, st)                         # dz -> dy2 in place
                 dh = new_act()
                 self._timed("conv3x3", "ka_conv3x3_fwd", dz, packs[pre + "conv2"][1], dh, None, None, None, 0, dg, None, B, C, C, code, st)
-                dW2 = torch.empty_like(blk.conv2.weight)
+                dW2 = conv_grad(blk.conv2.weight, i, False)
                 self._wgrad_launch(side, main, (dz, dW2), dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
                 dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
@@ -651,9 +688,10 @@ class SEResNetEngine:
                 _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place
                 dxc = new_act() if side is not None else dz       # dz / dh may still be read by the side stream
                 self._timed("conv3x3", "ka_conv3x3_fwd", dh, packs[pre + "conv1"][1], dxc, None, None, None, 0, None, None, B, C, C, code, st)
-                dW1 = torch.empty_like(blk.conv1.weight)
+                dW1 = conv_grad(blk.conv1.weight, i, True)
                 self._wgrad_launch(side, main, (dh, dW1), dh, bx, None, None, None, 0, slab, dW1, B, C, C, C, 0, twg, code)
                 grads[pre + "conv1.weight"] = dW1
+                conv_grads_done(i)
                 dx = new_act() if side is not None else dh
             _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
             dout = dx
@@ -671,9 +709,20 @@ class SEResNetEngine:
         self._wgrad_launch(side, main, (dout, dW0), dout, sv.xin, None, None, None, 0, slab, dW0, B, cin_pad,
                            p.obs_channels, C, 0, 0, code)
         grads["input_conv.weight"] = dW0
-        self._flush_fc_jobs(grads, dev, st)
+        fc_flat = self._flush_fc_jobs(grads, dev, st)
         if side is not None:
             main.wait_stream(side)          # every dW is complete before autograd hands the gradients on
+        if red is not None:
+            # the rest: the FC gradients already share one flat buffer; BatchNorm / head / stem gradients are coalesced
+            in_flat = set()
+            if fc_flat is not None:
+                lo, hi = fc_flat.data_ptr(), fc_flat.data_ptr() + 4 * fc_flat.numel()
+                in_flat = {n for n, t in grads.items() if lo <= t.data_ptr() < hi}
+                red.launch(fc_flat, "fc", red._event_now(fc_flat))
+            for n, t in grads.items():
+                if n not in in_flat and not (n.startswith("blocks.") and n.endswith(("conv1.weight", "conv2.weight"))):
+                    red.add_small(t)
+            red.finish()
         return grads
 
     def _linear_bwd_act(self, dy, x_act, lin, grads, wname, dx_act, bf, st):

@@ -730,7 +730,15 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                 self.scaler._lazy_init_scale_growth_tracker(device)
             scaler_t = torch.stack([self.scaler._scale.float().reshape(()),
                                     self.scaler._growth_tracker.float().reshape(())])
+        ddp = reducer = None
+        fm = self.forward_model
+        if (isinstance(fm, torch.nn.parallel.DistributedDataParallel) and torch.distributed.is_initialized()
+                and (torch.distributed.get_world_size(fm.process_group) > 1 or os.environ.get("KA_FORCE_COLLECTIVES", "0") == "1")
+                and os.environ.get("KA_DDP_OVERLAP", "1") != "0"):
+            from keisei_amd.hip.grad_reducer import OverlappedGradReducer
+            ddp, reducer = fm, OverlappedGradReducer(fm.process_group)
         return {
+            "ddp": ddp, "reducer": reducer,
             "data": dataset, "st": st, "scaler_t": scaler_t,
             "gscale": scaler_t[0:1] if scaler_t is not None else None,
             "lam_v": value_adapter.lambda_value if value_adapter is not None else p.lambda_value,
@@ -766,8 +774,21 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
              float(self.current_entropy_coeff), fs["combined"], B, sp)
         self.optimizer.zero_grad(set_to_none=True)
         t2 = time.perf_counter() if ht is not None else 0.0
-        torch.autograd.backward([out.policy_logits, out.value_logits, out.score_lead],
-                                [dlogits.view_as(out.policy_logits), dv, ds])
+        ddp = fs.get("ddp")
+        if ddp is not None:
+            # the engine exchanges gradient buckets DURING its backward (hip/grad_reducer.py); DDP's own post-backward
+            # reduction is switched off for this pass
+            engine = self.model._hip_engine
+            engine.grad_reducer = fs["reducer"]
+            try:
+                with ddp.no_sync():
+                    torch.autograd.backward([out.policy_logits, out.value_logits, out.score_lead],
+                                            [dlogits.view_as(out.policy_logits), dv, ds])
+            finally:
+                engine.grad_reducer = None
+        else:
+            torch.autograd.backward([out.policy_logits, out.value_logits, out.score_lead],
+                                    [dlogits.view_as(out.policy_logits), dv, ds])
         t3 = time.perf_counter() if ht is not None else 0.0
         tab = self._upload_table(st, device)
         call("ka_clip_adam_step", tab, st["blk_t"], st["blk_o"], st["nblocks"], st["partial"], st["ctl"],

@@ -85,3 +85,54 @@ def test_distributed_context_without_torchrun(monkeypatch):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="requires CUDA"):
             kd.setup_distributed(ctx, backend="nccl")
+
+
+def _reducer_worker(rank: int, world: int, port: int, outdir: str) -> None:
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group("gloo")
+    from keisei_amd.hip.grad_reducer import OverlappedGradReducer
+
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+
+    dist.all_reduce = counting
+    red = OverlappedGradReducer(bucket_bytes=4 * 100)
+    timeline = []
+    buckets = []
+    for b in range(3):                                   # three "blocks": each fills one bucket, exchanged at once
+        flat = torch.full((100,), float(rank + 1 + b))
+        timeline.append(("backward", b))
+        red.launch(flat, f"conv[{b}]")
+        timeline.append(("launched", b))
+        buckets.append(flat)
+    smalls = [torch.full((3,), float(rank)), torch.full((2, 2), 10.0 * rank)]
+    for t in smalls:
+        red.add_small(t)
+    red.finish()
+    dist.all_reduce = real
+    torch.save({"buckets": buckets, "smalls": smalls, "calls": calls, "log": red.log, "collectives": red.collectives},
+               os.path.join(outdir, f"red{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_overlapped_reducer_two_ranks():
+    """The engine-driven gradient exchange (hip/grad_reducer.py) on 2 gloo ranks: every bucket's collective is issued
+    while the 'backward' is still running (before the next block), the small tensors travel in ONE coalesced collective
+    at the end, the result is the rank average (DDP semantics), and the number of collectives is buckets + 1."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_reducer_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        a, b = torch.load(os.path.join(d, "red0.pt")), torch.load(os.path.join(d, "red1.pt"))
+    for r in (a, b):
+        assert r["collectives"] == 4 and r["calls"] == [100, 100, 100, 7]
+        assert [e[0] for e in r["log"]] == ["launch", "launch", "launch", "launch", "finish"]
+        assert [e[1] for e in r["log"][:4]] == ["conv[0]", "conv[1]", "conv[2]", "small"]
+        for k, flat in enumerate(r["buckets"]):
+            assert torch.equal(flat, torch.full((100,), 1.5 + k))          # mean of (1 + k) and (2 + k)
+        assert torch.equal(r["smalls"][0], torch.full((3,), 0.5)) and torch.equal(r["smalls"][1], torch.full((2, 2), 5.0))

@@ -20,6 +20,10 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate p
                   "--steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events",
        "correction": "counters are in KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of a wide coalesced read stream); WRITE_SIZE exact",
        "workload": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+# the build the counters were collected on (bench.py refuses to report traffic from a profile of other kernel sources)
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+out["kernel_source_sha16"] = bench.kernel_source_id()
 for k in sorted(set(fetch) | set(write)):
     f = 2.0 * 1024.0 * sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
     w = 1024.0 * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))

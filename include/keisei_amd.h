@@ -250,6 +250,46 @@ int ka_rollout_append(const float* obs, const void* legal, const long long* acti
 int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream);
 int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A, void* stream);
 
+/* ---- transformer encoder path (BASELINE config 5; keisei/training/models/transformer.py:37-95: nn.Linear(50, d),
+ * row/col nn.Embedding, nn.TransformerEncoder(nn.TransformerEncoderLayer(d, nhead, 4d, batch_first, norm_first), L),
+ * nn.Linear(81 d, 11259), value head).  Tokens are (B*81, d) row-major, bf16 (autocast) or fp32 (parity mode; its linear
+ * layers run on ka_gemm).  Dropout masks (nn.Dropout p = 0.1 inside the encoder layer, transformer.py:45-50) come from a
+ * counter-based hash of (seed, element index): recomputed in the backward, never stored. */
+/* C = epilogue(A * B^T), bf16 operands [M][lda] / [N][ldb] (K % 32 == 0), fp32 accumulate: forward nn.Linear (B = bf16
+ * weight copy), its input gradient (B = transposed copy) and its weight gradient (A, B = transposed activations, nsplit
+ * slabs over the token axis).  epilogue = +bias, ReLU, dropout, +residual, bf16 or fp32 store. */
+int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* residual, int M, int N, int K,
+                  int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p, unsigned long long seed,
+                  void* stream);
+int ka_tf_gemm_nt_slabs(int K, int nsplit);
+int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream);
+int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream);
+/* x[b,s,:] += row_embed[s/9] + col_embed[s%9] (transformer.py:84-87) and the embedding gradients (scratch: 81*d floats) */
+int ka_tf_add_pos(void* x, const float* row_embed, const float* col_embed, int B, int d, int dtype, void* stream);
+int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float* dcol, int B, int d, int dtype, void* stream);
+/* nn.LayerNorm(d) (eps 1e-5) forward / backward; part: (ka_tf_layernorm_parts(M) + 1) * 2 * d floats; dx = LN'(dy) + dres */
+int ka_tf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long long M,
+                        int d, float eps, int dtype, void* stream);
+int ka_tf_layernorm_parts(long long M);
+int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const void* dres, void* dx, float* part, float* dgamma, float* dbeta, long long M, int d, int dtype,
+                        void* stream);
+/* out = in * keep [* (act > 0)] [+ res] */
+int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
+                     unsigned long long seed, int dtype, void* stream);
+int ka_tf_colsum(const void* a, float* part, float* out, long long M, int N, int nsplit, int dtype, void* stream);
+int ka_tf_mean_pool(const void* x, float* pooled, int B, int d, int dtype, void* stream);
+int ka_tf_head_grad(const float* dpooled, const void* dflat, void* dx, int B, int d, int dtype, void* stream);
+int ka_tf_tanh(float* v, long long n, void* stream);
+int ka_tf_tanh_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
+/* nn.MultiheadAttention(d, nhead, batch_first) core over the 81 squares: softmax(Q K^T / sqrt(dh)) V per (board, head) on
+ * the matrix cores, dropout on the probabilities in training; qkv [B*81][3d] (in_proj output), out [B*81][d],
+ * lse [B][H][81] for the backward.  dh <= 64. */
+int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int dh, float drop_p, unsigned long long seed,
+                        int dtype, void* stream);
+int ka_tf_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int H, int dh, float drop_p,
+                        unsigned long long seed, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

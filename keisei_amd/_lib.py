@@ -71,9 +71,26 @@ _SIGS = {
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",
     "ka_pack_mask_bits": "pp ii p",
+    "ka_tf_gemm_nt": "ppppp iii iii iii f q p",
+    "ka_tf_gemm_nt_slabs": "ii",
+    "ka_tf_transpose_pad": "pp iiii i p",
+    "ka_tf_cast_pad": "pp q iii i p",
+    "ka_tf_add_pos": "ppp ii i p",
+    "ka_tf_pos_grad": "pppp ii i p",
+    "ka_tf_layernorm_fwd": "pppppp q i f i p",
+    "ka_tf_layernorm_parts": "q",
+    "ka_tf_layernorm_bwd": "pppppp pppp q i i p",
+    "ka_tf_drop_apply": "pppp q f q i p",
+    "ka_tf_colsum": "ppp q ii i p",
+    "ka_tf_mean_pool": "pp ii i p",
+    "ka_tf_head_grad": "ppp ii i p",
+    "ka_tf_tanh": "p q p",
+    "ka_tf_tanh_bwd": "ppp q p",
+    "ka_tf_attention_fwd": "ppp iii f q i p",
+    "ka_tf_attention_bwd": "pppp iii f q i p",
     "ka_version": "",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}   # q also carries 64-bit seeds
 
 _lib: Optional[ctypes.CDLL] = None
 _load_error: Optional[str] = None

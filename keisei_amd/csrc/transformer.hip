@@ -1,0 +1,761 @@
+// Transformer encoder path (BASELINE config 5; reference keisei/training/models/transformer.py:37-95 =
+// nn.TransformerEncoder(norm_first, batch_first, relu FFN, dropout 0.1) over the 81 board squares).
+//
+//   tokens (B*81, d) row-major, activations bf16 (AMP) or fp32 (parity mode)
+//
+// Kernels here:
+//   * gemm_nt_bf16_kernel   C = A * B^T on v_mfma_f32_16x16x32_bf16 (both operands K-contiguous), 128x128x32 LDS tiles,
+//                           register prefetch of the next K tile; epilogue bias / ReLU / dropout / residual; split-K
+//                           slabs.  Forward (B = weight), input gradient (B = transposed weight copy) and weight
+//                           gradient (A, B = transposed activations) are all this one form -- the transposed bf16
+//                           copies are produced by transpose_pad_kernel (activations) / the weight cache refresh.
+//   * attention_{fwd,bwd}   one wave per (board, head): Q, K, V (81 x dh) live in LDS, scores on the matrix cores
+//                           (bf16 MFMA, or the exact-f32 MFMA in parity mode), softmax in registers (row = 4 registers x
+//                           16 lanes), P only ever exists as 16/32-row tiles; backward recomputes P from the saved
+//                           log-sum-exp.
+//   * layer norm forward / backward, positional embedding add / gradient, dropout (counter-based hash: the mask is
+//     recomputed, never stored), mean pool, tanh.
+// The fp32 parity mode runs its linear layers on ka_gemm (gemm.hip, exact-f32 MFMA).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ dropout: counter-based keep mask
+// keep(element) = hash(seed, site, index) >= p * 2^32.  Recomputed wherever it is needed (forward epilogues, backward).
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long index, uint32_t thresh, float inv_keep) {
+    return mix32(seed + index * 0x9E3779B97F4A7C15ULL) >= thresh ? inv_keep : 0.f;
+}
+
+template <typename T> __device__ __forceinline__ float ldT(const T* p, size_t i);
+template <> __device__ __forceinline__ float ldT<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ldT<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i].v); }
+template <typename T> __device__ __forceinline__ void stT(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void stT<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stT<bf16_t>(bf16_t* p, size_t i, float v) { p[i].v = f2bf(v); }
+
+// ------------------------------------------------------------------ NT GEMM on the bf16 matrix cores
+struct NtArgs {
+    const uint16_t* A; const uint16_t* B;     // bf16 [M][lda], [N][ldb], K-contiguous, K % 32 == 0 (zero padded)
+    void* C; const float* bias; const void* residual;     // C [M][ldc] bf16 or fp32; residual like C (same dtype as C)
+    int M, N, K, lda, ldb, ldc;
+    int c_bf16, relu, ksplit_len;              // ksplit_len < K: gridDim.z slabs of fp32 [z][M][ldc], no epilogue
+    float drop_p; unsigned long long seed;     // dropout on the (bias, relu)'d value before the residual add
+};
+
+constexpr int kBM = 128, kBN = 128, kBK = 32, kLdsStride = kBK * 2 + 16;     // bytes per tile row (80: conflict-light)
+
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
+    __shared__ __attribute__((aligned(16))) char As[2][kBM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) char Bs[2][kBN * kLdsStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
+    // staging role: 128 rows x 4 pieces (16 B) per operand tile = 512 pieces, two per thread
+    const int srow = tid >> 2, spc = tid & 3;
+    uint4 ra[2], rb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = srow + 64 * h;
+            const int m = m0 + row, n = n0 + row;
+            ra[h] = m < g.M ? *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + k0 + spc * 8) : uint4{0, 0, 0, 0};
+            rb[h] = n < g.N ? *reinterpret_cast<const uint4*>(g.B + (size_t)n * g.ldb + k0 + spc * 8) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = srow + 64 * h;
+            *reinterpret_cast<uint4*>(As[buf] + row * kLdsStride + spc * 16) = ra[h];
+            *reinterpret_cast<uint4*>(Bs[buf] + row * kLdsStride + spc * 16) = rb[h];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kbeg < kend) {
+        load(kbeg);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+            const bool more = k0 + kBK < kend;
+            if (more) load(k0 + kBK);
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(As[buf] + (wm * 64 + i * 16 + r) * kLdsStride + q * 16);
+                bfr[i] = *reinterpret_cast<const bf16x8*>(Bs[buf] + (wn * 64 + i * 16 + r) * kLdsStride + q * 16);
+            }
+            // C^T tiles: the weight-like operand B is the MFMA "A" so that a lane holds 4 consecutive columns n of one row m
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (more) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // epilogue: lane (r, q) of tile (i, j): row m = i*16 + r, columns n = j*16 + 4q .. +3
+    const bool split = g.ksplit_len < g.K;
+    const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+    const uint32_t thresh = g.drop_p > 0.f ? (uint32_t)(g.drop_p * 4294967296.0) : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nb + e;
+                if (n >= g.N) continue;
+                float v = acc[i][j][e];
+                const size_t o = (size_t)m * g.ldc + n;
+                if (split) { static_cast<float*>(g.C)[(size_t)blockIdx.z * g.M * g.ldc + o] = v; continue; }
+                if (g.bias) v += g.bias[n];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.drop_p > 0.f) v *= keep_scale(g.seed, o, thresh, inv_keep);
+                if (g.c_bf16) {
+                    if (g.residual) v += bf2f(static_cast<const uint16_t*>(g.residual)[o]);
+                    static_cast<uint16_t*>(g.C)[o] = f2bf(v);
+                } else {
+                    if (g.residual) v += static_cast<const float*>(g.residual)[o];
+                    static_cast<float*>(g.C)[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[n][m] (bf16, leading dimension ldo >= M, columns M..ldo-1 zero) = in[m][n]; in is T with leading dimension ldi
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ in, uint16_t* __restrict__ out, int M, int N,
+                                                            int ldi, int ldo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int m = m0 + ty + k, n = n0 + tx;
+        tile[ty + k][tx] = (m < M && n < N) ? ldT<T>(in, (size_t)m * ldi + n) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int n = n0 + ty + k, m = m0 + tx;
+        if (n < N && m < ldo) out[(size_t)n * ldo + m] = f2bf(tile[tx][ty + k]);
+    }
+}
+
+// bf16 copy with zero-padded rows: out[m][0:ldo] = in[m][0:N] | 0
+template <typename T>
+__global__ void cast_pad_kernel(const T* __restrict__ in, uint16_t* __restrict__ out, long long M, int N, int ldi, int ldo) {
+    const size_t total = (size_t)M * ldo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / ldo; const int n = (int)(i - m * ldo);
+        out[i] = n < N ? f2bf(ldT<T>(in, m * ldi + n)) : (uint16_t)0;
+    }
+}
+
+// ------------------------------------------------------------------ positional embedding
+// x[b, s, :] += row_embed[s / 9] + col_embed[s % 9]     (transformer.py:84-87)
+template <typename T>
+__global__ void add_pos_kernel(T* __restrict__ x, const float* __restrict__ rowe, const float* __restrict__ cole, long long M, int d) {
+    const size_t total = (size_t)M * d;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / d; const int c = (int)(i - m * d), s = (int)(m % 81);
+        stT<T>(x, i, ldT<T>(x, i) + rowe[(s / 9) * d + c] + cole[(s % 9) * d + c]);
+    }
+}
+// dpos[s, c] = sum_b dx[b, s, c] (fixed order over b: deterministic); one thread per (s, c)
+template <typename T>
+__global__ void pos_grad_kernel(const T* __restrict__ dx, float* __restrict__ dpos, int B, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 81 * d) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ldT<T>(dx, (size_t)b * 81 * d + i);
+    dpos[i] = s;
+}
+// drow[r, c] = sum_col dpos[r*9+col, c]; dcol[col, c] = sum_r dpos[r*9+col, c]
+__global__ void pos_grad_fold_kernel(const float* __restrict__ dpos, float* __restrict__ drow, float* __restrict__ dcol, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * d) return;
+    const int a = i / d, c = i - a * d;
+    float sr = 0.f, sc = 0.f;
+    for (int k = 0; k < 9; ++k) { sr += dpos[(a * 9 + k) * d + c]; sc += dpos[(k * 9 + a) * d + c]; }
+    drow[i] = sr; dcol[i] = sc;
+}
+
+// ------------------------------------------------------------------ layer norm (eps 1e-5, biased variance)
+// one wave per row; mean / rstd kept in fp32 for the backward
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, long long M, int d,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + (size_t)row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += ldT<T>(xr, c);
+    const float mu = wave_sum(s) / d;
+    float v = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = ldT<T>(xr, c) - mu; v += t * t; }
+    const float rs = rsqrtf(wave_sum(v) / d + eps);
+    for (int c = lane; c < d; c += 64) stT<T>(y + (size_t)row * d, c, (ldT<T>(xr, c) - mu) * rs * gamma[c] + beta[c]);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dx is ADDED to dres (the residual-stream gradient)
+// when dres != NULL.  Per-workgroup partial sums of dgamma / dbeta: part[blockIdx.x][2][d].
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ part, long long M, int d,
+                                                            int rows_per_block) {
+    extern __shared__ float sm[];            // [4 waves][2][d] partial dgamma / dbeta (a lane always owns the same columns)
+    for (int i = threadIdx.x; i < 8 * d; i += blockDim.x) sm[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = sm + wave * 2 * d;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (long long row = r0 + wave; row < min(M, r0 + rows_per_block); row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float g = ldT<T>(dy, (size_t)row * d + c) * gamma[c], xh = (ldT<T>(x, (size_t)row * d + c) - mu) * rs;
+            s1 += g; s2 += g * xh;
+        }
+        s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+        for (int c = lane; c < d; c += 64) {
+            const size_t o = (size_t)row * d + c;
+            const float dyv = ldT<T>(dy, o), xh = (ldT<T>(x, o) - mu) * rs;
+            float v = rs * (dyv * gamma[c] - s1 - xh * s2);
+            if (dres) v += ldT<T>(dres, o);
+            stT<T>(dx, o, v);
+            mine[c] += dyv * xh;
+            mine[d + c] += dyv;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * d; i += blockDim.x)
+        part[(size_t)blockIdx.x * 2 * d + i] = ((sm[i] + sm[2 * d + i]) + sm[4 * d + i]) + sm[6 * d + i];
+}
+// out[i] = sum_p part[p][i]   (fixed order)
+__global__ void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------ elementwise pieces of the backward
+// out = in * keep(index) [* (act > 0)] [+ res]: dropout forward (fp32 mode, where the GEMM has no fused epilogue; + the
+// residual stream) and dropout backward (optionally through the ReLU that precedes the dropout)
+template <typename T>
+__global__ void drop_apply_kernel(const T* __restrict__ g_in, const T* __restrict__ act, const T* __restrict__ res,
+                                  T* __restrict__ g_out, long long n, float drop_p, unsigned long long seed) {
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)(drop_p * 4294967296.0) : 0u;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = ldT<T>(g_in, i);
+        if (drop_p > 0.f) v *= keep_scale(seed, i, thresh, inv_keep);
+        if (act && !(ldT<T>(act, i) > 0.f)) v = 0.f;
+        if (res) v += ldT<T>(res, i);
+        stT<T>(g_out, i, v);
+    }
+}
+// column sums of a T matrix [M][N] in nsplit row ranges: part[s][n] (fp32), fixed order inside a range
+template <typename T>
+__global__ void colsum_T_kernel(const T* __restrict__ a, float* __restrict__ part, long long M, int N, int nsplit) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (n >= N) return;
+    const long long per = (M + nsplit - 1) / nsplit, lo = s * per, hi = min(M, lo + per);
+    float acc = 0.f;
+    for (long long m = lo; m < hi; ++m) acc += ldT<T>(a, (size_t)m * N + n);
+    part[(size_t)s * N + n] = acc;
+}
+// pooled[b, c] = mean_s x[b, s, c]; backward: dx[b, s, c] += dpooled[b, c] / 81 (+ dflat[b, s*d + c] when given)
+template <typename T>
+__global__ void mean_pool_kernel(const T* __restrict__ x, float* __restrict__ pooled, int B, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, c = i - b * d;
+    float s = 0.f;
+    for (int k = 0; k < 81; ++k) s += ldT<T>(x, ((size_t)b * 81 + k) * d + c);
+    pooled[i] = s * (1.f / 81.f);
+}
+template <typename T>
+__global__ void head_grad_kernel(const float* __restrict__ dpooled, const T* __restrict__ dflat, T* __restrict__ dx, long long M, int d) {
+    const size_t total = (size_t)M * d;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / d; const int c = (int)(i - m * d);
+        float v = dpooled ? dpooled[(m / 81) * d + c] * (1.f / 81.f) : 0.f;
+        if (dflat) v += ldT<T>(dflat, i);
+        stT<T>(dx, i, v);
+    }
+}
+__global__ void tanh_kernel(float* __restrict__ v, long long n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x) v[i] = tanhf(v[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+// ------------------------------------------------------------------ attention: one wave per (board, head)
+// Operand convention of tile_mma: A[m][k] and B[n][k], both K-contiguous in LDS with element strides lda / ldb;
+// acc tile (16 x 16): lane (r, q) holds rows 4q..4q+3 of column r.
+template <typename T> struct Mm;
+template <> struct Mm<bf16_t> {
+    typedef uint16_t elem;
+    static constexpr int kStep = 32;
+    static __device__ __forceinline__ f32x4 run(const elem* A, int lda, const elem* B, int ldb, int kdim, int r, int q, f32x4 acc) {
+        for (int k0 = 0; k0 < kdim; k0 += 32) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + r * lda + k0 + 8 * q);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + r * ldb + k0 + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        }
+        return acc;
+    }
+    static __device__ __forceinline__ elem cvt(float v) { return f2bf(v); }
+    static __device__ __forceinline__ float up(elem v) { return bf2f(v); }
+};
+template <> struct Mm<float> {
+    typedef float elem;
+    static constexpr int kStep = 4;
+    static __device__ __forceinline__ f32x4 run(const elem* A, int lda, const elem* B, int ldb, int kdim, int r, int q, f32x4 acc) {
+        for (int k0 = 0; k0 < kdim; k0 += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * lda + k0 + q], B[r * ldb + k0 + q], acc, 0, 0, 0);
+        return acc;
+    }
+    static __device__ __forceinline__ elem cvt(float v) { return v; }
+    static __device__ __forceinline__ float up(elem v) { return v; }
+};
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int kS = 81, kSP = 96;          // sequence, padded to 6 row tiles
+
+struct AttnArgs {
+    const void* qkv;          // [B*81][3d]: q | k | v, head h at columns h*dh
+    void* out;                // [B*81][d]
+    float* lse;               // [B][H][81]
+    const void* dout;         // backward: [B*81][d]
+    void* dqkv;               // backward: [B*81][3d]
+    int B, H, dh, d;
+    float scale, drop_p; unsigned long long seed;
+};
+
+// LDS sizes (elements) for head dimension dh: K-padded to the MFMA step, N-padded to 16
+template <typename T> __host__ __device__ constexpr int attn_kp(int dh) { return (dh + Mm<T>::kStep - 1) / Mm<T>::kStep * Mm<T>::kStep; }
+__host__ __device__ constexpr int attn_np(int dh) { return (dh + 15) / 16 * 16; }
+
+template <typename T>
+__global__ __launch_bounds__(64) void attention_fwd_kernel(AttnArgs a) {
+    typedef typename Mm<T>::elem E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int dh = a.dh, KP = attn_kp<T>(dh), NP = attn_np(dh);
+    const int ldq = KP + 8, ldv = kSP + 8, ldp = kSP + 8;
+    E* Q = reinterpret_cast<E*>(smem);           // [96][ldq]   rows >= 81 and columns >= dh are zero
+    E* K = Q + kSP * ldq;                        // [96][ldq]
+    E* Vt = K + kSP * ldq;                       // [NP][ldv]   V transposed: Vt[c][s]
+    E* P = Vt + NP * ldv;                        // [16][ldp]   one row tile of the (dropped) probabilities
+    for (int i = lane; i < 2 * kSP * ldq + NP * ldv + 16 * ldp; i += 64) Q[i] = Mm<T>::cvt(0.f);
+    const T* base = static_cast<const T*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * dh;
+    for (int i = lane; i < kS * dh; i += 64) {
+        const int s = i / dh, c = i - s * dh;
+        const T* row = base + (size_t)s * 3 * a.d;
+        Q[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, c));
+        K[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, a.d + c));
+        Vt[c * ldv + s] = Mm<T>::cvt(ldT<T>(row, 2 * a.d + c));
+    }
+    __syncthreads();
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = a.drop_p > 0.f ? (uint32_t)(a.drop_p * 4294967296.0) : 0u;
+    for (int rt = 0; rt < 6; ++rt) {
+        f32x4 sc[6];
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) {
+            // acc^T trick: K rows as MFMA "A", Q rows as "B": lane (r, q) then holds score[row = rt*16 + r][col = ct*16 + 4q + i]
+            sc[ct] = Mm<T>::run(K + ct * 16 * ldq, ldq, Q + rt * 16 * ldq, ldq, KP, r, q, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        // row of this lane: rt*16 + r; its 96 columns live in 6 tiles x 4 registers x the 4 lanes q that share r
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = ct * 16 + 4 * q + i;
+                sc[ct][i] = col < kS ? sc[ct][i] * a.scale : -INFINITY;
+                mx = fmaxf(mx, sc[ct][i]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sc[ct][i] = __expf(sc[ct][i] - mx); sum += sc[ct][i]; }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const int row = rt * 16 + r;
+        const float inv = 1.f / sum;
+        if (q == 0 && row < kS) a.lse[((size_t)b * a.H + h) * kS + row] = mx + __logf(sum);
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = ct * 16 + 4 * q + i;
+                float p = sc[ct][i] * inv;
+                if (a.drop_p > 0.f) p *= keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                P[r * ldp + col] = Mm<T>::cvt(p);
+            }
+        __syncthreads();
+        // O[row][c] = sum_col P[row][col] V[col][c]: A = Vt rows (c), B = P rows -> lane holds O[row = r][c = 4q + i]
+        for (int nt = 0; nt < NP / 16; ++nt) {
+            const f32x4 o = Mm<T>::run(Vt + nt * 16 * ldv, ldv, P, ldp, kSP, r, q, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (row < kS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = nt * 16 + 4 * q + i;
+                    if (c < dh) stT<T>(static_cast<T*>(a.out), ((size_t)b * kS + row) * a.d + h * dh + c, o[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward of one (board, head): dQ, dK, dV from dO, with P recomputed from the saved log-sum-exp.
+//   Pd = dropout(P);  dV = Pd^T dO;  dPd = dO V^T;  dP = dropout'(dPd);  dS = P * (dP - rowsum(dP * P)) * scale
+//   dQ = dS K;  dK = dS^T Q
+template <typename T, int NT>
+__global__ __launch_bounds__(64) void attention_bwd_kernel(AttnArgs a) {
+    typedef typename Mm<T>::elem E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int dh = a.dh, KP = attn_kp<T>(dh), NP = attn_np(dh);
+    constexpr int RK = Mm<T>::kStep < 16 ? 16 : Mm<T>::kStep;   // rows per chunk = K extent of the transposed products
+    const int ldq = KP + 8, ldt = kSP + 8, ldc = RK + 8;
+    E* Q = reinterpret_cast<E*>(smem);        // natural [96][ldq]: Q, K, V, dO
+    E* K = Q + kSP * ldq;
+    E* V = K + kSP * ldq;
+    E* dO = V + kSP * ldq;
+    E* Qt = dO + kSP * ldq;                    // transposed [NP][ldt]: Qt[c][s], Kt, dOt
+    E* Kt = Qt + NP * ldt;
+    E* dOt = Kt + NP * ldt;
+    E* dS = dOt + NP * ldt;                    // [RK][ldt]  rows of the chunk
+    E* dSt = dS + RK * ldt;                    // [96][ldc]  the same tile transposed
+    E* Pdt = dSt + kSP * ldc;                  // [96][ldc]  dropped probabilities, transposed
+    const int total = 4 * kSP * ldq + 3 * NP * ldt + RK * ldt + 2 * kSP * ldc;
+    for (int i = lane; i < total; i += 64) Q[i] = Mm<T>::cvt(0.f);
+    const T* base = static_cast<const T*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * dh;
+    const T* dob = static_cast<const T*>(a.dout) + (size_t)b * kS * a.d + h * dh;
+    for (int i = lane; i < kS * dh; i += 64) {
+        const int s = i / dh, c = i - s * dh;
+        const T* row = base + (size_t)s * 3 * a.d;
+        const float qv = ldT<T>(row, c), kv = ldT<T>(row, a.d + c), vv = ldT<T>(row, 2 * a.d + c), gv = ldT<T>(dob, (size_t)s * a.d + c);
+        Q[s * ldq + c] = Mm<T>::cvt(qv); K[s * ldq + c] = Mm<T>::cvt(kv); V[s * ldq + c] = Mm<T>::cvt(vv); dO[s * ldq + c] = Mm<T>::cvt(gv);
+        Qt[c * ldt + s] = Mm<T>::cvt(qv); Kt[c * ldt + s] = Mm<T>::cvt(kv); dOt[c * ldt + s] = Mm<T>::cvt(gv);
+    }
+    __syncthreads();
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = a.drop_p > 0.f ? (uint32_t)(a.drop_p * 4294967296.0) : 0u;
+    constexpr int NTMAX = NT;                  // 16-wide tiles of the head dimension (dh <= 64)
+    f32x4 dK[6][NTMAX], dV[6][NTMAX];          // [column tile][dh tile]: lane holds dK[col = ct*16 + r][c = nt*16 + 4q + i]
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NTMAX; ++nt) { dK[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    T* dq = static_cast<T*>(a.dqkv) + (size_t)b * kS * 3 * a.d + h * dh;
+    for (int r0 = 0; r0 < kSP; r0 += RK) {
+        for (int rt = 0; rt < RK / 16; ++rt) {
+            const int row = r0 + rt * 16 + r;
+            const float l = row < kS ? a.lse[((size_t)b * a.H + h) * kS + row] : 0.f;
+            f32x4 p[6], dp[6];
+            float D = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) {
+                p[ct] = Mm<T>::run(K + ct * 16 * ldq, ldq, Q + (r0 + rt * 16) * ldq, ldq, KP, r, q, f32x4{0.f, 0.f, 0.f, 0.f});
+                dp[ct] = Mm<T>::run(V + ct * 16 * ldq, ldq, dO + (r0 + rt * 16) * ldq, ldq, KP, r, q, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = ct * 16 + 4 * q + i;
+                    const bool ok = col < kS && row < kS;
+                    const float pv = ok ? __expf(p[ct][i] * a.scale - l) : 0.f;
+                    float m = 1.f;
+                    if (a.drop_p > 0.f) m = keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                    const float dpv = ok ? dp[ct][i] * m : 0.f;        // gradient w.r.t. the un-dropped probability
+                    p[ct][i] = pv; dp[ct][i] = dpv;
+                    D += pv * dpv;
+                    Pdt[col * ldc + rt * 16 + r] = Mm<T>::cvt(pv * m);
+                }
+            }
+            D += __shfl_xor(D, 16); D += __shfl_xor(D, 32);
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = ct * 16 + 4 * q + i;
+                    const E v = Mm<T>::cvt(p[ct][i] * (dp[ct][i] - D) * a.scale);
+                    dS[(rt * 16 + r) * ldt + col] = v;
+                    dSt[col * ldc + rt * 16 + r] = v;
+                }
+        }
+        __syncthreads();
+        // dQ rows of the chunk: dQ[row][c] = sum_col dS[row][col] K[col][c]: A = Kt rows (c), B = dS rows
+        for (int rt = 0; rt < RK / 16; ++rt) {
+            const int row = r0 + rt * 16 + r;
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 o = Mm<T>::run(Kt + nt * 16 * ldt, ldt, dS + rt * 16 * ldt, ldt, kSP, r, q, f32x4{0.f, 0.f, 0.f, 0.f});
+                if (row < kS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = nt * 16 + 4 * q + i;
+                        if (c < dh) stT<T>(dq, (size_t)row * 3 * a.d + c, o[i]);
+                    }
+                }
+            }
+        }
+        // dK[col][c] += sum_row dS[row][col] Q[row][c]; dV[col][c] += sum_row Pd[row][col] dO[row][c]   (K extent = RK rows)
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NTMAX; ++nt) {
+                dK[ct][nt] = Mm<T>::run(Qt + nt * 16 * ldt + r0, ldt, dSt + ct * 16 * ldc, ldc, RK, r, q, dK[ct][nt]);
+                dV[ct][nt] = Mm<T>::run(dOt + nt * 16 * ldt + r0, ldt, Pdt + ct * 16 * ldc, ldc, RK, r, q, dV[ct][nt]);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) {
+        const int col = ct * 16 + r;
+        if (col >= kS) continue;
+#pragma unroll
+        for (int nt = 0; nt < NTMAX; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = nt * 16 + 4 * q + i;
+                if (c < dh) {
+                    stT<T>(dq, (size_t)col * 3 * a.d + a.d + c, dK[ct][nt][i]);
+                    stT<T>(dq, (size_t)col * 3 * a.d + 2 * a.d + c, dV[ct][nt][i]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T> size_t attn_fwd_lds(int dh) {
+    const int KP = attn_kp<T>(dh), NP = attn_np(dh);
+    return sizeof(typename Mm<T>::elem) * (size_t)(2 * kSP * (KP + 8) + NP * (kSP + 8) + 16 * (kSP + 8));
+}
+template <typename T> size_t attn_bwd_lds(int dh) {
+    const int KP = attn_kp<T>(dh), NP = attn_np(dh);
+    const int RK = Mm<T>::kStep < 16 ? 16 : Mm<T>::kStep;
+    return sizeof(typename Mm<T>::elem) * (size_t)(4 * kSP * (KP + 8) + 3 * NP * (kSP + 8) + RK * (kSP + 8) + 2 * kSP * (RK + 8));
+}
+
+inline int grid1d(size_t n, int cap) { const size_t b = (n + 255) / 256; return (int)(b < (size_t)cap ? (b ? b : 1) : cap); }
+
+}  // namespace
+
+#define KA_TF_DISPATCH(dtype, stmt)                                                                  \
+    do {                                                                                             \
+        if ((dtype) == KA_DTYPE_BF16) { typedef bf16_t T; stmt; }                                    \
+        else if ((dtype) == KA_DTYPE_F32) { typedef float T; stmt; }                                 \
+        else { ka_set_error("transformer: unknown dtype %d", (dtype)); return KA_ERR_ARG; }          \
+    } while (0)
+
+// ------------------------------------------------------------------ C ABI
+// C[M][ldc] = epilogue(A[M][lda] * B[N][ldb]^T): bf16 operands (K % 32 == 0, 16-byte aligned rows), fp32 accumulation.
+// nsplit > 1: C receives nsplit fp32 slabs [nsplit][M][ldc] of partial sums over K ranges (no epilogue; reduce with
+// ka_reduce_slabs).  Replaces nn.Linear / its input- and weight-gradient GEMMs of transformer.py:40-61 under autocast.
+extern "C" int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* residual, int M, int N, int K,
+                             int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p, unsigned long long seed,
+                             void* stream) {
+    KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "tf_gemm_nt: bad arguments");
+    KA_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, "tf_gemm_nt: K %% 32 and lda/ldb %% 8 required (K=%d lda=%d ldb=%d)", K, lda, ldb);
+    KA_REQUIRE(nsplit >= 1 && (nsplit == 1 || (!bias && !residual && !relu && !c_bf16 && drop_p == 0.f)), "tf_gemm_nt: split-K slabs carry no epilogue");
+    int len = K;
+    if (nsplit > 1) { len = ((K / 32 + nsplit - 1) / nsplit) * 32; nsplit = (K + len - 1) / len; }
+    NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, M, N, K, lda, ldb, ldc,
+             c_bf16, relu, len, drop_p, seed};
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), g);
+    return ka_check_launch("tf_gemm_nt");
+}
+// number of slabs ka_tf_gemm_nt writes for a requested split (the K ranges are whole 32-steps)
+extern "C" int ka_tf_gemm_nt_slabs(int K, int nsplit) {
+    if (nsplit <= 1) return 1;
+    const int len = ((K / 32 + nsplit - 1) / nsplit) * 32;
+    return (K + len - 1) / len;
+}
+
+// out[n][m] = bf16(in[m][n]), rows zero-padded to ldo (>= M, a multiple of 32): the K-contiguous operand form of the
+// weight-gradient GEMM (contraction over tokens) and of the transposed weight cache
+extern "C" int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream) {
+    KA_REQUIRE(in && out && ldo >= M, "tf_transpose_pad: bad arguments");
+    dim3 grid((N + 31) / 32, (ldo + 31) / 32);
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                                             static_cast<const T*>(in), static_cast<uint16_t*>(out), M, N, ldi, ldo));
+    return ka_check_launch("tf_transpose_pad");
+}
+extern "C" int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream) {
+    KA_REQUIRE(in && out && ldo >= N, "tf_cast_pad: bad arguments");
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(cast_pad_kernel<T>, dim3(grid1d((size_t)M * ldo, 4096)), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), static_cast<const T*>(in),
+                                             static_cast<uint16_t*>(out), M, N, ldi, ldo));
+    return ka_check_launch("tf_cast_pad");
+}
+
+extern "C" int ka_tf_add_pos(void* x, const float* row_embed, const float* col_embed, int B, int d, int dtype, void* stream) {
+    KA_REQUIRE(x && row_embed && col_embed, "tf_add_pos: null tensor");
+    const long long M = (long long)B * 81;
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(add_pos_kernel<T>, dim3(grid1d((size_t)M * d, 4096)), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), static_cast<T*>(x), row_embed, col_embed, M, d));
+    return ka_check_launch("tf_add_pos");
+}
+// scratch: 81*d floats
+extern "C" int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float* dcol, int B, int d, int dtype, void* stream) {
+    KA_REQUIRE(dx && scratch && drow && dcol, "tf_pos_grad: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(pos_grad_kernel<T>, dim3((81 * d + 255) / 256), dim3(256), 0, st,
+                                             static_cast<const T*>(dx), scratch, B, d));
+    hipLaunchKernelGGL(pos_grad_fold_kernel, dim3((9 * d + 255) / 256), dim3(256), 0, st, scratch, drow, dcol, d);
+    return ka_check_launch("tf_pos_grad");
+}
+
+extern "C" int ka_tf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   long long M, int d, float eps, int dtype, void* stream) {
+    KA_REQUIRE(x && gamma && beta && y && mean && rstd, "tf_layernorm_fwd: null tensor");
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), static_cast<const T*>(x), gamma, beta,
+                                             static_cast<T*>(y), mean, rstd, M, d, eps));
+    return ka_check_launch("tf_layernorm_fwd");
+}
+extern "C" int ka_tf_layernorm_parts(long long M) { const long long p = (M + 255) / 256; return (int)(p < 1024 ? p : 1024); }
+// dx = LayerNorm'(dy) [+ dres]; dgamma / dbeta [d] via part (ka_tf_layernorm_parts(M) * 2 * d floats)
+extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                   const void* dres, void* dx, float* part, float* dgamma, float* dbeta, long long M, int d,
+                                   int dtype, void* stream) {
+    KA_REQUIRE(dy && x && gamma && mean && rstd && dx && part && dgamma && dbeta, "tf_layernorm_bwd: null tensor");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nparts = ka_tf_layernorm_parts(M);
+    const int rpb = (int)((M + nparts - 1) / nparts);
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
+                                             static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
+                                             static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb));
+    // part rows are [dgamma | dbeta]
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, part + (size_t)nparts * 2 * d, nparts, 2 * d);
+    (void)hipMemcpyAsync(dgamma, part + (size_t)nparts * 2 * d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(dbeta, part + (size_t)nparts * 2 * d + d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return ka_check_launch("tf_layernorm_bwd");
+}
+
+extern "C" int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
+                                unsigned long long seed, int dtype, void* stream) {
+    KA_REQUIRE(g_in && g_out && n > 0, "tf_drop_apply: bad arguments");
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(drop_apply_kernel<T>, dim3(grid1d((size_t)n, 4096)), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), static_cast<const T*>(g_in),
+                                             static_cast<const T*>(act), static_cast<const T*>(res), static_cast<T*>(g_out),
+                                             n, drop_p, seed));
+    return ka_check_launch("tf_drop_apply");
+}
+// bias gradient: out[n] = sum_m a[m][n]; part: nsplit * N floats
+extern "C" int ka_tf_colsum(const void* a, float* part, float* out, long long M, int N, int nsplit, int dtype, void* stream) {
+    KA_REQUIRE(a && part && out && nsplit >= 1, "tf_colsum: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(colsum_T_kernel<T>, dim3((N + 255) / 256, nsplit), dim3(256), 0, st,
+                                             static_cast<const T*>(a), part, M, N, nsplit));
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, out, nsplit, N);
+    return ka_check_launch("tf_colsum");
+}
+extern "C" int ka_tf_mean_pool(const void* x, float* pooled, int B, int d, int dtype, void* stream) {
+    KA_REQUIRE(x && pooled, "tf_mean_pool: null tensor");
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(mean_pool_kernel<T>, dim3((B * d + 255) / 256), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), static_cast<const T*>(x), pooled, B, d));
+    return ka_check_launch("tf_mean_pool");
+}
+// dx[b,s,:] = dpooled[b,:] / 81 + dflat[b, s, :]   (gradient of the two heads w.r.t. the encoder output)
+extern "C" int ka_tf_head_grad(const float* dpooled, const void* dflat, void* dx, int B, int d, int dtype, void* stream) {
+    KA_REQUIRE(dx && (dpooled || dflat), "tf_head_grad: null tensor");
+    const long long M = (long long)B * 81;
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(head_grad_kernel<T>, dim3(grid1d((size_t)M * d, 4096)), dim3(256), 0,
+                                             static_cast<hipStream_t>(stream), dpooled, static_cast<const T*>(dflat),
+                                             static_cast<T*>(dx), M, d));
+    return ka_check_launch("tf_head_grad");
+}
+extern "C" int ka_tf_tanh(float* v, long long n, void* stream) {
+    KA_REQUIRE(v && n > 0, "tf_tanh: bad arguments");
+    hipLaunchKernelGGL(tanh_kernel, dim3(grid1d((size_t)n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), v, n);
+    return ka_check_launch("tf_tanh");
+}
+extern "C" int ka_tf_tanh_bwd(const float* dy, const float* y, float* dx, long long n, void* stream) {
+    KA_REQUIRE(dy && y && dx && n > 0, "tf_tanh_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d((size_t)n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, dx, n);
+    return ka_check_launch("tf_tanh_bwd");
+}
+
+// Multi-head self-attention over the 81 squares (nn.MultiheadAttention inside nn.TransformerEncoderLayer,
+// transformer.py:45-55): out = softmax(Q K^T / sqrt(dh)) V per (board, head), with dropout on the probabilities in
+// training; lse [B][H][81] is kept for the backward.  dh <= 64.
+extern "C" int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, int dh, float drop_p,
+                                   unsigned long long seed, int dtype, void* stream) {
+    KA_REQUIRE(qkv && out && lse && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_fwd: bad arguments (dh <= 64)");
+    AttnArgs a{qkv, out, lse, nullptr, nullptr, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KA_DTYPE_BF16) {
+        static std::atomic<unsigned long long> done{0};
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&attention_fwd_kernel<bf16_t>), done, "tf_attention_fwd")) return rc;
+        hipLaunchKernelGGL(attention_fwd_kernel<bf16_t>, dim3(B * H), dim3(64), attn_fwd_lds<bf16_t>(dh), st, a);
+    } else if (dtype == KA_DTYPE_F32) {
+        static std::atomic<unsigned long long> done{0};
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&attention_fwd_kernel<float>), done, "tf_attention_fwd")) return rc;
+        hipLaunchKernelGGL(attention_fwd_kernel<float>, dim3(B * H), dim3(64), attn_fwd_lds<float>(dh), st, a);
+    } else { ka_set_error("tf_attention_fwd: unknown dtype %d", dtype); return KA_ERR_ARG; }
+    return ka_check_launch("tf_attention_fwd");
+}
+extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int H, int dh,
+                                   float drop_p, unsigned long long seed, int dtype, void* stream) {
+    KA_REQUIRE(qkv && dout && lse && dqkv && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_bwd: bad arguments (dh <= 64)");
+    AttnArgs a{qkv, nullptr, const_cast<float*>(lse), dout, dqkv, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nt = attn_np(dh) / 16;
+#define KA_ATTN_BWD(T_, NT_)                                                                                              \
+    do {                                                                                                                  \
+        static std::atomic<unsigned long long> done{0};                                                                   \
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&attention_bwd_kernel<T_, NT_>), done, "tf_attention_bwd")) return rc; \
+        hipLaunchKernelGGL((attention_bwd_kernel<T_, NT_>), dim3(B * H), dim3(64), attn_bwd_lds<T_>(dh), st, a);           \
+    } while (0)
+    if (dtype == KA_DTYPE_BF16) {
+        if (nt == 1) KA_ATTN_BWD(bf16_t, 1); else if (nt == 2) KA_ATTN_BWD(bf16_t, 2); else if (nt == 3) KA_ATTN_BWD(bf16_t, 3); else KA_ATTN_BWD(bf16_t, 4);
+    } else if (dtype == KA_DTYPE_F32) {
+        if (nt == 1) KA_ATTN_BWD(float, 1); else if (nt == 2) KA_ATTN_BWD(float, 2); else if (nt == 3) KA_ATTN_BWD(float, 3); else KA_ATTN_BWD(float, 4);
+    } else { ka_set_error("tf_attention_bwd: unknown dtype %d", dtype); return KA_ERR_ARG; }
+#undef KA_ATTN_BWD
+    return ka_check_launch("tf_attention_bwd");
+}

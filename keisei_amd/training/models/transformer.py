@@ -1,5 +1,6 @@
 """Transformer with learned row+column embeddings, scalar contract
-(mirror of keisei/training/models/transformer.py:13-95; BASELINE config 5, forward only)."""
+(mirror of keisei/training/models/transformer.py:13-95; BASELINE config 5).  CPU tensors run the nn children; CUDA/HIP
+tensors run the hand-written kernels of keisei_amd/hip/transformer.py (forward and backward)."""
 from __future__ import annotations
 
 import dataclasses
@@ -45,6 +46,10 @@ class TransformerModel(BaseModel):
 
     def forward(self, obs: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         self._check_obs(obs)
+        if obs.is_cuda:
+            # hand-written HIP path (keisei_amd/hip/transformer.py); raises if the library is missing -- no fallback
+            from keisei_amd.hip.transformer import run_model
+            return run_model(self, obs)
         b, sq = obs.shape[0], self.BOARD_SIZE * self.BOARD_SIZE
         tokens = self.input_proj(obs.permute(0, 2, 3, 1).reshape(b, sq, self.OBS_CHANNELS))
         pos = self.row_embed(self._row_idx)[:, None, :] + self.col_embed(self._col_idx)[None, :, :]

@@ -182,6 +182,28 @@ def closed_form_cotangents(batch: int) -> tuple:
     return cp, cv, cs
 
 
+def hash_fill(sd: Dict[str, torch.Tensor], salt: int = 0) -> Dict[str, torch.Tensor]:
+    """Init-like closed-form weights for ANY state_dict (the scalar-contract models): matrices U(-1, 1) / sqrt(fan_in),
+    1-D tensors named like norm scales 1 +- 0.1, other 1-D tensors +- 0.05 (embeddings: +- 0.5), from the counter-based
+    hash -- full rank, reproducible everywhere, nothing to store."""
+    out: Dict[str, torch.Tensor] = {}
+    for k_idx, (key, t) in enumerate(sd.items()):
+        if not t.dtype.is_floating_point:
+            out[key] = t.clone()
+            continue
+        u = _hash_uniform(t.numel(), 5000 + 1000 * salt + k_idx)
+        if "embed" in key:
+            v = 0.5 * u
+        elif t.ndim >= 2:
+            v = u / math.sqrt(max(1, t[0].numel()))
+        elif "norm" in key and key.endswith("weight"):
+            v = 1.0 + 0.1 * u
+        else:
+            v = 0.05 * u
+        out[key] = v.to(t.dtype).reshape(t.shape)
+    return out
+
+
 def closed_form_fill(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Generic closed-form weights for any state_dict (used for the scalar-contract models,
     whose policy_fc is too large to commit): float tensors get amp*sin(.), norm scales ~1,

@@ -20,6 +20,7 @@ Fixture inventory:
   g5_update     one full KataGoPPOAlgorithm.update() on CPU with recorded randperm sequences
   g6_adam       clip_grad_norm_ + Adam, 3 steps
   g7_scalar     mlp / transformer tiny forward
+  g9_transformer TransformerModel (2 small configs, hash weights): eval / train(dropout 0) outputs, fp64 gradients
   g8_sl         two SLTrainer.train_epoch() calls on a 3-shard directory: shard arrays, visiting order, metrics, weights
 """
 
@@ -473,6 +474,52 @@ def g7_scalar() -> None:
     npz("g7_scalar", **arrays)
 
 
+def g9_transformer() -> None:
+    """TransformerModel (transformer.py:37-95) with init-like hash weights: eval outputs, and -- with every dropout of the
+    encoder layers set to p = 0, so that train mode is deterministic -- train-mode outputs and fp64 gradients (norms of
+    every tensor, every tensor of <= 20 000 elements in full, 8 rows of the policy matrix)."""
+    arrays = {}
+    for tag, p, batch in (("d32h4L2.", {"d_model": 32, "nhead": 4, "num_layers": 2}, 3),
+                          ("d64h2L1.", {"d_model": 64, "nhead": 2, "num_layers": 1}, 5)):
+        m = build_model("transformer", p)
+        sd = orc.hash_fill(m.state_dict())
+        m.load_state_dict(sd, strict=True)
+        obs = _mixed_obs(batch + batch % 2, 900)[:batch]
+        arrays[tag + "obs"] = obs
+        m.eval()
+        with torch.no_grad():
+            pol, val = m(obs)
+        arrays[tag + "eval.policy"], arrays[tag + "eval.value"] = pol, val
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        cp = orc._hash_uniform(batch * 11259, 7101).float().reshape(batch, 11259)
+        cv = orc._hash_uniform(batch, 7102).float().reshape(batch, 1)
+        m64 = build_model("transformer", p).double()
+        m64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()})
+        for mod in m64.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        m.train(); m64.train()
+        pol, val = m(obs)
+        arrays[tag + "train.policy"], arrays[tag + "train.value"] = pol, val
+        pol64, val64 = m64(obs.double())
+        loss = (pol64 * cp.double()).sum() / batch + (val64 * cv.double()).sum()
+        grads = dict(zip([n for n, _ in m64.named_parameters()], torch.autograd.grad(loss, list(m64.parameters()))))
+        names = list(grads)
+        arrays[tag + "grad_names"] = np.array(names)
+        arrays[tag + "grad_norms64"] = np.array([float(g.norm()) for g in grads.values()])
+        for n, g in grads.items():
+            if g.numel() <= SMALL:
+                arrays[f"{tag}grad64.{n}"] = g.float()
+        arrays[tag + "grad64.policy_fc.weight[:8]"] = grads["policy_fc.weight"][:8].float()
+    npz("g9_transformer", **arrays)
+
+
 def g8_sl() -> None:
     """keisei/sl: write_shard -> SLDataset -> SLTrainer.train_epoch() x 2 (CPU fp32), with the order in which the
     shuffling DataLoader visited the positions recorded per epoch."""
@@ -527,7 +574,7 @@ def g8_sl() -> None:
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    for fn in (g1_block, g2_model_tiny, g2_model_mid16, g2_model_full, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar, g8_sl):
+    for fn in (g1_block, g2_model_tiny, g2_model_mid16, g2_model_full, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar, g8_sl, g9_transformer):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -1,0 +1,237 @@
+"""GPU: the TransformerModel HIP path (BASELINE config 5; reference transformer.py:37-95) -- kernels against plain fp32
+CPU math, the model against reference-generated fixtures (g9: fp32 outputs, fp64 gradients), the bf16 mode against a
+measured bound, and the statistics / reproducibility of the counter-based dropout."""
+import math
+
+import pytest
+import torch
+
+from keisei_amd import _lib
+from keisei_amd.training.model_registry import build_model
+from oracle import keisei_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def st():
+    return _lib.stream_ptr(torch.device(DEV))
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 200, 64, 1), (130, 139, 96, 1), (257, 384, 2592, 1), (64, 96, 4096, 8)])
+def test_gemm_nt_bf16(M, N, K, split):
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).bfloat16()
+    ref = a.float() @ b.float().T
+    ad, bd = a.to(DEV), b.to(DEV)
+    if split == 1:
+        out = torch.empty(M, N, device=DEV)
+        _lib.call("ka_tf_gemm_nt", ad, bd, out, bias.to(DEV), None, M, N, K, K, K, N, 0, 1, 1, 0.0, 0, st())
+        want = torch.relu(ref + bias)
+        assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=1e-3 * math.sqrt(K) / 8)
+        out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        _lib.call("ka_tf_gemm_nt", ad, bd, out16, bias.to(DEV), res.to(DEV), M, N, K, K, K, N, 1, 0, 1, 0.0, 0, st())
+        want = (ref + bias + res.float()).bfloat16().float()
+        assert float((out16.float().cpu() - want).abs().max()) <= 0.02 * float(want.abs().max())
+    else:
+        ns = _lib.query("ka_tf_gemm_nt_slabs", K, split)
+        slab = torch.empty(ns, M, N, device=DEV)
+        _lib.call("ka_tf_gemm_nt", ad, bd, slab, None, None, M, N, K, K, K, N, 0, 0, split, 0.0, 0, st())
+        assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=2e-2)
+
+
+def test_transpose_and_cast_pad():
+    x = torch.randn(70, 45)
+    out = torch.full((45, 96), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_tf_transpose_pad", x.to(DEV), out, 70, 45, 45, 96, _lib.DTYPE_F32, st())
+    assert torch.equal(out[:, :70].cpu(), x.T.bfloat16()) and float(out[:, 70:].abs().max()) == 0
+    out = torch.full((70, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_tf_cast_pad", x.bfloat16().to(DEV), out, 70, 45, 45, 64, _lib.DTYPE_BF16, st())
+    assert torch.equal(out[:, :45].cpu(), x.bfloat16()) and float(out[:, 45:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layernorm_forward_backward(dt):
+    M, d = 243, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, d, generator=g).to(dt)
+    gam, bet = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    dy = torch.randn(M, d, generator=g).to(dt)
+    dres = torch.randn(M, d, generator=g).to(dt)
+    xr = x.float().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    y.backward(dy.float())
+    code = _lib.dtype_code(dt)
+    xd = x.to(DEV)
+    yd = torch.empty_like(xd); mu = torch.empty(M, device=DEV); rs = torch.empty(M, device=DEV)
+    _lib.call("ka_tf_layernorm_fwd", xd, gam.to(DEV), bet.to(DEV), yd, mu, rs, M, d, 1e-5, code, st())
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert torch.allclose(yd.float().cpu(), y.detach(), rtol=tol, atol=tol)
+    nparts = _lib.query("ka_tf_layernorm_parts", M)
+    ws = torch.empty((nparts + 1) * 2 * d, device=DEV)
+    dx = torch.empty_like(xd); dg = torch.empty(d, device=DEV); db = torch.empty(d, device=DEV)
+    _lib.call("ka_tf_layernorm_bwd", dy.to(DEV), xd, gam.to(DEV), mu, rs, dres.to(DEV), dx, ws, dg, db, M, d, code, st())
+    assert torch.allclose(dx.float().cpu(), xr.grad + dres.float(), rtol=tol, atol=2 * tol)
+    assert torch.allclose(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-3 if dt == torch.float32 else 0.3)
+    assert torch.allclose(db.cpu(), br.grad, rtol=1e-3, atol=1e-3 if dt == torch.float32 else 0.3)
+
+
+def _attn_ref(qkv, B, H, dh):
+    d = H * dh
+    q, k, v = (t.reshape(B, 81, H, dh).transpose(1, 2) for t in qkv.reshape(B, 81, 3, d).unbind(2))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * 81, d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dt,H,dh", [(torch.float32, 4, 8), (torch.float32, 2, 32), (torch.bfloat16, 8, 32), (torch.bfloat16, 2, 64),
+                                     (torch.bfloat16, 4, 8), (torch.float32, 3, 24)])
+def test_attention_forward_backward(dt, H, dh):
+    B, d = 3, H * dh
+    g = torch.Generator().manual_seed(H * 100 + dh)
+    qkv = torch.randn(B * 81, 3 * d, generator=g).to(dt)
+    dout = torch.randn(B * 81, d, generator=g).to(dt)
+    ref_in = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(ref_in, B, H, dh)
+    o_ref.backward(dout.double())
+    code = _lib.dtype_code(dt)
+    qd = qkv.to(DEV)
+    out = torch.empty(B * 81, d, dtype=dt, device=DEV); lse = torch.empty(B, H, 81, device=DEV)
+    _lib.call("ka_tf_attention_fwd", qd, out, lse, B, H, dh, 0.0, 0, code, st())
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    assert torch.allclose(out.double().cpu(), o_ref.detach(), rtol=tol, atol=tol)
+    assert torch.allclose(lse.double().cpu(), lse_ref.detach(), rtol=1e-3 if dt == torch.bfloat16 else 1e-5, atol=tol)
+    dq = torch.full((B * 81, 3 * d), float("nan"), dtype=dt, device=DEV)
+    _lib.call("ka_tf_attention_bwd", qd, dout.to(DEV), lse, dq, B, H, dh, 0.0, 0, code, st())
+    ref = ref_in.grad
+    err = float((dq.double().cpu() - ref).norm() / ref.norm())
+    assert err < (2e-5 if dt == torch.float32 else 2e-2), err
+
+
+def test_attention_dropout_is_consistent_between_forward_and_backward():
+    """With dropout the kernel's own forward is the reference for its backward: d(sum(out * w)) / d(qkv) by central
+    differences of the fp32 forward (same seed = same mask) against the backward kernel; and the mask keeps 1 - p."""
+    B, H, dh, p, seed = 1, 2, 16, 0.3, 1234567
+    d = H * dh
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(81, 3 * d, generator=g).to(DEV)
+    w = torch.randn(81, d, generator=g).to(DEV)
+
+    def fwd(x):
+        out = torch.empty(81, d, device=DEV); lse = torch.empty(B, H, 81, device=DEV)
+        _lib.call("ka_tf_attention_fwd", x.contiguous(), out, lse, B, H, dh, p, seed, _lib.DTYPE_F32, st())
+        return out, lse
+
+    out, lse = fwd(qkv)
+    dq = torch.empty_like(qkv)
+    _lib.call("ka_tf_attention_bwd", qkv, w, lse, dq, B, H, dh, p, seed, _lib.DTYPE_F32, st())
+    idx = [(0, 0), (5, 3), (40, d + 7), (80, 2 * d + 1), (17, 2 * d + dh + 2)]
+    for (r, c) in idx:
+        e = torch.zeros_like(qkv); e[r, c] = 1e-2
+        num = float((((fwd(qkv + e)[0] - fwd(qkv - e)[0]) * w).sum() / 2e-2))
+        assert abs(num - float(dq[r, c])) <= 2e-2 * max(1.0, abs(num)), (r, c, num, float(dq[r, c]))
+    out0, _ = fwd(qkv)
+    assert torch.equal(out, out0)                       # same seed, same mask
+    # v = 1: out = sum of kept probabilities / (1 - p) -> mean 1 over rows when the mask keeps 1 - p of the mass
+    ones = qkv.clone(); ones[:, 2 * d:] = 1.0
+    kept = fwd(ones)[0]
+    assert abs(float(kept.mean()) - 1.0) < 0.05
+
+
+def _fixture_model(tag, p):
+    m = build_model("transformer", p)
+    m.load_state_dict(orc.hash_fill(m.state_dict()), strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return m.to(DEV)
+
+
+CONFIGS = [("d32h4L2.", {"d_model": 32, "nhead": 4, "num_layers": 2}), ("d64h2L1.", {"d_model": 64, "nhead": 2, "num_layers": 1})]
+
+
+@pytest.mark.parametrize("tag,p", CONFIGS)
+def test_transformer_fp32_matches_reference(golden, tag, p):
+    g = golden("g9_transformer")
+    m = _fixture_model(tag, p)
+    obs = g[tag + "obs"].to(DEV)
+    B = obs.shape[0]
+    m.eval()
+    with torch.no_grad():
+        pol, val = m(obs)
+    assert pol.shape == (B, 11259) and val.shape == (B, 1)
+    assert torch.allclose(pol.cpu(), g[tag + "eval.policy"], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(val.cpu(), g[tag + "eval.value"], rtol=1e-4, atol=2e-5)
+    m.train()
+    pol, val = m(obs)
+    assert torch.allclose(pol.detach().cpu(), g[tag + "train.policy"], rtol=1e-4, atol=2e-5)
+    cp = orc._hash_uniform(B * 11259, 7101).float().reshape(B, 11259).to(DEV)
+    cv = orc._hash_uniform(B, 7102).float().reshape(B, 1).to(DEV)
+    ((pol * cp).sum() / B + (val * cv).sum()).backward()
+    names = list(g.np(tag + "grad_names"))
+    norms = dict(zip(names, g.np(tag + "grad_norms64")))
+    worst_n = worst_l2 = 0.0
+    for n, prm in m.named_parameters():
+        assert prm.grad is not None, n
+        worst_n = max(worst_n, abs(float(prm.grad.double().norm()) - norms[n]) / (norms[n] + 1e-30))
+        for key, got in ((f"{tag}grad64.{n}", prm.grad), (f"{tag}grad64.{n}[:8]", prm.grad[:8])):
+            if key in g:
+                ref = g[key].double()
+                worst_l2 = max(worst_l2, float((got.double().cpu() - ref).norm() / (ref.norm() + 1e-30)))
+    print(f"{tag} fp32 gradients vs reference fp64: norm {worst_n:.2e}, rel L2 {worst_l2:.2e}")
+    assert worst_n < 1e-4 and worst_l2 < 1e-4
+
+
+@pytest.mark.parametrize("tag,p", CONFIGS)
+def test_transformer_bf16_bound(golden, tag, p):
+    """bf16 autocast: policy logits within 3 % of |logit|max of the reference's fp32 output (measured ~1 %), gradient
+    norms within 10 %, every stored gradient tensor within 15 % relative L2 of the reference's fp64 gradient."""
+    g = golden("g9_transformer")
+    m = _fixture_model(tag, p)
+    obs = g[tag + "obs"].to(DEV)
+    B = obs.shape[0]
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pol, val = m(obs)
+    ref = g[tag + "train.policy"]
+    e = float((pol.detach().float().cpu() - ref).abs().max()) / float(ref.abs().max())
+    cp = orc._hash_uniform(B * 11259, 7101).float().reshape(B, 11259).to(DEV)
+    cv = orc._hash_uniform(B, 7102).float().reshape(B, 1).to(DEV)
+    ((pol.float() * cp).sum() / B + (val.float() * cv).sum()).backward()
+    names = list(g.np(tag + "grad_names"))
+    norms = dict(zip(names, g.np(tag + "grad_norms64")))
+    worst_n = worst_l2 = 0.0
+    for n, prm in m.named_parameters():
+        worst_n = max(worst_n, abs(float(prm.grad.double().norm()) - norms[n]) / (norms[n] + 1e-30))
+        key = f"{tag}grad64.{n}"
+        if key in g:
+            refg = g[key].double()
+            worst_l2 = max(worst_l2, float((prm.grad.double().cpu() - refg).norm() / (refg.norm() + 1e-30)))
+    print(f"{tag} bf16: policy {e:.4f} of |logit|max, gradient norms off by {worst_n:.3f}, rel L2 {worst_l2:.3f}")
+    assert e < 0.03 and worst_n < 0.10 and worst_l2 < 0.15
+
+
+def test_transformer_training_mode_dropout():
+    """Train mode with the reference's dropout 0.1: outputs differ from eval mode and from call to call (fresh seed per
+    forward), stay finite, and every parameter receives a finite gradient."""
+    torch.manual_seed(0)
+    m = build_model("transformer", {"d_model": 64, "nhead": 4, "num_layers": 2}).to(DEV)
+    obs = torch.randn(4, 50, 9, 9, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        pe, _ = m(obs)
+    m.train()
+    p1, v1 = m(obs)
+    p2, _ = m(obs)
+    assert not torch.equal(p1, p2) and not torch.equal(p1.detach(), pe)
+    assert float((p1.detach() - pe).abs().max()) < 0.6 * float(pe.abs().max()) + 0.5
+    (p1.sum() + v1.sum()).backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters())
+    with pytest.raises(ValueError, match="Expected obs shape"):
+        m(torch.zeros(2, 46, 9, 9, device=DEV))

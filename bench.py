@@ -191,6 +191,87 @@ def cpu_baseline(shape, seconds_budget=25.0):
                       f"minibatch {Bc}, median of {len(times)} step(s) (~{sum(times):.0f} s of CPU work) after a probe step"}
 
 
+def run_transformer(args, device):
+    """BASELINE configs[4]: transformer (d_model 256, nhead 8, 6 layers -- SURVEY 8d fixes the sizing, no reference config
+    names one), minibatch 4096, one GPU: forward (bf16 autocast, train mode with the encoder's dropout 0.1) + clipped-
+    surrogate policy loss over the legal actions + MSE value loss against returns (ScalarValueAdapter, value_adapter.py:43-
+    59) + backward + fused clip / Adam.  The reference cannot train this model, so there is no training
+    loop to mirror; the step is the same statement sequence as katago_ppo.py:849-933 with the scalar adapter."""
+    from keisei_amd import _lib
+    from keisei_amd.training.fused_optim import FusedAdamMixin
+    from keisei_amd.training.model_registry import build_model
+
+    d, H, L, B = 256, 8, 6, args.batch or 4096
+    torch.manual_seed(1234)
+    model = build_model("transformer", {"d_model": d, "nhead": H, "num_layers": L}).to(device)
+    model.train()
+    n_params = sum(p.numel() for p in model.parameters())
+    total = 4 * B
+    data = synth_dataset(total, 1234, device)
+    returns = torch.randn(total, generator=torch.Generator().manual_seed(5)).clamp(-1, 1).to(device)
+
+    class Step(FusedAdamMixin):
+        def __init__(self):
+            self.optimizer = torch.optim.Adam(model.parameters(), lr=2e-4)
+            self._hip_state = {}
+            assert self._fused_optimizer_ok()
+            self.st = self._adam_tables(device)
+            self.flags = torch.zeros(2, dtype=torch.int32, device=device)
+            self.acc = torch.zeros(5, device=device)
+
+        def __call__(self, idx):
+            sp = _lib.stream_ptr(device)
+            obs = data["obs"][idx]
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+                logits, value = model(obs)
+            Bn, A = logits.shape
+            dlogits = torch.empty_like(logits)
+            new_lp = torch.empty(Bn, device=device); rowloss = torch.empty(Bn, device=device); rowent = torch.empty(Bn, device=device)
+            _lib.call("ka_policy_loss", logits, data["masks"], data["actions"], data["old_lp"], data["adv"], idx, dlogits, new_lp,
+                      rowloss, rowent, self.flags, None, 0.2, 1.0 / Bn, 0.01 / Bn, Bn, A, 0, sp)
+            dv = (2.0 * 1.5 / Bn) * (value.detach() - returns[idx].unsqueeze(1))          # d(1.5 * MSE)/dv: (B, 1) scalars
+            self.optimizer.zero_grad(set_to_none=True)
+            torch.autograd.backward([logits, value], [dlogits, dv])
+            st = self.st
+            tab = self._upload_table(st, device)
+            _lib.call("ka_clip_adam_step", tab, st["blk_t"], st["blk_o"], st["nblocks"], st["partial"], st["ctl"], st["step_dev"],
+                      None, self.flags, self.acc[4:5], 1.0, 2e-4, 0.9, 0.999, 1e-8, sp)
+            model._hip_engine.notify_weights_updated()
+
+    step = Step()
+    perm = torch.randperm(total, device=device)
+    nmb = total // B
+    print(f"[bench] transformer d={d} h={H} L={L}: {n_params / 1e6:.1f} M parameters, {args.warmup} warm-up + {args.steps} timed steps",
+          file=sys.stderr, flush=True)
+    for i in range(args.warmup):
+        step(perm[(i % nmb) * B:(i % nmb + 1) * B])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        j = (args.warmup + i) % nmb
+        step(perm[j * B:(j + 1) * B])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    flags = step.flags.cpu().tolist()
+    M = B * 81
+    lin = 2.0 * M * (64 * d + L * (3 * d * d + d * d + 8 * d * d)) + 2.0 * B * 81 * d * 11259
+    attn = L * 4.0 * B * H * 81 * 81 * (d // H)
+    flop_step = 3.0 * (lin + attn)
+    out = {"metric": "PPO samples/sec, transformer d256 h8 L6 on 50x9x9", "value": round(B * args.steps / elapsed, 1), "unit": "samples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"transformer d_model {d}, nhead {H}, {L} layers ({n_params / 1e6:.0f} M parameters, 233 M of them "
+                                  f"the 81*d -> 11259 policy layer), minibatch {B}, clip loss + value MSE + backward + clip + Adam, "
+                                  "train mode (dropout 0.1)", "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1"},
+           "roofline": {"bound": "mfma", "kernel": "whole step (linear layers + attention on the matrix cores)",
+                        "achieved": round(flop_step / (elapsed / args.steps) / 1e12, 1),
+                        "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flop_step / (elapsed / args.steps) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+                        "traffic": None, "flop_per_step": flop_step},
+           "guard_flags": flags, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def run_workload(args, dtype, steps, warmup, device, rank, world, dev_index, events_steps):
     """Build the model + synthetic epoch, run `warmup` untimed and `steps` timed minibatch steps of the product path
     (barrier + synchronize on both sides, MAX over ranks), then -- OUTSIDE the timed region -- `events_steps` more steps
@@ -276,7 +357,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="40x256", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="40x256", choices=sorted(WORKLOADS) + ["transformer"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="override the minibatch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -307,6 +388,11 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == "transformer":
+        if world > 1:
+            raise SystemExit("the transformer workload is a single-GPU bench line (BASELINE configs[4])")
+        run_transformer(args, device)
+        return
     if args.dist_dry_run:
         counts = {"syncbn": 0, "gradient": 0, "other": 0}
         real = dist.all_reduce

@@ -264,7 +264,7 @@ int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
 int ka_tf_gemm_nt_slabs(int K, int nsplit);
 int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream);
 int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream);
-/* x[b,s,:] += row_embed[s/9] + col_embed[s%9] (transformer.py:84-87) and the embedding gradients (scratch: 81*d floats) */
+/* x[b,s,:] += row_embed[s/9] + col_embed[s%9] (transformer.py:84-87) and the embedding gradients (scratch: 65*81*d floats) */
 int ka_tf_add_pos(void* x, const float* row_embed, const float* col_embed, int B, int d, int dtype, void* stream);
 int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float* dcol, int B, int d, int dtype, void* stream);
 /* nn.LayerNorm(d) (eps 1e-5) forward / backward; part: (ka_tf_layernorm_parts(M) + 1) * 2 * d floats; dx = LN'(dy) + dres */

@@ -157,6 +157,37 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
         if (n < N && m < ldo) out[(size_t)n * ldo + m] = f2bf(tile[tx][ty + k]);
     }
 }
+// bf16 -> bf16, N % 8 == 0, ldi % 8 == 0, ldo % 8 == 0: 64 x 64 tiles, every global access a 16-byte piece (the weight-
+// gradient GEMMs transpose two activation tensors per linear layer: the scalar form above cost 10 % of a step)
+__global__ __launch_bounds__(256) void transpose_pad_bf16v_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                                  int M, int N, int ldi, int ldo) {
+    __shared__ uint16_t tile[64][64 + 2];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (tid >> 3) + 32 * h, pc = tid & 7;            // row m, 8 columns n
+        const int m = m0 + row, n = n0 + pc * 8;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (m < M && n < N) v = *reinterpret_cast<const uint4*>(in + (size_t)m * ldi + n);
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[row][pc * 8 + k] = e[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = (tid >> 3) + 32 * h, pc = tid & 7;            // output row n, 8 columns m
+        const int n = n0 + col, m = m0 + pc * 8;
+        if (n < N && m < ldo) {
+            uint4 v;
+            uint16_t* e = reinterpret_cast<uint16_t*>(&v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = tile[pc * 8 + k][col];
+            *reinterpret_cast<uint4*>(out + (size_t)n * ldo + m) = v;
+        }
+    }
+}
 
 // bf16 copy with zero-padded rows: out[m][0:ldo] = in[m][0:N] | 0
 template <typename T>
@@ -178,14 +209,15 @@ __global__ void add_pos_kernel(T* __restrict__ x, const float* __restrict__ rowe
         stT<T>(x, i, ldT<T>(x, i) + rowe[(s / 9) * d + c] + cole[(s % 9) * d + c]);
     }
 }
-// dpos[s, c] = sum_b dx[b, s, c] (fixed order over b: deterministic); one thread per (s, c)
+// part[z][s, c] = sum over the z-th range of boards of dx[b, s, c] (fixed order); summed over z by sum_parts_kernel
 template <typename T>
-__global__ void pos_grad_kernel(const T* __restrict__ dx, float* __restrict__ dpos, int B, int d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void pos_grad_kernel(const T* __restrict__ dx, float* __restrict__ part, int B, int d, int nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.y;
     if (i >= 81 * d) return;
+    const int per = (B + nz - 1) / nz, lo = z * per, hi = min(B, lo + per);
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += ldT<T>(dx, (size_t)b * 81 * d + i);
-    dpos[i] = s;
+    for (int b = lo; b < hi; ++b) s += ldT<T>(dx, (size_t)b * 81 * d + i);
+    part[(size_t)z * 81 * d + i] = s;
 }
 // drow[r, c] = sum_col dpos[r*9+col, c]; dcol[col, c] = sum_r dpos[r*9+col, c]
 __global__ void pos_grad_fold_kernel(const float* __restrict__ dpos, float* __restrict__ drow, float* __restrict__ dcol, int d) {
@@ -258,7 +290,15 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, float* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nparts; ++p) s += part[(size_t)p * n + i];
     out[i] = s;
 }
 
@@ -285,7 +325,15 @@ __global__ void colsum_T_kernel(const T* __restrict__ a, float* __restrict__ par
     if (n >= N) return;
     const long long per = (M + nsplit - 1) / nsplit, lo = s * per, hi = min(M, lo + per);
     float acc = 0.f;
-    for (long long m = lo; m < hi; ++m) acc += ldT<T>(a, (size_t)m * N + n);
+    long long m = lo;
+    for (; m + 8 <= hi; m += 8) {             // eight rows requested before the first is added (same order of additions)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ldT<T>(a, (size_t)(m + u) * N + n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; m < hi; ++m) acc += ldT<T>(a, (size_t)m * N + n);
     part[(size_t)s * N + n] = acc;
 }
 // pooled[b, c] = mean_s x[b, s, c]; backward: dx[b, s, c] += dpooled[b, c] / 81 (+ dflat[b, s*d + c] when given)
@@ -385,14 +433,37 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(AttnArgs a) {
     E* K = Q + kSP * ldq;                        // [96][ldq]
     E* Vt = K + kSP * ldq;                       // [NP][ldv]   V transposed: Vt[c][s]
     E* P = Vt + NP * ldv;                        // [16][ldp]   one row tile of the (dropped) probabilities
-    for (int i = lane; i < 2 * kSP * ldq + NP * ldv + 16 * ldp; i += 64) Q[i] = Mm<T>::cvt(0.f);
+    constexpr int VE = 16 / sizeof(E);       // elements per 16-byte piece (E and T have the same size)
+    {
+        uint4* z = reinterpret_cast<uint4*>(smem);
+        const int n16 = (int)((size_t)(2 * kSP * ldq + NP * ldv + 16 * ldp) * sizeof(E) / 16);
+        for (int i = lane; i < n16; i += 64) z[i] = uint4{0, 0, 0, 0};
+    }
+    __syncthreads();
     const T* base = static_cast<const T*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * dh;
-    for (int i = lane; i < kS * dh; i += 64) {
-        const int s = i / dh, c = i - s * dh;
-        const T* row = base + (size_t)s * 3 * a.d;
-        Q[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, c));
-        K[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, a.d + c));
-        Vt[c * ldv + s] = Mm<T>::cvt(ldT<T>(row, 2 * a.d + c));
+    if (dh % VE == 0) {
+        // 16-byte pieces: Q and K keep their layout (one 16-byte LDS store each), V is scattered into its transpose
+        const int ppr = dh / VE;
+        for (int i = lane; i < kS * ppr; i += 64) {
+            const int s = i / ppr, c0 = (i - s * ppr) * VE;
+            const T* row = base + (size_t)s * 3 * a.d + c0;
+            const uint4 qv = *reinterpret_cast<const uint4*>(row);
+            const uint4 kv = *reinterpret_cast<const uint4*>(row + a.d);
+            const uint4 vv = *reinterpret_cast<const uint4*>(row + 2 * a.d);
+            *reinterpret_cast<uint4*>(Q + s * ldq + c0) = qv;
+            *reinterpret_cast<uint4*>(K + s * ldq + c0) = kv;
+            const E* ve = reinterpret_cast<const E*>(&vv);
+#pragma unroll
+            for (int k = 0; k < VE; ++k) Vt[(c0 + k) * ldv + s] = ve[k];
+        }
+    } else {
+        for (int i = lane; i < kS * dh; i += 64) {
+            const int s = i / dh, c = i - s * dh;
+            const T* row = base + (size_t)s * 3 * a.d;
+            Q[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, c));
+            K[s * ldq + c] = Mm<T>::cvt(ldT<T>(row, a.d + c));
+            Vt[c * ldv + s] = Mm<T>::cvt(ldT<T>(row, 2 * a.d + c));
+        }
     }
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
@@ -472,15 +543,43 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(AttnArgs a) {
     E* dSt = dS + RK * ldt;                    // [96][ldc]  the same tile transposed
     E* Pdt = dSt + kSP * ldc;                  // [96][ldc]  dropped probabilities, transposed
     const int total = 4 * kSP * ldq + 3 * NP * ldt + RK * ldt + 2 * kSP * ldc;
-    for (int i = lane; i < total; i += 64) Q[i] = Mm<T>::cvt(0.f);
+    constexpr int VE = 16 / sizeof(E);
+    {
+        uint4* z = reinterpret_cast<uint4*>(smem);
+        const int n16 = (int)((size_t)total * sizeof(E) / 16);
+        for (int i = lane; i < n16; i += 64) z[i] = uint4{0, 0, 0, 0};
+    }
+    __syncthreads();
     const T* base = static_cast<const T*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * dh;
     const T* dob = static_cast<const T*>(a.dout) + (size_t)b * kS * a.d + h * dh;
-    for (int i = lane; i < kS * dh; i += 64) {
-        const int s = i / dh, c = i - s * dh;
-        const T* row = base + (size_t)s * 3 * a.d;
-        const float qv = ldT<T>(row, c), kv = ldT<T>(row, a.d + c), vv = ldT<T>(row, 2 * a.d + c), gv = ldT<T>(dob, (size_t)s * a.d + c);
-        Q[s * ldq + c] = Mm<T>::cvt(qv); K[s * ldq + c] = Mm<T>::cvt(kv); V[s * ldq + c] = Mm<T>::cvt(vv); dO[s * ldq + c] = Mm<T>::cvt(gv);
-        Qt[c * ldt + s] = Mm<T>::cvt(qv); Kt[c * ldt + s] = Mm<T>::cvt(kv); dOt[c * ldt + s] = Mm<T>::cvt(gv);
+    if (dh % VE == 0) {
+        const int ppr = dh / VE;
+        for (int i = lane; i < kS * ppr; i += 64) {
+            const int s = i / ppr, c0 = (i - s * ppr) * VE;
+            const T* row = base + (size_t)s * 3 * a.d + c0;
+            const uint4 qv = *reinterpret_cast<const uint4*>(row);
+            const uint4 kv = *reinterpret_cast<const uint4*>(row + a.d);
+            const uint4 vv = *reinterpret_cast<const uint4*>(row + 2 * a.d);
+            const uint4 gv = *reinterpret_cast<const uint4*>(dob + (size_t)s * a.d + c0);
+            *reinterpret_cast<uint4*>(Q + s * ldq + c0) = qv;
+            *reinterpret_cast<uint4*>(K + s * ldq + c0) = kv;
+            *reinterpret_cast<uint4*>(V + s * ldq + c0) = vv;
+            *reinterpret_cast<uint4*>(dO + s * ldq + c0) = gv;
+            const E* qe = reinterpret_cast<const E*>(&qv); const E* ke = reinterpret_cast<const E*>(&kv);
+            const E* ge = reinterpret_cast<const E*>(&gv);
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+                Qt[(c0 + k) * ldt + s] = qe[k]; Kt[(c0 + k) * ldt + s] = ke[k]; dOt[(c0 + k) * ldt + s] = ge[k];
+            }
+        }
+    } else {
+        for (int i = lane; i < kS * dh; i += 64) {
+            const int s = i / dh, c = i - s * dh;
+            const T* row = base + (size_t)s * 3 * a.d;
+            const float qv = ldT<T>(row, c), kv = ldT<T>(row, a.d + c), vv = ldT<T>(row, 2 * a.d + c), gv = ldT<T>(dob, (size_t)s * a.d + c);
+            Q[s * ldq + c] = Mm<T>::cvt(qv); K[s * ldq + c] = Mm<T>::cvt(kv); V[s * ldq + c] = Mm<T>::cvt(vv); dO[s * ldq + c] = Mm<T>::cvt(gv);
+            Qt[c * ldt + s] = Mm<T>::cvt(qv); Kt[c * ldt + s] = Mm<T>::cvt(kv); dOt[c * ldt + s] = Mm<T>::cvt(gv);
+        }
     }
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
@@ -619,6 +718,12 @@ extern "C" int ka_tf_gemm_nt_slabs(int K, int nsplit) {
 // weight-gradient GEMM (contraction over tokens) and of the transposed weight cache
 extern "C" int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream) {
     KA_REQUIRE(in && out && ldo >= M, "tf_transpose_pad: bad arguments");
+    if (dtype == KA_DTYPE_BF16 && N % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0) {
+        hipLaunchKernelGGL(transpose_pad_bf16v_kernel, dim3((N + 63) / 64, (ldo + 63) / 64), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(in), static_cast<uint16_t*>(out), M, N,
+                           ldi, ldo);
+        return ka_check_launch("tf_transpose_pad");
+    }
     dim3 grid((N + 31) / 32, (ldo + 31) / 32);
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                                              static_cast<const T*>(in), static_cast<uint16_t*>(out), M, N, ldi, ldo));
@@ -639,12 +744,14 @@ extern "C" int ka_tf_add_pos(void* x, const float* row_embed, const float* col_e
                                              static_cast<hipStream_t>(stream), static_cast<T*>(x), row_embed, col_embed, M, d));
     return ka_check_launch("tf_add_pos");
 }
-// scratch: 81*d floats
+// scratch: 65 * 81 * d floats
 extern "C" int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float* dcol, int B, int d, int dtype, void* stream) {
     KA_REQUIRE(dx && scratch && drow && dcol, "tf_pos_grad: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(pos_grad_kernel<T>, dim3((81 * d + 255) / 256), dim3(256), 0, st,
-                                             static_cast<const T*>(dx), scratch, B, d));
+    const int nz = B < 64 ? B : 64, n = 81 * d;
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(pos_grad_kernel<T>, dim3((n + 255) / 256, nz), dim3(256), 0, st,
+                                             static_cast<const T*>(dx), scratch + n, B, d, nz));
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch + n, scratch, nz, n);
     hipLaunchKernelGGL(pos_grad_fold_kernel, dim3((9 * d + 255) / 256), dim3(256), 0, st, scratch, drow, dcol, d);
     return ka_check_launch("tf_pos_grad");
 }

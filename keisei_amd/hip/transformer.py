@@ -111,7 +111,7 @@ class TransformerEngine:
         code = _lib.dtype_code(T)
         dy_code = _lib.DTYPE_F32 if dy_is_f32 else code
         # bias gradient
-        nsb = max(1, min(256, (M + 511) // 512))
+        nsb = max(1, min(1024, (M + 255) // 256))
         part = self._buf("colsum", nsb * N, torch.float32, dev)
         db = torch.empty(N, device=dev)
         _call("ka_tf_colsum", dy, part, db, M, N, nsb, dy_code, st)
@@ -300,7 +300,7 @@ class TransformerEngine:
             dx = dx_new
         # ---- embeddings and input projection
         drow, dcol = torch.empty(9, d, device=dev), torch.empty(9, d, device=dev)
-        _call("ka_tf_pos_grad", dx, self._buf("pos", 81 * d, torch.float32, dev), drow, dcol, B, d, code, st)
+        _call("ka_tf_pos_grad", dx, self._buf("pos", 65 * 81 * d, torch.float32, dev), drow, dcol, B, d, code, st)
         grads["row_embed.weight"], grads["col_embed.weight"] = drow, dcol
         tmp: Dict[str, torch.Tensor] = {}
         w_in = m.input_proj.weight

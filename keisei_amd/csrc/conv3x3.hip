@@ -107,6 +107,139 @@ template <> struct Mma<float> {
     }
 };
 
+// ---- epilogue, all in registers: lane (r, q) holds square mt*16+r of board bb for every row tile mt, and for
+// tile j the 4 consecutive channels cb[j] .. cb[j]+3 (tiles 2k and 2k+1 together: 8 consecutive channels)
+template <typename T, int NTW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kMTW][NTW], int bb, int nt0, int NT, int r, int q) {
+    int cb[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) cb[j] = chan_of(min(nt0 + j, NT - 1), 4 * q, NT);
+    // masked epilogue: the y pieces of the first tile pair are requested BEFORE the statistics arithmetic, which
+    // then covers their HBM latency (requesting both pairs up front spills and is slower)
+    constexpr int TP0 = NTW >= 2 ? 2 : 1;
+    typedef __attribute__((ext_vector_type(4 * TP0))) __bf16 bvec0;
+    bvec0 yv0[kMTW];
+    if constexpr (sizeof(T) == 2) {
+        if (a.ep_y) {
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                const int p = mt * 16 + r;
+                yv0[mt] = bvec0{};
+                if (p < KA_BOARD)
+                    yv0[mt] = *reinterpret_cast<const bvec0*>(static_cast<const char*>(a.ep_y) +
+                                                              ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[0]) * 2);
+            }
+        }
+    }
+    if (a.bsum || a.sqpart) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            float s0[4], ss[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] = 0.f; ss[i] = 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                const bool in = mt * 16 + r < KA_BOARD;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = in ? acc[mt][j][i] : 0.f;
+                    s0[i] += v; ss[i] += v * v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] = row_sum16(s0[i]); ss[i] = row_sum16(ss[i]); }
+            if (r == 0 && nt0 + j < NT) {
+                if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+                if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + (size_t)bb * a.Cout + cb[j]) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+            }
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (!a.ep_y) {
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                const int p = mt * 16 + r;
+                if (p >= KA_BOARD) continue;
+                char* orow = static_cast<char*>(a.out) + (size_t)(bb * KA_BOARD + p) * a.Cout * 2;
+                if constexpr (NTW >= 2) {
+#pragma unroll
+                    for (int j = 0; j < NTW; j += 2) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { o[i] = (__bf16)acc[mt][j][i]; o[4 + i] = (__bf16)acc[mt][j + 1][i]; }
+                        if (nt0 + j < NT) *reinterpret_cast<bf16x8*>(orow + cb[j] * 2) = o;
+                    }
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)acc[mt][0][i];
+                    *reinterpret_cast<bf16x4*>(orow + cb[0] * 2) = o;
+                }
+            }
+        } else {
+            // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da, one PAIR of tiles (8
+            // consecutive channels, 16-byte accesses) at a time; a lone tile (NTW == 1) uses 8-byte accesses
+            constexpr int TP = NTW >= 2 ? 2 : 1, NE = 4 * TP;
+            typedef __attribute__((ext_vector_type(NE))) __bf16 bvec;
+#pragma unroll
+            for (int j = 0; j < NTW; j += TP) {
+                if (nt0 + j >= NT) continue;
+                bvec yv[kMTW];
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const int p = mt * 16 + r;
+                    if (j == 0) { yv[mt] = yv0[mt]; continue; }
+                    yv[mt] = bvec{};
+                    if (p < KA_BOARD)
+                        yv[mt] = *reinterpret_cast<const bvec*>(static_cast<const char*>(a.ep_y) +
+                                                                ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2);
+                }
+                float esc[NE], esh[NE], emu[NE], eis[NE], t1[NE], t2[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    esc[e] = a.ep_scale[cb[j] + e]; esh[e] = a.ep_shift[cb[j] + e];
+                    emu[e] = a.ep_mean[cb[j] + e]; eis[e] = a.ep_invstd[cb[j] + e];
+                    t1[e] = 0.f; t2[e] = 0.f;
+                }
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const int p = mt * 16 + r;
+                    const bool in = p < KA_BOARD;
+                    bvec o;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const float y = (float)yv[mt][e];
+                        const __bf16 db = (__bf16)acc[mt][j + (e >> 2)][e & 3];
+                        const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                        t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
+                        o[e] = (__bf16)d;
+                    }
+                    if (in) *reinterpret_cast<bvec*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2) = o;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
+                if (r == 0) {
+#pragma unroll
+                    for (int e = 0; e < NE; e += 4) {
+                        *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
+                        *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
+                    }
+                }
+            }
+        }
+    } else {
+        float* out = static_cast<float*>(a.out);
+#pragma unroll
+        for (int mt = 0; mt < kMTW; ++mt) {
+            const int p = mt * 16 + r;
+            if (p >= KA_BOARD) continue;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                if (nt0 + j < NT) *reinterpret_cast<f32x4*>(out + (size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) = acc[mt][j];
+        }
+    }
+}
+
 // NTW = 16-channel tiles per wave (the workgroup's slab is 4*NTW tiles wide).  WM = boards (= groups of 4 waves) per
 // workgroup: 2 -> 512 threads, the second wave of every SIMD owns the second board and its MFMAs fill the first one's
 // LDS/L2 stalls; 1 -> 256 threads and two INDEPENDENT workgroups per CU (registers capped at 256 by the launch
@@ -346,138 +479,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     }
 
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 2] = __builtin_amdgcn_s_memtime();
-    // ---- epilogue, all in registers: lane (r, q) holds square mt*16+r of board bb for every row tile mt, and for
-    // tile j the 4 consecutive channels cb[j] .. cb[j]+3 (tiles 2k and 2k+1 together: 8 consecutive channels)
     const int bb = b0 + mhalf;
-    if (wave_active && bb < a.B) {
-        int cb[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) cb[j] = chan_of(min(nt0 + j, NT - 1), 4 * q, NT);
-        // masked epilogue: the y pieces of the first tile pair are requested BEFORE the statistics arithmetic, which
-        // then covers their HBM latency (requesting both pairs up front spills and is slower)
-        constexpr int TP0 = NTW >= 2 ? 2 : 1;
-        typedef __attribute__((ext_vector_type(4 * TP0))) __bf16 bvec0;
-        bvec0 yv0[kMTW];
-        if constexpr (sizeof(T) == 2) {
-            if (a.ep_y) {
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
-                    const int p = mt * 16 + r;
-                    yv0[mt] = bvec0{};
-                    if (p < KA_BOARD)
-                        yv0[mt] = *reinterpret_cast<const bvec0*>(static_cast<const char*>(a.ep_y) +
-                                                                  ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[0]) * 2);
-                }
-            }
-        }
-        if (a.bsum || a.sqpart) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                float s0[4], ss[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { s0[i] = 0.f; ss[i] = 0.f; }
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
-                    const bool in = mt * 16 + r < KA_BOARD;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = in ? acc[mt][j][i] : 0.f;
-                        s0[i] += v; ss[i] += v * v;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { s0[i] = row_sum16(s0[i]); ss[i] = row_sum16(ss[i]); }
-                if (r == 0 && nt0 + j < NT) {
-                    if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
-                    if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + (size_t)bb * a.Cout + cb[j]) = f32x4{ss[0], ss[1], ss[2], ss[3]};
-                }
-            }
-        }
-        if constexpr (sizeof(T) == 2) {
-            if (!a.ep_y) {
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
-                    const int p = mt * 16 + r;
-                    if (p >= KA_BOARD) continue;
-                    char* orow = static_cast<char*>(a.out) + (size_t)(bb * KA_BOARD + p) * a.Cout * 2;
-                    if constexpr (NTW >= 2) {
-#pragma unroll
-                        for (int j = 0; j < NTW; j += 2) {
-                            bf16x8 o;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { o[i] = (__bf16)acc[mt][j][i]; o[4 + i] = (__bf16)acc[mt][j + 1][i]; }
-                            if (nt0 + j < NT) *reinterpret_cast<bf16x8*>(orow + cb[j] * 2) = o;
-                        }
-                    } else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)acc[mt][0][i];
-                        *reinterpret_cast<bf16x4*>(orow + cb[0] * 2) = o;
-                    }
-                }
-            } else {
-                // fused  da = dh*[bn(y) > 0]  and the BatchNorm-backward partial sums of da, one PAIR of tiles (8
-                // consecutive channels, 16-byte accesses) at a time; a lone tile (NTW == 1) uses 8-byte accesses
-                constexpr int TP = NTW >= 2 ? 2 : 1, NE = 4 * TP;
-                typedef __attribute__((ext_vector_type(NE))) __bf16 bvec;
-#pragma unroll
-                for (int j = 0; j < NTW; j += TP) {
-                    if (nt0 + j >= NT) continue;
-                    bvec yv[kMTW];
-#pragma unroll
-                    for (int mt = 0; mt < kMTW; ++mt) {
-                        const int p = mt * 16 + r;
-                        if (j == 0) { yv[mt] = yv0[mt]; continue; }
-                        yv[mt] = bvec{};
-                        if (p < KA_BOARD)
-                            yv[mt] = *reinterpret_cast<const bvec*>(static_cast<const char*>(a.ep_y) +
-                                                                    ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2);
-                    }
-                    float esc[NE], esh[NE], emu[NE], eis[NE], t1[NE], t2[NE];
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        esc[e] = a.ep_scale[cb[j] + e]; esh[e] = a.ep_shift[cb[j] + e];
-                        emu[e] = a.ep_mean[cb[j] + e]; eis[e] = a.ep_invstd[cb[j] + e];
-                        t1[e] = 0.f; t2[e] = 0.f;
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < kMTW; ++mt) {
-                        const int p = mt * 16 + r;
-                        const bool in = p < KA_BOARD;
-                        bvec o;
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) {
-                            const float y = (float)yv[mt][e];
-                            const __bf16 db = (__bf16)acc[mt][j + (e >> 2)][e & 3];
-                            const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
-                            t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
-                            o[e] = (__bf16)d;
-                        }
-                        if (in) *reinterpret_cast<bvec*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) * 2) = o;
-                    }
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
-                    if (r == 0) {
-#pragma unroll
-                        for (int e = 0; e < NE; e += 4) {
-                            *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
-                            *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb[j] + e) = f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
-                        }
-                    }
-                }
-            }
-        } else {
-            float* out = static_cast<float*>(a.out);
-#pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
-                const int p = mt * 16 + r;
-                if (p >= KA_BOARD) continue;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    if (nt0 + j < NT) *reinterpret_cast<f32x4*>(out + (size_t)(bb * KA_BOARD + p) * a.Cout + cb[j]) = acc[mt][j];
-            }
-        }
-    }
+    if (wave_active && bb < a.B) conv_epilogue<T, NTW>(a, acc, bb, nt0, NT, r, q);
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
 }
 

@@ -451,15 +451,22 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_dz_kernel(
 
 // ---------------------------------------------------------------- backward tail, single pass
 // tail_bwd_reduce + the per-board squeeze-excite FC chain backward + tail_bwd_dz in ONE read of dout/out/y:
-//   du = dout*[out>0]                                          (kept in registers, with y, between the two phases)
+//   du = dout*[out>0]                                          (kept in registers between the two phases)
 //   dse[b,c] = sig'(a_c) * sum_p du*z, dse[b,C+c] = sum_p du   (z = scale*y+shift)                -> written out
 //   dh[b,j]  = [se1[b,j] > 0] * sum_k dse[b,k] * W2[k,j]       (se_fc2 backward + ReLU mask)      -> written out
 //   dsq[b,c] = sum_j dh[b,j] * W1[j,c]                         (se_fc1 backward)
 //   dz = du*sigmoid(a_c) + dsq[b,c]/81;   s1 = sum_p dz, s2 = sum_p dz*yhat
 // One workgroup per board; a thread owns one 16-byte channel piece (8 bf16 / 4 f32 channels) and every nsl-th square.
+// Everything the second phase needs from y is linear in three per-(board, channel) sums taken in the first:
+//   Sg = sum_p du, Sgy = sum_p du*(y-mean), Sy = sum_p (y-mean)     (centred on the BatchNorm mean: no cancellation)
+//   sum_p du*z = scale*Sgy + (shift + mean*scale)*Sg
+//   s1 = gate*Sg + 81*add,  s2 = invstd*(gate*Sgy + add*Sy)         (add = dsq/81)
+// so y is not kept: a board costs a thread MAXSQ 16-byte registers instead of 2*MAXSQ, which is what lets three
+// workgroups share a CU (the kernel waits on memory: more boards in flight per CU is what it needs), and the second
+// reduction through LDS is gone.
 // The FC weight gradients (dW2 = dse^T se1, dW1 = dh^T sqz) stay with the GEMM kernels, off the data-gradient chain.
 template <typename T, int MAXSQ, int NTHR>
-__global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6 ? 6 : 4))) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
     const float* __restrict__ W2, const float* __restrict__ W1, const float* __restrict__ mean,
@@ -472,49 +479,69 @@ __global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
     const int tid = threadIdx.x, b = blockIdx.x;
     const int groups = C / P16, nsl = NTHR / groups;          // channel pieces per square, square slices
     const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
-    float* red1 = lds;                       // [nsl][C]
-    float* red2 = red1 + nsl * C;            // [nsl][C]
-    float* v_dse = red2 + nsl * C;           // [2C]
+    // partial sums: the slices that share a wave are combined by lane exchanges, one LDS row per wave (per slice when a
+    // slice is wider than a wave)
+    const int rowthr = groups > 64 ? groups : 64, nrow = NTHR / rowthr;
+    float* red_g = lds;                      // [nrow][C]
+    float* red_gy = red_g + nrow * C;        // [nrow][C]
+    float* red_y = red_gy + nrow * C;        // [nrow][C]
+    float* v_dse = red_y + nrow * C;         // [2C]
     float* v_part = v_dse + 2 * C;           // [NTHR]
-    float* v_dh = v_part + NTHR;         // [H]
+    float* v_dh = v_part + NTHR;             // [H]
     float* v_dsq = v_dh + H;                 // [C]
     float* v_gate = v_dsq + C;               // [C]: sigmoid of the gate logits, one evaluation per channel
     const size_t base = (size_t)b * KA_BOARD * C + c0;
 
-    float sc[P16], sh[P16], r1[P16], r2[P16];
+    float mu[P16], sg[P16], sgy[P16], sy[P16];
 #pragma unroll
-    for (int e = 0; e < P16; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; r1[e] = 0.f; r2[e] = 0.f; }
-    vec16 du[MAXSQ], yv[MAXSQ];
+    for (int e = 0; e < P16; ++e) { mu[e] = mean[c0 + e]; sg[e] = 0.f; sgy[e] = 0.f; sy[e] = 0.f; }
+    vec16 du[MAXSQ];
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
         const int p = slice + i * nsl;
-        du[i] = vec16{}; yv[i] = vec16{};
+        du[i] = vec16{};
         if (p < KA_BOARD) {
             const vec16 g = *reinterpret_cast<const vec16*>(dout + base + (size_t)p * C);
             const vec16 o = *reinterpret_cast<const vec16*>(out + base + (size_t)p * C);
-            yv[i] = *reinterpret_cast<const vec16*>(y + base + (size_t)p * C);
+            const vec16 yv = *reinterpret_cast<const vec16*>(y + base + (size_t)p * C);
             float gf[P16], of[P16], yf[P16];
-            E::unpack(g, gf); E::unpack(o, of); E::unpack(yv[i], yf);
+            E::unpack(g, gf); E::unpack(o, of); E::unpack(yv, yf);
 #pragma unroll
             for (int e = 0; e < P16; ++e) {
+                const float yc = yf[e] - mu[e];
                 gf[e] = of[e] > 0.f ? gf[e] : 0.f;
-                r1[e] += gf[e] * (yf[e] * sc[e] + sh[e]);
-                r2[e] += gf[e];
+                sg[e] += gf[e];
+                sgy[e] += gf[e] * yc;
+                sy[e] += yc;
             }
             du[i] = E::pack(gf);             // exact: a masked copy of dout
         }
     }
+    for (int off = groups; off < 64; off <<= 1) {             // lanes cg, cg + groups, ... of a wave hold the same channels
 #pragma unroll
-    for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = r1[e]; red2[slice * C + c0 + e] = r2[e]; }
+        for (int e = 0; e < P16; ++e) {
+            sg[e] += __shfl_xor(sg[e], off); sgy[e] += __shfl_xor(sgy[e], off); sy[e] += __shfl_xor(sy[e], off);
+        }
+    }
+    if (groups >= 64 || (tid & 63) < groups) {
+        const int row = tid / rowthr;
+#pragma unroll
+        for (int e = 0; e < P16; ++e) {
+            red_g[row * C + c0 + e] = sg[e]; red_gy[row * C + c0 + e] = sgy[e]; red_y[row * C + c0 + e] = sy[e];
+        }
+    }
     __syncthreads();
     for (int c = tid; c < C; c += NTHR) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
-        const float sg = sigmoidf_(se[(size_t)b * 2 * C + c]);
-        const float d1 = t1 * sg * (1.f - sg);
-        v_gate[c] = sg;
-        v_dse[c] = d1; v_dse[C + c] = t2;
-        dse_out[(size_t)b * 2 * C + c] = d1; dse_out[(size_t)b * 2 * C + C + c] = t2;
+        float tg = 0.f, tgy = 0.f, ty = 0.f;
+        for (int s = 0; s < nrow; ++s) { tg += red_g[s * C + c]; tgy += red_gy[s * C + c]; ty += red_y[s * C + c]; }
+        red_g[c] = tg; red_gy[c] = tgy; red_y[c] = ty;        // row 0 now holds the totals (read again by this thread only)
+        const float scl = scale[c];
+        const float t1 = scl * tgy + (shift[c] + mean[c] * scl) * tg;     // sum_p du*z
+        const float sgm = sigmoidf_(se[(size_t)b * 2 * C + c]);
+        const float d1 = t1 * sgm * (1.f - sgm);
+        v_gate[c] = sgm;
+        v_dse[c] = d1; v_dse[C + c] = tg;
+        dse_out[(size_t)b * 2 * C + c] = d1; dse_out[(size_t)b * 2 * C + C + c] = tg;
     }
     __syncthreads();
     {   // dh[j] = sum_k dse[k] W2[k][j]: thread (j, part) sums every parts-th k
@@ -537,38 +564,24 @@ __global__ __launch_bounds__(NTHR) void tail_bwd_fused_kernel(
         float a = 0.f;
         for (int j = 0; j < H; ++j) a += v_dh[j] * W1[(size_t)j * C + c];
         v_dsq[c] = a;
+        const float gate = v_gate[c], add = a / KA_BOARD;
+        s1p[(size_t)b * C + c] = gate * red_g[c] + KA_BOARD * add;
+        s2p[(size_t)b * C + c] = invstd[c] * (gate * red_gy[c] + add * red_y[c]);
     }
     __syncthreads();
-    float gate[P16], add[P16], mu[P16], is[P16], a1[P16], a2[P16];
+    float gate[P16], add[P16];
 #pragma unroll
-    for (int e = 0; e < P16; ++e) {
-        gate[e] = v_gate[c0 + e];
-        add[e] = v_dsq[c0 + e] / KA_BOARD;
-        mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
-        a1[e] = 0.f; a2[e] = 0.f;
-    }
+    for (int e = 0; e < P16; ++e) { gate[e] = v_gate[c0 + e]; add[e] = v_dsq[c0 + e] / KA_BOARD; }
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
         const int p = slice + i * nsl;
         if (p < KA_BOARD) {
-            float df[P16], yf[P16];
-            E::unpack(du[i], df); E::unpack(yv[i], yf);
+            float df[P16];
+            E::unpack(du[i], df);
 #pragma unroll
-            for (int e = 0; e < P16; ++e) {
-                df[e] = df[e] * gate[e] + add[e];
-                a1[e] += df[e];
-                a2[e] += df[e] * ((yf[e] - mu[e]) * is[e]);
-            }
+            for (int e = 0; e < P16; ++e) df[e] = df[e] * gate[e] + add[e];
             *reinterpret_cast<vec16*>(dz + base + (size_t)p * C) = E::pack(df);
         }
-    }
-#pragma unroll
-    for (int e = 0; e < P16; ++e) { red1[slice * C + c0 + e] = a1[e]; red2[slice * C + c0 + e] = a2[e]; }
-    __syncthreads();
-    for (int c = tid; c < C; c += NTHR) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int s = 0; s < nsl; ++s) { t1 += red1[s * C + c]; t2 += red2[s * C + c]; }
-        s1p[(size_t)b * C + c] = t1; s2p[(size_t)b * C + c] = t2;
     }
 }
 
@@ -654,7 +667,7 @@ __global__ __launch_bounds__(kThreads) void block_dx_kernel(
 // statistics are an exact two-pass computation (sum and max first, then squared deviations and ties) with two LDS
 // combines instead of a serial Welford chain with a division per element.
 template <typename T, int MAXSQ, int NTHR>
-__global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6 || sizeof(T) == 4 ? 6 : 4))) void block_tail_fwd16_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C) {
     typedef Elem<T> E;
@@ -664,9 +677,13 @@ __global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
     const int tid = threadIdx.x, b = blockIdx.x;
     const int groups = C / P16, nsl = NTHR / groups;
     const int cg = tid % groups, slice = tid / groups, c0 = cg * P16;
-    float* redA = lds;                   // [nsl][C]
-    float* redB = redA + nsl * C;        // [nsl][C]
-    float* redC = redB + nsl * C;        // [nsl][C]
+    // partial results: the slices that share a wave are combined by lane exchanges first, one LDS row per wave (per
+    // slice when a slice is wider than a wave): a quarter of the LDS of a row per slice, so more boards fit a CU
+    const int rowthr = groups > 64 ? groups : 64, nrow = NTHR / rowthr, prow = tid / rowthr;
+    const bool writer = groups >= 64 || (tid & 63) < groups;
+    float* redA = lds;                   // [nrow][C]
+    float* redB = redA + nrow * C;       // [nrow][C]
+    float* redC = redB + nrow * C;       // [nrow][C]
     const size_t base = (size_t)b * KA_BOARD * C + c0;
     const bool raw = scale == nullptr;       // pooled statistics of y as it is (ka_pool_fwd): no transform, no store
     // v = (y*scale + shift)*gate + bias = y*ca + cb: the two per-channel coefficients (one sigmoid per channel) are
@@ -679,11 +696,11 @@ __global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
         }
         __syncthreads();
     }
-    float ca[P16], cb[P16], sum[P16], mx[P16], mn[P16];
+    float ca[P16], cb[P16], sum[P16], mx[P16];
 #pragma unroll
     for (int e = 0; e < P16; ++e) {
         ca[e] = raw ? 1.f : redA[c0 + e]; cb[e] = raw ? 0.f : redB[c0 + e];
-        sum[e] = 0.f; mx[e] = -INFINITY; mn[e] = INFINITY;
+        sum[e] = 0.f; mx[e] = -INFINITY;
     }
     if (!raw) __syncthreads();               // coefficients read before redA/redB are reused
     vec16 ov[MAXSQ];
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
                     v = rnd<T>(fmaxf(v, 0.f));
                 }
                 u[e] = v;
-                sum[e] += v; mx[e] = fmaxf(mx[e], v); mn[e] = fminf(mn[e], v);
+                sum[e] += v; mx[e] = fmaxf(mx[e], v);
             }
             ov[i] = E::pack(u);
             if (!raw) *reinterpret_cast<vec16*>(out + base + (size_t)p * C) = ov[i];
@@ -712,30 +729,36 @@ __global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
     }
     if (!pool) return;
     // combine 1 (one thread per channel, conflict-free): sum -> mean, max, min; totals go back through LDS row 0
+    for (int off = groups; off < 64; off <<= 1) {
 #pragma unroll
-    for (int e = 0; e < P16; ++e) { redA[slice * C + c0 + e] = sum[e]; redB[slice * C + c0 + e] = mx[e]; redC[slice * C + c0 + e] = mn[e]; }
+        for (int e = 0; e < P16; ++e) {
+            sum[e] += __shfl_xor(sum[e], off);
+            mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], off));
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int e = 0; e < P16; ++e) { redA[prow * C + c0 + e] = sum[e]; redB[prow * C + c0 + e] = mx[e]; }
+    }
     __syncthreads();
-    float tmean = 0.f, thi = -INFINITY, tlo = INFINITY;
+    float tmean = 0.f, thi = -INFINITY;
     for (int c = tid; c < C; c += NTHR) {
         float t = 0.f;
-        thi = -INFINITY; tlo = INFINITY;
-        for (int s2 = 0; s2 < nsl; ++s2) {
+        thi = -INFINITY;
+        for (int s2 = 0; s2 < nrow; ++s2) {
             t += redA[s2 * C + c];
             thi = fmaxf(thi, redB[s2 * C + c]);
-            tlo = fminf(tlo, redC[s2 * C + c]);
         }
         tmean = t / KA_BOARD;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += NTHR) { redA[c] = tmean; redB[c] = thi; redC[c] = tlo; }
+    for (int c = tid; c < C; c += NTHR) { redA[c] = tmean; redB[c] = thi; }
     __syncthreads();
-    float mean[P16];
-    bool flat[P16];
+    float mean[P16], tcnt[P16];
 #pragma unroll
     for (int e = 0; e < P16; ++e) {
         mean[e] = redA[c0 + e]; mx[e] = redB[c0 + e];
-        flat[e] = redB[c0 + e] == redC[c0 + e];                    // a constant plane has variance exactly 0
-        sum[e] = 0.f; mn[e] = 0.f;                                  // reused: squared deviations, tie count
+        sum[e] = 0.f; tcnt[e] = 0.f;                                // sum reused: squared deviations; tie count
     }
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
@@ -747,24 +770,30 @@ __global__ __launch_bounds__(NTHR) void block_tail_fwd16_kernel(
             for (int e = 0; e < P16; ++e) {
                 const float d = u[e] - mean[e];
                 sum[e] += d * d;
-                mn[e] += u[e] == mx[e] ? 1.f : 0.f;
+                tcnt[e] += u[e] == mx[e] ? 1.f : 0.f;
             }
         }
     }
     __syncthreads();
     // combine 2: squared deviations and tie counts (rows 1.. of redA/redB; row 0 still holds mean / max)
-    float* sqd = redC;                       // [nsl][C] (min no longer needed)
-    float* tie = redC + nsl * C;             // [nsl][C]
+    float* sqd = redC;                       // [nrow][C]
+    float* tie = redC + nrow * C;            // [nrow][C]
+    for (int off = groups; off < 64; off <<= 1) {
 #pragma unroll
-    for (int e = 0; e < P16; ++e) { sqd[slice * C + c0 + e] = flat[e] ? 0.f : sum[e]; tie[slice * C + c0 + e] = mn[e]; }
+        for (int e = 0; e < P16; ++e) { sum[e] += __shfl_xor(sum[e], off); tcnt[e] += __shfl_xor(tcnt[e], off); }
+    }
+    if (writer) {
+#pragma unroll
+        for (int e = 0; e < P16; ++e) { sqd[prow * C + c0 + e] = sum[e]; tie[prow * C + c0 + e] = tcnt[e]; }
+    }
     __syncthreads();
     float* row = pool + (size_t)b * 4 * C;
     for (int c = tid; c < C; c += NTHR) {
         float m2 = 0.f, ties = 0.f;
-        for (int s2 = 0; s2 < nsl; ++s2) { m2 += sqd[s2 * C + c]; ties += tie[s2 * C + c]; }
+        for (int s2 = 0; s2 < nrow; ++s2) { m2 += sqd[s2 * C + c]; ties += tie[s2 * C + c]; }
         row[c] = redA[c];
         row[C + c] = redB[c];
-        row[2 * C + c] = sqrtf(m2 / KA_BOARD);
+        row[2 * C + c] = ties == (float)KA_BOARD ? 0.f : sqrtf(m2 / KA_BOARD);   // every square at the max: a constant plane has variance exactly 0
         row[3 * C + c] = ties;
     }
 }
@@ -985,7 +1014,8 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
     const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
     if (nsq > 0 && nsq <= 11 && B > 0) {
         const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
-        const size_t lds = (size_t)4 * (nt / (C / p16)) * C * sizeof(float);
+        const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
+        const size_t lds = (size_t)4 * nrow * C * sizeof(float);
 #define KA_TAILF_LAUNCH(MAXSQ, NTHR) \
         KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
                                                 (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C))
@@ -1009,7 +1039,8 @@ extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, 
     const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
     if (nsq > 0 && nsq <= 11 && B > 0) {
         const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
-        const size_t lds = (size_t)4 * (nt / (C / p16)) * C * sizeof(float);
+        const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
+        const size_t lds = (size_t)4 * nrow * C * sizeof(float);
 #define KA_POOL_LAUNCH(MAXSQ, NTHR) \
         KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
                                                 (const T*)x, nullptr, nullptr, nullptr, nullptr, (T*)nullptr, pool, C))
@@ -1080,8 +1111,9 @@ extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nt = 0;
     const int nsq = tail_fused_plan(C, H, dtype, &nt);
-    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, nsl = nt / (C / p16);
-    const size_t lds = ((size_t)2 * nsl * C + 2 * C + nt + H + 2 * C) * sizeof(float);
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+    const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
+    const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 2 * C) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
 #define KA_TAIL_LAUNCH(MAXSQ, NTHR) \
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \

@@ -293,7 +293,10 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     const bool wave_active = nt0 < NT;
 
     const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 0] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0) {
+        a.stamps[wg_lin * 8 + 0] = __builtin_amdgcn_s_memtime();
+        a.stamps[wg_lin * 8 + 3] = __builtin_amdgcn_s_memrealtime();      // 100 MHz: with slot 4, the clock the kernel held
+    }
     const int nchunks = a.Cin / a.KC;
     for (int kc = 0; kc < nchunks; ++kc) {
         if (kc > 0) __syncthreads();
@@ -482,7 +485,10 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 2] = __builtin_amdgcn_s_memtime();
     const int bb = b0 + mhalf;
     if (wave_active && bb < a.B) conv_epilogue<T, NTW>(a, acc, bb, nt0, NT, r, q);
-    if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0) {
+        a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
+        a.stamps[wg_lin * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Pack (Co,Ci,3,3) fp32 weights into MFMA fragment order.
@@ -654,7 +660,7 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
     return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
 }
 
-// diagnostic: stamps != null makes every conv3x3 workgroup record 4 s_memtime values (100 MHz ticks are NOT used:
+// diagnostic: stamps != null makes every conv3x3 workgroup record 4 s_memtime values and 2 s_memrealtime values (100 MHz ticks are NOT used:
 // s_memtime counts shader clocks); pass null to switch off
 extern "C" int ka_debug_conv_stamps(unsigned long long* stamps) { g_stamps.store(stamps); return KA_OK; }
 

@@ -43,10 +43,12 @@ PEAK_HBM_GBS = 8000.0
 
 
 def kernel_source_id() -> str:
-    """sha256[:16] over the HIP sources the library is built from: ties a counter profile under profiles/ to a build."""
+    """sha256[:16] over the HIP sources the roofline kernel (conv3x3_kernel) is built from: ties a counter profile under
+    profiles/ to the build of that kernel."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted((ROOT / "keisei_amd" / "csrc").glob("*.h*")):
+    for name in ("common.h", "conv3x3.hip", "conv_g.h", "conv_g.hip"):
+        f = ROOT / "keisei_amd" / "csrc" / name
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

@@ -490,11 +490,14 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
     float* v_dh = v_part + NTHR;             // [H]
     float* v_dsq = v_dh + H;                 // [C]
     float* v_gate = v_dsq + C;               // [C]: sigmoid of the gate logits, one evaluation per channel
+    float* v_mu = v_gate + C;                // [C]: BatchNorm mean (read per square: eight registers fewer across the loop)
     const size_t base = (size_t)b * KA_BOARD * C + c0;
 
-    float mu[P16], sg[P16], sgy[P16], sy[P16];
+    for (int c = tid; c < C; c += NTHR) v_mu[c] = mean[c];
+    float sg[P16], sgy[P16], sy[P16];
 #pragma unroll
-    for (int e = 0; e < P16; ++e) { mu[e] = mean[c0 + e]; sg[e] = 0.f; sgy[e] = 0.f; sy[e] = 0.f; }
+    for (int e = 0; e < P16; ++e) { sg[e] = 0.f; sgy[e] = 0.f; sy[e] = 0.f; }
+    __syncthreads();
     vec16 du[MAXSQ];
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
             E::unpack(g, gf); E::unpack(o, of); E::unpack(yv, yf);
 #pragma unroll
             for (int e = 0; e < P16; ++e) {
-                const float yc = yf[e] - mu[e];
+                const float yc = yf[e] - v_mu[c0 + e];
                 gf[e] = of[e] > 0.f ? gf[e] : 0.f;
                 sg[e] += gf[e];
                 sgy[e] += gf[e] * yc;
@@ -1113,7 +1116,7 @@ extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* 
     const int nsq = tail_fused_plan(C, H, dtype, &nt);
     const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
     const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
-    const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 2 * C) * sizeof(float);
+    const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 3 * C) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
 #define KA_TAIL_LAUNCH(MAXSQ, NTHR) \
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \

@@ -4,8 +4,8 @@ set -e
 other=$1; steps=${2:-8}
 mkdir -p gpurun_out
 for round in 1 2; do
-  KEISEI_AMD_LIB=$other timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline > gpurun_out/ab_other_$round.json 2> gpurun_out/ab_other_$round.err
-  timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline > gpurun_out/ab_this_$round.json 2> gpurun_out/ab_this_$round.err
+  KEISEI_AMD_LIB=$other timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-fp32 > gpurun_out/ab_other_$round.json 2> gpurun_out/ab_other_$round.err
+  timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-fp32 > gpurun_out/ab_this_$round.json 2> gpurun_out/ab_this_$round.err
 done
 python - <<'PY'
 import json

@@ -4,7 +4,7 @@
 //   tokens (B*81, d) row-major, activations bf16 (AMP) or fp32 (parity mode)
 //
 // Kernels here:
-//   * gemm_nt_bf16_kernel   C = A * B^T on v_mfma_f32_16x16x32_bf16 (both operands K-contiguous), 128x128x32 LDS tiles,
+//   * gemm_nt_bf16_kernel   C = A * B^T on v_mfma_f32_16x16x32_bf16 (both operands K-contiguous), 128x128x64 LDS tiles,
 //                           register prefetch of the next K tile; epilogue bias / ReLU / dropout / residual; split-K
 //                           slabs.  Forward (B = weight), input gradient (B = transposed weight copy) and weight
 //                           gradient (A, B = transposed activations) are all this one form -- the transposed bf16
@@ -21,13 +21,21 @@
 namespace {
 
 // ------------------------------------------------------------------ dropout: counter-based keep mask
-// keep(element) = hash(seed, site, index) >= p * 2^32.  Recomputed wherever it is needed (forward epilogues, backward).
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-    return (uint32_t)x;
+// keep(element) = 16 bits of hash32(seed, index >> 1) >= p * 2^16: one 32-bit hash (two multiplies) serves the two
+// elements of an index pair, so the epilogues and elementwise kernels that own runs of consecutive elements pay half a
+// hash per element (the 64-bit mixer used before cost more than the 16 MFMAs of a 128x128x32 GEMM step per output
+// tile).  Recomputed wherever it is needed (forward epilogues, backward); never stored.  p is realised to 2^-16.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
 }
+__device__ __forceinline__ uint32_t drop_thresh(float p) { return p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u; }
 __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long index, uint32_t thresh, float inv_keep) {
-    return mix32(seed + index * 0x9E3779B97F4A7C15ULL) >= thresh ? inv_keep : 0.f;
+    const unsigned long long pair = index >> 1;
+    const uint32_t key = (uint32_t)seed * 0x9E3779B1U + (uint32_t)(seed >> 32) * 0x85EBCA6BU;      // uniform
+    const uint32_t h = hash32((uint32_t)pair * 0x9E3779B1U + (uint32_t)(pair >> 32) * 0xC2B2AE35U + key);
+    const uint32_t bits = (index & 1) ? (h >> 16) : (h & 0xFFFFu);
+    return bits >= thresh ? inv_keep : 0.f;
 }
 
 template <typename T> __device__ __forceinline__ float ldT(const T* p, size_t i);
@@ -46,33 +54,39 @@ struct NtArgs {
     float drop_p; unsigned long long seed;     // dropout on the (bias, relu)'d value before the residual add
 };
 
-constexpr int kBM = 128, kBN = 128, kBK = 32, kLdsStride = kBK * 2 + 16;     // bytes per tile row (80: conflict-light)
+constexpr int kBM = 128, kBN = 128, kBK = 64, kLdsStride = kBK * 2 + 16;     // bytes per tile row (144: 16 rows x 16 B land on 64 different banks)
 
+// 128x128x64 tiles, 256 threads (wave = 64x64 of the tile: 16 accumulator tiles), register-staged double buffering: the
+// global loads of k-tile t+1 are in flight during the 32 MFMAs of k-tile t, one barrier per k-tile.  K is a multiple of
+// 32; a trailing half tile is zero-filled.  Epilogue: a lane owns 4 consecutive columns of a row in every accumulator
+// tile, so bias / residual / output move as 16- or 8-byte pieces when N and ldc allow it (vec4).
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
-    __shared__ __attribute__((aligned(16))) char As[2][kBM * kLdsStride];
-    __shared__ __attribute__((aligned(16))) char Bs[2][kBN * kLdsStride];
+    extern __shared__ __attribute__((aligned(16))) char nt_smem[];
+    auto As = [&](int buf) { return nt_smem + buf * (kBM * kLdsStride); };
+    auto Bs = [&](int buf) { return nt_smem + 2 * kBM * kLdsStride + buf * (kBN * kLdsStride); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
     const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
-    // staging role: 128 rows x 4 pieces (16 B) per operand tile = 512 pieces, two per thread
-    const int srow = tid >> 2, spc = tid & 3;
-    uint4 ra[2], rb[2];
+    // staging role: 128 rows x 8 pieces (16 B) per operand tile = 1024 pieces, four per thread and operand
+    const int srow = tid >> 3, spc = tid & 7;
+    uint4 ra[4], rb[4];
     auto load = [&](int k0) {
+        const bool kok = k0 + spc * 8 < kend;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = srow + 64 * h;
+        for (int h = 0; h < 4; ++h) {
+            const int row = srow + 32 * h;
             const int m = m0 + row, n = n0 + row;
-            ra[h] = m < g.M ? *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + k0 + spc * 8) : uint4{0, 0, 0, 0};
-            rb[h] = n < g.N ? *reinterpret_cast<const uint4*>(g.B + (size_t)n * g.ldb + k0 + spc * 8) : uint4{0, 0, 0, 0};
+            ra[h] = (kok && m < g.M) ? *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + k0 + spc * 8) : uint4{0, 0, 0, 0};
+            rb[h] = (kok && n < g.N) ? *reinterpret_cast<const uint4*>(g.B + (size_t)n * g.ldb + k0 + spc * 8) : uint4{0, 0, 0, 0};
         }
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = srow + 64 * h;
-            *reinterpret_cast<uint4*>(As[buf] + row * kLdsStride + spc * 16) = ra[h];
-            *reinterpret_cast<uint4*>(Bs[buf] + row * kLdsStride + spc * 16) = rb[h];
+        for (int h = 0; h < 4; ++h) {
+            const int row = srow + 32 * h;
+            *reinterpret_cast<uint4*>(As(buf) + row * kLdsStride + spc * 16) = ra[h];
+            *reinterpret_cast<uint4*>(Bs(buf) + row * kLdsStride + spc * 16) = rb[h];
         }
     };
     f32x4 acc[4][4];
@@ -88,18 +102,21 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
         for (int k0 = kbeg; k0 < kend; k0 += kBK) {
             const bool more = k0 + kBK < kend;
             if (more) load(k0 + kBK);
-            bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(As[buf] + (wm * 64 + i * 16 + r) * kLdsStride + q * 16);
-                bfr[i] = *reinterpret_cast<const bf16x8*>(Bs[buf] + (wn * 64 + i * 16 + r) * kLdsStride + q * 16);
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(As(buf) + (wm * 64 + i * 16 + r) * kLdsStride + kk * 64 + q * 16);
+                    bfr[i] = *reinterpret_cast<const bf16x8*>(Bs(buf) + (wn * 64 + i * 16 + r) * kLdsStride + kk * 64 + q * 16);
+                }
+                // C^T tiles: the weight-like operand B is the MFMA "A" so that a lane holds 4 consecutive columns n of one row m
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
-            // C^T tiles: the weight-like operand B is the MFMA "A" so that a lane holds 4 consecutive columns n of one row m
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             if (more) store(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -108,7 +125,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     // epilogue: lane (r, q) of tile (i, j): row m = i*16 + r, columns n = j*16 + 4q .. +3
     const bool split = g.ksplit_len < g.K;
     const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
-    const uint32_t thresh = g.drop_p > 0.f ? (uint32_t)(g.drop_p * 4294967296.0) : 0u;
+    const uint32_t thresh = drop_thresh(g.drop_p);
+    const bool vec4 = (g.N & 3) == 0 && (g.ldc & 3) == 0;      // (the C / residual / bias bases are whole allocations)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r;
@@ -116,12 +134,42 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nb = n0 + wn * 64 + j * 16 + 4 * q;
+            if (nb >= g.N) continue;
+            const size_t ob = (size_t)m * g.ldc + nb;
+            if (vec4) {                                          // nb + 3 < N
+                f32x4 v = acc[i][j];
+                if (split) { *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + (size_t)blockIdx.z * g.M * g.ldc + ob) = v; continue; }
+                if (g.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + nb); v += bv; }
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (g.drop_p > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= keep_scale(g.seed, ob + e, thresh, inv_keep);
+                }
+                if (g.c_bf16) {
+                    if (g.residual) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const uint16_t*>(g.residual) + ob);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(static_cast<uint16_t*>(g.C) + ob) = o;
+                } else {
+                    if (g.residual) v += *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.residual) + ob);
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + ob) = v;
+                }
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nb + e;
                 if (n >= g.N) continue;
                 float v = acc[i][j][e];
-                const size_t o = (size_t)m * g.ldc + n;
+                const size_t o = ob + e;
                 if (split) { static_cast<float*>(g.C)[(size_t)blockIdx.z * g.M * g.ldc + o] = v; continue; }
                 if (g.bias) v += g.bias[n];
                 if (g.relu) v = fmaxf(v, 0.f);
@@ -307,10 +355,36 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, float* __restri
 // residual stream) and dropout backward (optionally through the ReLU that precedes the dropout)
 template <typename T>
 __global__ void drop_apply_kernel(const T* __restrict__ g_in, const T* __restrict__ act, const T* __restrict__ res,
-                                  T* __restrict__ g_out, long long n, float drop_p, unsigned long long seed) {
+                                  T* __restrict__ g_out, long long n, float drop_p, unsigned long long seed, int vec) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P = E::kPer16;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)(drop_p * 4294967296.0) : 0u;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t thresh = drop_thresh(drop_p);
+    // 16-byte pieces when every pointer is 16-byte aligned (vec); the scalar loop covers n % P, or everything
+    const size_t nv = vec ? (size_t)n / P : 0, gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    for (size_t v = gid; v < nv; v += gsz) {
+        float x[P];
+        E::unpack(*reinterpret_cast<const vec16*>(g_in + v * P), x);
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int e = 0; e < P; ++e) x[e] *= keep_scale(seed, v * P + e, thresh, inv_keep);
+        }
+        if (act) {
+            float a_[P];
+            E::unpack(*reinterpret_cast<const vec16*>(act + v * P), a_);
+#pragma unroll
+            for (int e = 0; e < P; ++e) x[e] = a_[e] > 0.f ? x[e] : 0.f;
+        }
+        if (res) {
+            float r_[P];
+            E::unpack(*reinterpret_cast<const vec16*>(res + v * P), r_);
+#pragma unroll
+            for (int e = 0; e < P; ++e) x[e] += r_[e];
+        }
+        *reinterpret_cast<vec16*>(g_out + v * P) = E::pack(x);
+    }
+    for (size_t i = nv * P + gid; i < (size_t)n; i += gsz) {
         float v = ldT<T>(g_in, i);
         if (drop_p > 0.f) v *= keep_scale(seed, i, thresh, inv_keep);
         if (act && !(ldT<T>(act, i) > 0.f)) v = 0.f;
@@ -467,7 +541,7 @@ __global__ __launch_bounds__(64) void attention_fwd_kernel(AttnArgs a) {
     }
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const uint32_t thresh = a.drop_p > 0.f ? (uint32_t)(a.drop_p * 4294967296.0) : 0u;
+    const uint32_t thresh = drop_thresh(a.drop_p);
     for (int rt = 0; rt < 6; ++rt) {
         f32x4 sc[6];
 #pragma unroll
@@ -583,7 +657,7 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(AttnArgs a) {
     }
     __syncthreads();
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const uint32_t thresh = a.drop_p > 0.f ? (uint32_t)(a.drop_p * 4294967296.0) : 0u;
+    const uint32_t thresh = drop_thresh(a.drop_p);
     constexpr int NTMAX = NT;                  // 16-wide tiles of the head dimension (dh <= 64)
     f32x4 dK[6][NTMAX], dV[6][NTMAX];          // [column tile][dh tile]: lane holds dK[col = ct*16 + r][c = nt*16 + 4q + i]
 #pragma unroll
@@ -700,17 +774,19 @@ extern "C" int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float*
     KA_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, "tf_gemm_nt: K %% 32 and lda/ldb %% 8 required (K=%d lda=%d ldb=%d)", K, lda, ldb);
     KA_REQUIRE(nsplit >= 1 && (nsplit == 1 || (!bias && !residual && !relu && !c_bf16 && drop_p == 0.f)), "tf_gemm_nt: split-K slabs carry no epilogue");
     int len = K;
-    if (nsplit > 1) { len = ((K / 32 + nsplit - 1) / nsplit) * 32; nsplit = (K + len - 1) / len; }
+    if (nsplit > 1) { len = ((K + kBK - 1) / kBK + nsplit - 1) / nsplit * kBK; nsplit = (K + len - 1) / len; }
     NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, M, N, K, lda, ldb, ldc,
              c_bf16, relu, len, drop_p, seed};
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), g);
+    static std::atomic<unsigned long long> done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel), done, "tf_gemm_nt")) return rc;
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256),
+                       2 * (kBM + kBN) * kLdsStride, static_cast<hipStream_t>(stream), g);
     return ka_check_launch("tf_gemm_nt");
 }
-// number of slabs ka_tf_gemm_nt writes for a requested split (the K ranges are whole 32-steps)
+// number of slabs ka_tf_gemm_nt writes for a requested split (the K ranges are whole 64-steps)
 extern "C" int ka_tf_gemm_nt_slabs(int K, int nsplit) {
     if (nsplit <= 1) return 1;
-    const int len = ((K / 32 + nsplit - 1) / nsplit) * 32;
+    const int len = ((K + kBK - 1) / kBK + nsplit - 1) / nsplit * kBK;
     return (K + len - 1) / len;
 }
 
@@ -786,10 +862,13 @@ extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* g
 extern "C" int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
                                 unsigned long long seed, int dtype, void* stream) {
     KA_REQUIRE(g_in && g_out && n > 0, "tf_drop_apply: bad arguments");
-    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(drop_apply_kernel<T>, dim3(grid1d((size_t)n, 4096)), dim3(256), 0,
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(g_in) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(res) |
+                           reinterpret_cast<uintptr_t>(g_out);
+    const int vec = (bits & 15) == 0;
+    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(drop_apply_kernel<T>, dim3(grid1d((size_t)n / 4, 4096)), dim3(256), 0,
                                              static_cast<hipStream_t>(stream), static_cast<const T*>(g_in),
                                              static_cast<const T*>(act), static_cast<const T*>(res), static_cast<T*>(g_out),
-                                             n, drop_p, seed));
+                                             n, drop_p, seed, vec));
     return ka_check_launch("tf_drop_apply");
 }
 // bias gradient: out[n] = sum_m a[m][n]; part: nsplit * N floats

@@ -333,6 +333,117 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * d; i += blockDim.x)
         part[(size_t)blockIdx.x * 2 * d + i] = ((sm[i] + sm[2 * d + i]) + sm[4 * d + i]) + sm[6 * d + i];
 }
+// 16-byte forms of the two kernels above for rows of L = d / (elements per 16 bytes) pieces, L a power of two <= 64
+// (d = 256: half a wave per bf16 row).  A group of L lanes owns a row and keeps its piece in registers: one read of every
+// operand, row sums by lane exchanges inside the group, and in the backward the dgamma / dbeta sums of a lane's columns
+// stay in registers over all its rows (combined across the groups of a wave by lane exchanges, across the 4 waves through
+// LDS in wave order: deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, long long M,
+                                                                int d, float eps, int L, int iters) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P = E::kPer16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / L, pl = lane - sub * L, rpw = 64 / L;
+    float gm[P], bt[P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) { gm[e] = gamma[pl * P + e]; bt[e] = beta[pl * P + e]; }
+    const float inv_d = 1.f / d;
+    for (int it = 0; it < iters; ++it) {
+        const long long row = (((long long)blockIdx.x * iters + it) * 4 + wave) * rpw + sub;
+        const bool ok = row < M;
+        float v[P];
+        if (ok) E::unpack(*reinterpret_cast<const vec16*>(x + (size_t)row * d + pl * P), v);
+        else {
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < P; ++e) s += v[e];
+        for (int off = 1; off < L; off <<= 1) s += __shfl_xor(s, off);
+        const float mu = s * inv_d;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < P; ++e) { v[e] -= mu; q2 += v[e] * v[e]; }
+        for (int off = 1; off < L; off <<= 1) q2 += __shfl_xor(q2, off);
+        const float rs = rsqrtf(q2 * inv_d + eps);
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = v[e] * rs * gm[e] + bt[e];
+            *reinterpret_cast<vec16*>(y + (size_t)row * d + pl * P) = E::pack(v);
+            if (pl == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                                T* __restrict__ dx, float* __restrict__ part, long long M, int d,
+                                                                int rows_per_block, int L) {
+    typedef Elem<T> E;
+    typedef typename E::vec16 vec16;
+    constexpr int P = E::kPer16;
+    extern __shared__ float sm[];            // [4 waves][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / L, pl = lane - sub * L, rpw = 64 / L;
+    float gm[P], dg[P], db[P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) { gm[e] = gamma[pl * P + e]; dg[e] = 0.f; db[e] = 0.f; }
+    const float inv_d = 1.f / d;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, rend = min(M, r0 + rows_per_block);
+    // (every lane of a wave runs the same number of iterations: the lane exchanges need the whole wave)
+    for (long long base = r0 + wave * rpw; base < rend; base += 4 * rpw) {
+        const long long row = base + sub;
+        const bool ok = row < rend;
+        float g[P], xh[P], dyv[P];
+        float mu = 0.f, rs = 0.f;
+        if (ok) {
+            E::unpack(*reinterpret_cast<const vec16*>(dy + (size_t)row * d + pl * P), dyv);
+            E::unpack(*reinterpret_cast<const vec16*>(x + (size_t)row * d + pl * P), xh);
+            mu = mean[row]; rs = rstd[row];
+        } else {
+#pragma unroll
+            for (int e = 0; e < P; ++e) { dyv[e] = 0.f; xh[e] = 0.f; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            xh[e] = (xh[e] - mu) * rs;
+            g[e] = dyv[e] * gm[e];
+            s1 += g[e]; s2 += g[e] * xh[e];
+        }
+        for (int off = 1; off < L; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+        s1 *= inv_d; s2 *= inv_d;
+        if (ok) {
+            float v[P];
+#pragma unroll
+            for (int e = 0; e < P; ++e) v[e] = rs * (g[e] - s1 - xh[e] * s2);
+            if (dres) {
+                float rr[P];
+                E::unpack(*reinterpret_cast<const vec16*>(dres + (size_t)row * d + pl * P), rr);
+#pragma unroll
+                for (int e = 0; e < P; ++e) v[e] += rr[e];
+            }
+            *reinterpret_cast<vec16*>(dx + (size_t)row * d + pl * P) = E::pack(v);
+#pragma unroll
+            for (int e = 0; e < P; ++e) { dg[e] += dyv[e] * xh[e]; db[e] += dyv[e]; }
+        }
+    }
+    for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) { dg[e] += __shfl_xor(dg[e], off); db[e] += __shfl_xor(db[e], off); }
+    }
+    if (lane < L) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) { sm[wave * 2 * d + pl * P + e] = dg[e]; sm[wave * 2 * d + d + pl * P + e] = db[e]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * d; i += blockDim.x)
+        part[(size_t)blockIdx.x * 2 * d + i] = ((sm[i] + sm[2 * d + i]) + sm[4 * d + i]) + sm[6 * d + i];
+}
 // out[i] = sum_p part[p][i]   (fixed order)
 __global__ void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -752,6 +863,13 @@ template <typename T> size_t attn_bwd_lds(int dh) {
     return sizeof(typename Mm<T>::elem) * (size_t)(4 * kSP * (KP + 8) + 3 * NP * (kSP + 8) + RK * (kSP + 8) + 2 * kSP * (RK + 8));
 }
 
+// lanes per row of the 16-byte LayerNorm kernels (0: use the one-wave-per-row forms)
+inline int ln_vec_lanes(int d, int dtype, uintptr_t ptr_bits) {
+    const int P = dtype == KA_DTYPE_BF16 ? 8 : 4;
+    if (d % P != 0 || (ptr_bits & 15)) return 0;
+    const int L = d / P;
+    return (L >= 1 && L <= 64 && (L & (L - 1)) == 0) ? L : 0;
+}
 inline int grid1d(size_t n, int cap) { const size_t b = (n + 255) / 256; return (int)(b < (size_t)cap ? (b ? b : 1) : cap); }
 
 }  // namespace
@@ -835,12 +953,20 @@ extern "C" int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float
 extern "C" int ka_tf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                    long long M, int d, float eps, int dtype, void* stream) {
     KA_REQUIRE(x && gamma && beta && y && mean && rstd, "tf_layernorm_fwd: null tensor");
+    if (const int L = ln_vec_lanes(d, dtype, reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y))) {
+        const int rpw = 64 / L, iters = 4;
+        const long long rows_per_block = 4LL * rpw * iters;
+        KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_fwd_vec_kernel<T>, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)),
+                                                 dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const T*>(x), gamma, beta,
+                                                 static_cast<T*>(y), mean, rstd, M, d, eps, L, iters));
+        return ka_check_launch("tf_layernorm_fwd");
+    }
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
                                              static_cast<hipStream_t>(stream), static_cast<const T*>(x), gamma, beta,
                                              static_cast<T*>(y), mean, rstd, M, d, eps));
     return ka_check_launch("tf_layernorm_fwd");
 }
-extern "C" int ka_tf_layernorm_parts(long long M) { const long long p = (M + 255) / 256; return (int)(p < 1024 ? p : 1024); }
+extern "C" int ka_tf_layernorm_parts(long long M) { const long long p = (M + 127) / 128; return (int)(p < 2048 ? p : 2048); }
 // dx = LayerNorm'(dy) [+ dres]; dgamma / dbeta [d] via part (ka_tf_layernorm_parts(M) * 2 * d floats)
 extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    const void* dres, void* dx, float* part, float* dgamma, float* dbeta, long long M, int d,
@@ -849,6 +975,12 @@ extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* g
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nparts = ka_tf_layernorm_parts(M);
     const int rpb = (int)((M + nparts - 1) / nparts);
+    if (const int L = ln_vec_lanes(d, dtype, reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) |
+                                              reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dx))) {
+        KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_vec_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
+                                                 static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
+                                                 static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb, L));
+    } else
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
                                              static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
                                              static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb));

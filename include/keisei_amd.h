@@ -262,6 +262,11 @@ int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
                   int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p, unsigned long long seed,
                   void* stream);
 int ka_tf_gemm_nt_slabs(int K, int nsplit);
+/* dW = dY^T X straight from the row-major activations (weight gradient of nn.Linear, transformer.py:40-61): C[z][N][ldc]
+ * fp32 slabs over token ranges (z < ka_tf_gemm_tn_slabs(M, nsplit); one slab = the result), A [M][lda] (N columns) and
+ * B [M][ldb] (K columns) bf16, N / K / lda / ldb multiples of 8.  Operand fragments by LDS transpose reads: no transposed copies. */
+int ka_tf_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nsplit, void* stream);
+int ka_tf_gemm_tn_slabs(int M, int nsplit);
 int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream);
 int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream);
 /* x[b,s,:] += row_embed[s/9] + col_embed[s%9] (transformer.py:84-87) and the embedding gradients (scratch: 65*81*d floats) */

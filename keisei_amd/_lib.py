@@ -73,6 +73,8 @@ _SIGS = {
     "ka_pack_mask_bits": "pp ii p",
     "ka_tf_gemm_nt": "ppppp iii iii iii f q p",
     "ka_tf_gemm_nt_slabs": "ii",
+    "ka_tf_gemm_tn": "ppp iii iii i p",
+    "ka_tf_gemm_tn_slabs": "ii",
     "ka_tf_transpose_pad": "pp iiii i p",
     "ka_tf_cast_pad": "pp q iii i p",
     "ka_tf_add_pos": "ppp ii i p",

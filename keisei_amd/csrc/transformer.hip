@@ -186,6 +186,105 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ TN GEMM: C[n][k] = sum_m A[m][n] * B[m][k]
+// The weight gradient of a linear layer (dW = dY^T X, contraction over the tokens) straight from the row-major
+// activations: [64 tokens][128 columns] tiles of both operands are staged row-major in LDS and the MFMA fragments are
+// read with the hardware transpose read (ds_read_b64_tr_b16), as wgrad.hip does for the convolutions -- no transposed
+// copy of either tensor (the NT form needed two transposes per layer: 8 % of a step).  128x128 output tile per
+// 256-thread workgroup, split over token ranges (gridDim.z fp32 slabs, reduced in a fixed order by ka_reduce_slabs).
+struct TnArgs {
+    const uint16_t* A; const uint16_t* B; float* C;      // A [M][lda] (N columns used), B [M][ldb] (K columns used), C [z][N][ldc]
+    int M, N, K, lda, ldb, ldc, msplit_len;
+};
+constexpr int kTnRows = 64, kTnStride = 128 * 2 + 32;    // 288 B: 8 consecutive rows of a transpose read spread over all banks
+typedef __attribute__((address_space(3))) bf16x4* tn_lds_ptr;
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char tn_smem[];
+    auto As = [&](int buf) { return tn_smem + buf * (2 * kTnRows * kTnStride); };
+    auto Bs = [&](int buf) { return tn_smem + buf * (2 * kTnRows * kTnStride) + kTnRows * kTnStride; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
+    const int mbeg = blockIdx.z * g.msplit_len, mend = min(g.M, mbeg + g.msplit_len);
+    // staging role: 64 rows x 16 pieces (16 B) per operand tile, four per thread and operand
+    const int srow = tid >> 4, spc = tid & 15;
+    const bool a_ok = n0 + spc * 8 < g.N, b_ok = k0 + spc * 8 < g.K;
+    uint4 ra[4], rb[4];
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int m = m0 + srow + 16 * h;
+            ra[h] = (a_ok && m < mend) ? *reinterpret_cast<const uint4*>(g.A + (size_t)m * g.lda + n0 + spc * 8) : uint4{0, 0, 0, 0};
+            rb[h] = (b_ok && m < mend) ? *reinterpret_cast<const uint4*>(g.B + (size_t)m * g.ldb + k0 + spc * 8) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int row = srow + 16 * h;
+            *reinterpret_cast<uint4*>(As(buf) + row * kTnStride + spc * 16) = ra[h];
+            *reinterpret_cast<uint4*>(Bs(buf) + row * kTnStride + spc * 16) = rb[h];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (mbeg < mend) {
+        load(mbeg);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int m0 = mbeg; m0 < mend; m0 += kTnRows) {
+            const bool more = m0 + kTnRows < mend;
+            if (more) load(m0 + kTnRows);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // MFMA k-slot (q, j) <-> tile row 4q+j (j < 4) / 16+4q+(j-4) for both operands; lane r <-> column r of the tile
+                const int row1 = kk * 32 + 4 * q + (r >> 2), row2 = row1 + 16, cl = 4 * (r & 3);
+                bf16x8 an[4], bk[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ca = (wn * 64 + i * 16 + cl) * 2, cb = (wk * 64 + i * 16 + cl) * 2;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tn_lds_ptr)(As(buf) + row1 * kTnStride + ca));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tn_lds_ptr)(As(buf) + row2 * kTnStride + ca));
+                    an[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tn_lds_ptr)(Bs(buf) + row1 * kTnStride + cb));
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tn_lds_ptr)(Bs(buf) + row2 * kTnStride + cb));
+                    bk[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[j], an[i], acc[i][j], 0, 0, 0);
+            }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // lane (r, q) of tile (i, j): row n = i*16 + r, columns k = j*16 + 4q .. +3
+    float* C = g.C + (size_t)blockIdx.z * g.N * g.ldc;
+    const bool vec4 = (g.K & 3) == 0 && (g.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + r;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kb = k0 + wk * 64 + j * 16 + 4 * q;
+            if (kb >= g.K) continue;
+            if (vec4) { *reinterpret_cast<f32x4*>(C + (size_t)n * g.ldc + kb) = acc[i][j]; continue; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kb + e < g.K) C[(size_t)n * g.ldc + kb + e] = acc[i][j][e];
+        }
+    }
+}
+
 // out[n][m] (bf16, leading dimension ldo >= M, columns M..ldo-1 zero) = in[m][n]; in is T with leading dimension ldi
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ in, uint16_t* __restrict__ out, int M, int N,
@@ -900,6 +999,28 @@ extern "C" int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float*
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256),
                        2 * (kBM + kBN) * kLdsStride, static_cast<hipStream_t>(stream), g);
     return ka_check_launch("tf_gemm_nt");
+}
+// C[z][N][ldc] (fp32 slabs, z < ka_tf_gemm_tn_slabs(M, nsplit)) = partial sums over token ranges of A^T B, A [M][lda] and
+// B [M][ldb] row-major bf16 with N resp. K columns (N, K, lda, ldb multiples of 8: 16-byte pieces).  One slab: C is the
+// result.  Replaces autograd's weight gradient of nn.Linear (transformer.py:40-61) without transposed operand copies.
+extern "C" int ka_tf_gemm_tn_slabs(int M, int nsplit) {
+    if (nsplit <= 1) return 1;
+    const int len = ((M + kTnRows - 1) / kTnRows + nsplit - 1) / nsplit * kTnRows;
+    return (M + len - 1) / len;
+}
+extern "C" int ka_tf_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nsplit,
+                             void* stream) {
+    KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "tf_gemm_tn: bad arguments");
+    KA_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N && ldb >= K && ldc >= K,
+               "tf_gemm_tn: N, K, lda, ldb must be multiples of 8 (N=%d K=%d lda=%d ldb=%d ldc=%d)", N, K, lda, ldb, ldc);
+    const int ns = ka_tf_gemm_tn_slabs(M, nsplit);
+    const int len = ns == 1 ? M : ((M + kTnRows - 1) / kTnRows + nsplit - 1) / nsplit * kTnRows;
+    TnArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, M, N, K, lda, ldb, ldc, len};
+    static std::atomic<unsigned long long> done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel), done, "tf_gemm_tn")) return rc;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((K + 127) / 128, (N + 127) / 128, ns), dim3(256), 4 * kTnRows * kTnStride,
+                       static_cast<hipStream_t>(stream), g);
+    return ka_check_launch("tf_gemm_tn");
 }
 // number of slabs ka_tf_gemm_nt writes for a requested split (the K ranges are whole 64-steps)
 extern "C" int ka_tf_gemm_nt_slabs(int K, int nsplit) {

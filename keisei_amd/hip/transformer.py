@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -118,7 +120,20 @@ class TransformerEngine:
         grads[bname] = db
         dW = torch.empty(N, K, device=dev)
         dx = None
-        if T == torch.bfloat16:
+        tn_ok = (T == torch.bfloat16 and not dy_is_f32 and N % 8 == 0 and K % 8 == 0 and x.shape[1] % 8 == 0
+                 and os.environ.get("KA_TF_TN", "1") != "0")
+        if tn_ok:
+            # weight gradient straight from the row-major activations (LDS transpose reads: no transposed copies)
+            tiles = ((N + 127) // 128) * ((K + 127) // 128)
+            want = max(1, min(M // 64, (512 + tiles - 1) // tiles))
+            ns = _lib.query("ka_tf_gemm_tn_slabs", M, want)
+            if ns == 1:
+                _call("ka_tf_gemm_tn", dy, x, dW, M, N, K, N, x.shape[1], K, 1, st)
+            else:
+                slab = self._buf("slab", ns * N * K, torch.float32, dev)
+                _call("ka_tf_gemm_tn", dy, x, slab, M, N, K, N, x.shape[1], K, want, st)
+                _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
+        if T == torch.bfloat16 and not tn_ok:
             Mp = _r32(M)
             dyT = self._buf("dyT", N * Mp, torch.bfloat16, dev)
             xT = self._buf("xT", x.shape[1] * Mp, torch.bfloat16, dev)
@@ -133,6 +148,7 @@ class TransformerEngine:
                 slab = self._buf("slab", ns * N * K, torch.float32, dev)
                 _call("ka_tf_gemm_nt", dyT, xT, slab, None, None, N, K, Mp, Mp, Mp, K, 0, 0, want, 0.0, 0, st)
                 _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
+        if T == torch.bfloat16:
             if need_dx:
                 wT16 = self._weights16(dev)[name][1]                  # [K][N32]
                 if dy_is_f32 or N % 32:

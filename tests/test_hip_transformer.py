@@ -43,6 +43,23 @@ def test_gemm_nt_bf16(M, N, K, split):
         assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,ldb,split", [(300, 200, 64, 64, 1), (130, 136, 96, 104, 1), (4097, 256, 1024, 1024, 7),
+                                             (64, 8, 8, 8, 1), (1000, 768, 256, 256, 16)])
+def test_gemm_tn_bf16(M, N, K, ldb, split):
+    """dW = dY^T X from the row-major operands (LDS transpose reads): ragged token counts, column counts that do not
+    fill a tile, padded operand rows, one slab and several."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, N, generator=g).bfloat16()
+    b = torch.randn(M, ldb, generator=g).bfloat16()
+    ref = a.float().T @ b.float()[:, :K]
+    ns = _lib.query("ka_tf_gemm_tn_slabs", M, split)
+    slab = torch.full((ns, N, K), float("nan"), device=DEV)
+    _lib.call("ka_tf_gemm_tn", a.to(DEV), b.to(DEV), slab, M, N, K, N, ldb, K, split, st())
+    torch.cuda.synchronize()
+    assert ns >= 1 and (split == 1) == (ns == 1)
+    assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(M) / 4)
+
+
 def test_transpose_and_cast_pad():
     x = torch.randn(70, 45)
     out = torch.full((45, 96), 7.0, dtype=torch.bfloat16, device=DEV)

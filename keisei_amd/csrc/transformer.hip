@@ -543,21 +543,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
     for (int i = threadIdx.x; i < 2 * d; i += blockDim.x)
         part[(size_t)blockIdx.x * 2 * d + i] = ((sm[i] + sm[2 * d + i]) + sm[4 * d + i]) + sm[6 * d + i];
 }
-// out[i] = sum_p part[p][i]   (fixed order)
-__global__ void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_p part[p][i]   (fixed order).  A 256-thread workgroup owns 32 columns: thread (column, g) sums the g-th
+// eighth of the parts in order (column-contiguous 128-byte reads), thread (column, 0) then adds the eight partials in order.
+// (One thread per column walked up to 2048 strided parts alone: 59 us for the 512 LayerNorm columns.)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    const int per = (nparts + 7) / 8, lo = g * per, hi = min(nparts, lo + per);
     float s = 0.f;
-    int p = 0;
-    for (; p + 8 <= nparts; p += 8) {
-        float v[8];
+    if (i < n) {
+        int p = lo;
+        for (; p + 8 <= hi; p += 8) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + i];
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < hi; ++p) s += part[(size_t)p * n + i];
     }
-    for (; p < nparts; ++p) s += part[(size_t)p * n + i];
-    out[i] = s;
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += red[u][col];
+        out[i] = t;
+    }
 }
 
 // ------------------------------------------------------------------ elementwise pieces of the backward
@@ -952,6 +965,262 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ bf16 attention with the operands in registers (dh <= 32)
+// One wave per (board, head), four per workgroup.  Q, K, V, dO rows are loaded from global memory straight into MFMA
+// fragments (16 bytes per lane: a row of the tile, 8 consecutive head dimensions).  The two orientations of a 16x16x32
+// MFMA give a score tile either as [query = lane r][4 keys] (operands K, Q) or as [4 queries][key = lane r] (operands
+// Q, K); in both, the four values a lane holds in two neighbouring tiles are exactly one operand fragment of the next
+// product under the k-slot permutation {4q+j, 16+4q+j} -- the permutation the LDS transpose read delivers for the other
+// operand.  So P (forward), dS and the dropped P (backward) never leave the registers; LDS holds one natural-layout
+// [96][dh] matrix at a time, read once with ds_read_b64_tr_b16 into the transposed fragments (V^T; K^T, Q^T, dO^T), 9.6 KB
+// per wave instead of 73 KB: 16 waves per CU instead of 2.  The backward computes each score / dP tile in both
+// orientations (the MFMAs are not what this kernel waits for): pass A per query tile (softmax terms, D, dQ), pass B per
+// key tile (dK, dV); D[query] travels between the passes through 96 floats of LDS.
+constexpr int kAtStride = 96;                // bytes per row of the natural-layout LDS matrix (<= 64 B of data; 32 x odd)
+constexpr int kAtWaveLds = kSP * kAtStride + kSP * 4;
+typedef __attribute__((address_space(3))) bf16x4* at_lds_ptr;
+
+struct AtCtx {
+    int lane, r, q, dh;
+    char* buf;                               // this wave's [96][kAtStride] matrix
+    // row-major fragment of row tile t, k-step ks, of a global matrix with row stride ldg (elements)
+    __device__ __forceinline__ bf16x8 frag_g(const uint16_t* base, size_t ldg, int t, int ks) const {
+        const int row = t * 16 + r, col = ks * 32 + q * 8;
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return (row < kS && col < dh) ? *reinterpret_cast<const bf16x8*>(base + (size_t)row * ldg + col) : z;
+    }
+    // natural layout into LDS: rows >= 81 and columns >= dh are zero
+    __device__ __forceinline__ void stage(const uint16_t* base, size_t ldg, int ppr) const {
+        for (int i = lane; i < kSP * ppr; i += 64) {
+            const int s = i / ppr, c0 = (i - s * ppr) * 8;
+            uint4 v = {0, 0, 0, 0};
+            if (s < kS && c0 < dh) v = *reinterpret_cast<const uint4*>(base + (size_t)s * ldg + c0);
+            *reinterpret_cast<uint4*>(buf + s * kAtStride + c0 * 2) = v;
+        }
+    }
+    // transposed fragment: column nt*16 + r of the LDS matrix at the rows (k-slots) pair*32 + {4q+j, 16+4q+j}
+    __device__ __forceinline__ bf16x8 frag_t(int pair, int nt) const {
+        const int row1 = pair * 32 + 4 * q + (r >> 2), cl = (nt * 16 + 4 * (r & 3)) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((at_lds_ptr)(buf + row1 * kAtStride + cl));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((at_lds_ptr)(buf + (row1 + 16) * kAtStride + cl));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+};
+__device__ __forceinline__ bf16x8 at_pack(const f32x4& a, const f32x4& b) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (__bf16)a[e]; v[4 + e] = (__bf16)b[e]; }
+    return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attention_fwd_reg_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
+    const int wave = threadIdx.x >> 6;
+    AtCtx c{(int)(threadIdx.x & 63), (int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), a.dh, at_smem + wave * kAtWaveLds};
+    const int r = c.r, q = c.q;
+    const int bh = min(blockIdx.x * 4 + wave, a.B * a.H - 1);      // (a surplus wave repeats the last pair: same values, same stores)
+    const int b = bh / a.H, h = bh - b * a.H;
+    const uint16_t* qb = static_cast<const uint16_t*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const size_t ldg = 3 * (size_t)a.d;
+    c.stage(qb + 2 * a.d, ldg, NT * 2);
+    bf16x8 Kf[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Kf[j] = c.frag_g(qb + a.d, ldg, j, 0);
+    __syncthreads();
+    bf16x8 Vt[3][NT];
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Vt[pr][nt] = c.frag_t(pr, nt);
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(a.drop_p);
+    uint16_t* ob = static_cast<uint16_t*>(a.out) + (size_t)b * kS * a.d + h * a.dh;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        const bf16x8 Qf = c.frag_g(qb, ldg, i, 0);
+        const int row = i * 16 + r;
+        f32x4 sc[6];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[j], Qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[j][e] = (j * 16 + 4 * q + e < kS) ? sc[j][e] * a.scale : -INFINITY;
+                mx = fmaxf(mx, sc[j][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[j][e] = __expf(sc[j][e] - mx); sum += sc[j][e]; }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+        if (q == 0 && row < kS) a.lse[((size_t)b * a.H + h) * kS + row] = mx + __logf(sum);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pv = sc[j][e] * inv;
+                if (a.drop_p > 0.f) pv *= keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + j * 16 + 4 * q + e, thresh, inv_keep);
+                sc[j][e] = pv;
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vt[pr][nt], at_pack(sc[2 * pr], sc[2 * pr + 1]), o, 0, 0, 0);
+            const int cc = nt * 16 + 4 * q;        // lane holds O[row][cc .. cc+3]
+            if (row < kS && cc < a.dh) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (__bf16)o[e];
+                *reinterpret_cast<bf16x4*>(ob + (size_t)row * a.d + cc) = ov;
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attention_bwd_reg_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
+    const int wave = threadIdx.x >> 6;
+    AtCtx c{(int)(threadIdx.x & 63), (int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), a.dh, at_smem + wave * kAtWaveLds};
+    float* Dq = reinterpret_cast<float*>(c.buf + kSP * kAtStride);          // [96]
+    const int r = c.r, q = c.q;
+    const int bh = min(blockIdx.x * 4 + wave, a.B * a.H - 1);
+    const int b = bh / a.H, h = bh - b * a.H;
+    const uint16_t* qb = static_cast<const uint16_t*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const uint16_t* gb = static_cast<const uint16_t*>(a.dout) + (size_t)b * kS * a.d + h * a.dh;
+    uint16_t* dqb = static_cast<uint16_t*>(a.dqkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const float* lse = a.lse + ((size_t)b * a.H + h) * kS;
+    const size_t ldg = 3 * (size_t)a.d;
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(a.drop_p);
+    auto store4 = [&](uint16_t* base, int row, int cc, const f32x4& v) {    // 4 consecutive head dimensions of one token
+        if (row < kS && cc < a.dh) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(base + (size_t)row * ldg + cc) = o;
+        }
+    };
+    // ---- pass A: per query tile -- D[query] and dQ
+    c.stage(qb + a.d, ldg, NT * 2);                                   // K
+    {
+        bf16x8 Kf[6], Vf[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { Kf[j] = c.frag_g(qb + a.d, ldg, j, 0); Vf[j] = c.frag_g(qb + 2 * a.d, ldg, j, 0); }
+        __syncthreads();
+        bf16x8 Kt[3][NT];
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Kt[pr][nt] = c.frag_t(pr, nt);
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+            const bf16x8 Qf = c.frag_g(qb, ldg, i, 0), Gf = c.frag_g(gb, a.d, i, 0);
+            const int row = i * 16 + r;
+            const float l = row < kS ? lse[row] : 0.f;
+            f32x4 p[6], dp[6];
+            float D = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[j], Qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[j], Gf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = j * 16 + 4 * q + e;
+                    const bool ok = col < kS && row < kS;
+                    const float pv = ok ? __expf(p[j][e] * a.scale - l) : 0.f;
+                    float m = 1.f;
+                    if (a.drop_p > 0.f) m = keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                    const float dpv = ok ? dp[j][e] * m : 0.f;         // gradient w.r.t. the un-dropped probability
+                    p[j][e] = pv; dp[j][e] = dpv;
+                    D += pv * dpv;
+                }
+            }
+            D += __shfl_xor(D, 16); D += __shfl_xor(D, 32);
+            if (q == 0) Dq[row] = D;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[j][e] = p[j][e] * (dp[j][e] - D) * a.scale;      // dS
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+                    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kt[pr][nt], at_pack(p[2 * pr], p[2 * pr + 1]), o, 0, 0, 0);
+                store4(dqb, row, nt * 16 + 4 * q, o);                   // dQ[row][nt*16 + 4q ..]
+            }
+        }
+    }
+    // ---- pass B: per key tile -- dK and dV (scores in the other orientation: lane = [4 queries][key r])
+    __syncthreads();                                                  // K^T fragments are in registers: the matrix may go
+    c.stage(qb, ldg, NT * 2);                                         // Q
+    bf16x8 Qf[6], Gf[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { Qf[i] = c.frag_g(qb, ldg, i, 0); Gf[i] = c.frag_g(gb, a.d, i, 0); }
+    __syncthreads();
+    bf16x8 Qt[3][NT], Gt[3][NT];
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Qt[pr][nt] = c.frag_t(pr, nt);
+    __syncthreads();
+    c.stage(gb, a.d, NT * 2);                                         // dO
+    __syncthreads();
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Gt[pr][nt] = c.frag_t(pr, nt);
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const bf16x8 Kf = c.frag_g(qb + a.d, ldg, j, 0), Vf = c.frag_g(qb + 2 * a.d, ldg, j, 0);
+        const int col = j * 16 + r;
+        f32x4 dK[NT], dV[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dK[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            f32x4 ds[2], pd[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int i = 2 * pr + hf;
+                const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qf[i], Kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gf[i], Vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = i * 16 + 4 * q + e;
+                    const bool ok = col < kS && row < kS;
+                    const float pv = ok ? __expf(s[e] * a.scale - lse[min(row, kS - 1)]) : 0.f;
+                    float m = 1.f;
+                    if (a.drop_p > 0.f) m = keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                    const float dpv = ok ? g[e] * m : 0.f;
+                    ds[hf][e] = pv * (dpv - Dq[row]) * a.scale;
+                    pd[hf][e] = pv * m;
+                }
+            }
+            const bf16x8 dsf = at_pack(ds[0], ds[1]), pdf = at_pack(pd[0], pd[1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                dK[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[pr][nt], dsf, dK[nt], 0, 0, 0);
+                dV[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gt[pr][nt], pdf, dV[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {                              // lane holds d{K,V}[key = col][nt*16 + 4q ..]
+            store4(dqb + a.d, col, nt * 16 + 4 * q, dK[nt]);
+            store4(dqb + 2 * a.d, col, nt * 16 + 4 * q, dV[nt]);
+        }
+    }
+}
+
 template <typename T> size_t attn_fwd_lds(int dh) {
     const int KP = attn_kp<T>(dh), NP = attn_np(dh);
     return sizeof(typename Mm<T>::elem) * (size_t)(2 * kSP * (KP + 8) + NP * (kSP + 8) + 16 * (kSP + 8));
@@ -1066,7 +1335,7 @@ extern "C" int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float
     const int nz = B < 64 ? B : 64, n = 81 * d;
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(pos_grad_kernel<T>, dim3((n + 255) / 256, nz), dim3(256), 0, st,
                                              static_cast<const T*>(dx), scratch + n, B, d, nz));
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch + n, scratch, nz, n);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 31) / 32), dim3(256), 0, st, scratch + n, scratch, nz, n);
     hipLaunchKernelGGL(pos_grad_fold_kernel, dim3((9 * d + 255) / 256), dim3(256), 0, st, scratch, drow, dcol, d);
     return ka_check_launch("tf_pos_grad");
 }
@@ -1106,7 +1375,7 @@ extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* g
                                              static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
                                              static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb));
     // part rows are [dgamma | dbeta]
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, part, part + (size_t)nparts * 2 * d, nparts, 2 * d);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, part + (size_t)nparts * 2 * d, nparts, 2 * d);
     (void)hipMemcpyAsync(dgamma, part + (size_t)nparts * 2 * d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dbeta, part + (size_t)nparts * 2 * d + d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
     return ka_check_launch("tf_layernorm_bwd");
@@ -1130,7 +1399,7 @@ extern "C" int ka_tf_colsum(const void* a, float* part, float* out, long long M,
     hipStream_t st = static_cast<hipStream_t>(stream);
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(colsum_T_kernel<T>, dim3((N + 255) / 256, nsplit), dim3(256), 0, st,
                                              static_cast<const T*>(a), part, M, N, nsplit));
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, out, nsplit, N);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, out, nsplit, N);
     return ka_check_launch("tf_colsum");
 }
 extern "C" int ka_tf_mean_pool(const void* x, float* pooled, int B, int d, int dtype, void* stream) {
@@ -1167,6 +1436,13 @@ extern "C" int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B
     KA_REQUIRE(qkv && out && lse && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_fwd: bad arguments (dh <= 64)");
     AttnArgs a{qkv, out, lse, nullptr, nullptr, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool reg_form = dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && !getenv("KA_TF_ATTN_LDS");
+    if (reg_form) {           // operands in registers, four (board, head) pairs per workgroup
+        const int grid = (B * H + 3) / 4;
+        if (dh <= 16) hipLaunchKernelGGL(attention_fwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        else          hipLaunchKernelGGL(attention_fwd_reg_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        return ka_check_launch("tf_attention_fwd");
+    }
     if (dtype == KA_DTYPE_BF16) {
         static std::atomic<unsigned long long> done{0};
         if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&attention_fwd_kernel<bf16_t>), done, "tf_attention_fwd")) return rc;
@@ -1184,6 +1460,12 @@ extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const floa
     AttnArgs a{qkv, nullptr, const_cast<float*>(lse), dout, dqkv, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = attn_np(dh) / 16;
+    if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && !getenv("KA_TF_ATTN_LDS")) {
+        const int grid = (B * H + 3) / 4;
+        if (dh <= 16) hipLaunchKernelGGL(attention_bwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        else          hipLaunchKernelGGL(attention_bwd_reg_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        return ka_check_launch("tf_attention_bwd");
+    }
 #define KA_ATTN_BWD(T_, NT_)                                                                                              \
     do {                                                                                                                  \
         static std::atomic<unsigned long long> done{0};                                                                   \

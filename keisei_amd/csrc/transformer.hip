@@ -30,6 +30,12 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ uint32_t drop_thresh(float p) { return p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u; }
+// the same mask for indices below 2^32, on 32-bit arithmetic (key = drop_key(seed), computed once)
+__device__ __forceinline__ uint32_t drop_key(unsigned long long seed) { return (uint32_t)seed * 0x9E3779B1U + (uint32_t)(seed >> 32) * 0x85EBCA6BU; }
+__device__ __forceinline__ float keep_scale32(uint32_t key, uint32_t index, uint32_t thresh, float inv_keep) {
+    const uint32_t h = hash32((index >> 1) * 0x9E3779B1U + key);
+    return ((index & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thresh ? inv_keep : 0.f;
+}
 __device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long index, uint32_t thresh, float inv_keep) {
     const unsigned long long pair = index >> 1;
     const uint32_t key = (uint32_t)seed * 0x9E3779B1U + (uint32_t)(seed >> 32) * 0x85EBCA6BU;      // uniform
@@ -1034,7 +1040,7 @@ __global__ __launch_bounds__(256) void attention_fwd_reg_kernel(AttnArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) Vt[pr][nt] = c.frag_t(pr, nt);
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const uint32_t thresh = drop_thresh(a.drop_p);
+    const uint32_t thresh = drop_thresh(a.drop_p), dkey = drop_key(a.seed), ibase = (uint32_t)bh * kSP * kSP;
     uint16_t* ob = static_cast<uint16_t*>(a.out) + (size_t)b * kS * a.d + h * a.dh;
 #pragma unroll 1
     for (int i = 0; i < 6; ++i) {
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(256) void attention_fwd_reg_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pv = sc[j][e] * inv;
-                if (a.drop_p > 0.f) pv *= keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + j * 16 + 4 * q + e, thresh, inv_keep);
+                if (a.drop_p > 0.f) pv *= keep_scale32(dkey, ibase + row * kSP + j * 16 + 4 * q + e, thresh, inv_keep);
                 sc[j][e] = pv;
             }
 #pragma unroll
@@ -1086,7 +1092,7 @@ __global__ __launch_bounds__(256) void attention_fwd_reg_kernel(AttnArgs a) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attention_bwd_reg_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attention_bwd_reg_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
     const int wave = threadIdx.x >> 6;
     AtCtx c{(int)(threadIdx.x & 63), (int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), a.dh, at_smem + wave * kAtWaveLds};
@@ -1100,7 +1106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const float* lse = a.lse + ((size_t)b * a.H + h) * kS;
     const size_t ldg = 3 * (size_t)a.d;
     const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    const uint32_t thresh = drop_thresh(a.drop_p);
+    const uint32_t thresh = drop_thresh(a.drop_p), dkey = drop_key(a.seed), ibase = (uint32_t)bh * kSP * kSP;
     auto store4 = [&](uint16_t* base, int row, int cc, const f32x4& v) {    // 4 consecutive head dimensions of one token
         if (row < kS && cc < a.dh) {
             bf16x4 o;
@@ -1112,9 +1118,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // ---- pass A: per query tile -- D[query] and dQ
     c.stage(qb + a.d, ldg, NT * 2);                                   // K
     {
-        bf16x8 Kf[6], Vf[6];
+        bf16x8 Kf[6];                                                  // (V fragments are fetched per tile: cache-resident)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { Kf[j] = c.frag_g(qb + a.d, ldg, j, 0); Vf[j] = c.frag_g(qb + 2 * a.d, ldg, j, 0); }
+        for (int j = 0; j < 6; ++j) Kf[j] = c.frag_g(qb + a.d, ldg, j, 0);
         __syncthreads();
         bf16x8 Kt[3][NT];
 #pragma unroll
@@ -1131,14 +1137,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 p[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[j], Qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[j], Gf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.frag_g(qb + 2 * a.d, ldg, j, 0), Gf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int col = j * 16 + 4 * q + e;
                     const bool ok = col < kS && row < kS;
                     const float pv = ok ? __expf(p[j][e] * a.scale - l) : 0.f;
                     float m = 1.f;
-                    if (a.drop_p > 0.f) m = keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                    if (a.drop_p > 0.f) m = keep_scale32(dkey, ibase + row * kSP + col, thresh, inv_keep);
                     const float dpv = ok ? dp[j][e] * m : 0.f;         // gradient w.r.t. the un-dropped probability
                     p[j][e] = pv; dp[j][e] = dpv;
                     D += pv * dpv;
@@ -1163,11 +1169,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // ---- pass B: per key tile -- dK and dV (scores in the other orientation: lane = [4 queries][key r])
     __syncthreads();                                                  // K^T fragments are in registers: the matrix may go
     c.stage(qb, ldg, NT * 2);                                         // Q
-    bf16x8 Qf[6], Gf[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { Qf[i] = c.frag_g(qb, ldg, i, 0); Gf[i] = c.frag_g(gb, a.d, i, 0); }
     __syncthreads();
-    bf16x8 Qt[3][NT], Gt[3][NT];
+    bf16x8 Qt[3][NT], Gt[3][NT];                                      // (row-major Q / dO fragments are fetched per tile)
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
@@ -1192,15 +1195,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int i = 2 * pr + hf;
-                const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qf[i], Kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gf[i], Vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.frag_g(qb, ldg, i, 0), Kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.frag_g(gb, a.d, i, 0), Vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = i * 16 + 4 * q + e;
                     const bool ok = col < kS && row < kS;
                     const float pv = ok ? __expf(s[e] * a.scale - lse[min(row, kS - 1)]) : 0.f;
                     float m = 1.f;
-                    if (a.drop_p > 0.f) m = keep_scale(a.seed, ((unsigned long long)bh * kSP + row) * kSP + col, thresh, inv_keep);
+                    if (a.drop_p > 0.f) m = keep_scale32(dkey, ibase + row * kSP + col, thresh, inv_keep);
                     const float dpv = ok ? g[e] * m : 0.f;
                     ds[hf][e] = pv * (dpv - Dq[row]) * a.scale;
                     pd[hf][e] = pv * m;
@@ -1436,7 +1439,8 @@ extern "C" int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B
     KA_REQUIRE(qkv && out && lse && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_fwd: bad arguments (dh <= 64)");
     AttnArgs a{qkv, out, lse, nullptr, nullptr, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool reg_form = dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && !getenv("KA_TF_ATTN_LDS");
+    const bool reg_form = dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
+                          !getenv("KA_TF_ATTN_LDS");
     if (reg_form) {           // operands in registers, four (board, head) pairs per workgroup
         const int grid = (B * H + 3) / 4;
         if (dh <= 16) hipLaunchKernelGGL(attention_fwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
@@ -1460,7 +1464,8 @@ extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const floa
     AttnArgs a{qkv, nullptr, const_cast<float*>(lse), dout, dqkv, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = attn_np(dh) / 16;
-    if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && !getenv("KA_TF_ATTN_LDS")) {
+    if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
+        !getenv("KA_TF_ATTN_LDS")) {
         const int grid = (B * H + 3) / 4;
         if (dh <= 16) hipLaunchKernelGGL(attention_bwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
         else          hipLaunchKernelGGL(attention_bwd_reg_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);

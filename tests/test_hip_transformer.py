@@ -129,6 +129,32 @@ def test_attention_forward_backward(dt, H, dh):
     assert err < (2e-5 if dt == torch.float32 else 2e-2), err
 
 
+@pytest.mark.parametrize("H,dh,p", [(8, 32, 0.1), (4, 8, 0.3), (3, 16, 0.0)])
+def test_register_attention_equals_the_lds_form(monkeypatch, H, dh, p):
+    """bf16, head dimension <= 32: the register-resident kernels (the default) against the LDS-tile kernels
+    (KA_TF_ATTN_LDS=1) on the same seed -- same dropout mask in both score orientations of the backward, same softmax."""
+    B, d, seed = 5, H * dh, 987654321
+    g = torch.Generator().manual_seed(H + dh)
+    qkv = torch.randn(B * 81, 3 * d, generator=g).bfloat16().to(DEV)
+    dout = torch.randn(B * 81, d, generator=g).bfloat16().to(DEV)
+    res = {}
+    for form in ("1", ""):
+        if form:
+            monkeypatch.setenv("KA_TF_ATTN_LDS", form)
+        else:
+            monkeypatch.delenv("KA_TF_ATTN_LDS")
+        out = torch.full((B * 81, d), float("nan"), dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, H, 81, device=DEV)
+        _lib.call("ka_tf_attention_fwd", qkv, out, lse, B, H, dh, p, seed, _lib.DTYPE_BF16, st())
+        dq = torch.full((B * 81, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.call("ka_tf_attention_bwd", qkv, dout, lse, dq, B, H, dh, p, seed, _lib.DTYPE_BF16, st())
+        torch.cuda.synchronize()
+        res[form] = (out.float().cpu(), lse.cpu(), dq.float().cpu())
+    (o0, l0, g0), (o1, l1, g1) = res["1"], res[""]
+    assert torch.allclose(l1, l0, rtol=1e-5, atol=1e-5)
+    assert float((o1 - o0).abs().max()) <= 2e-2 * float(o0.abs().max())
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-2
+
+
 def test_attention_dropout_is_consistent_between_forward_and_backward():
     """With dropout the kernel's own forward is the reference for its backward: d(sum(out * w)) / d(qkv) by central
     differences of the fp32 forward (same seed = same mask) against the backward kernel; and the mask keeps 1 - p."""

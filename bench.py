@@ -382,6 +382,8 @@ def main() -> None:
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    if args.dist_dry_run:
+        os.environ.setdefault("KA_FORCE_COLLECTIVES", "1")     # world size 1: issue every collective of the N > 1 step anyway
     if world > 1 or args.dist_dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -504,9 +504,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
         const int p = slice + i * nsl;
         du[i] = vec16{};
         if (p < KA_BOARD) {
-            const vec16 g = *reinterpret_cast<const vec16*>(dout + base + (size_t)p * C);
-            const vec16 o = *reinterpret_cast<const vec16*>(out + base + (size_t)p * C);
-            const vec16 yv = *reinterpret_cast<const vec16*>(y + base + (size_t)p * C);
+            const vec16 g = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C));
+            const vec16 o = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(out + base + (size_t)p * C));
+            const vec16 yv = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(y + base + (size_t)p * C));
             float gf[P16], of[P16], yf[P16];
             E::unpack(g, gf); E::unpack(o, of); E::unpack(yv, yf);
 #pragma unroll
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
             E::unpack(du[i], df);
 #pragma unroll
             for (int e = 0; e < P16; ++e) df[e] = df[e] * gate[e] + add[e];
-            *reinterpret_cast<vec16*>(dz + base + (size_t)p * C) = E::pack(df);
+            __builtin_nontemporal_store(E::pack(df), reinterpret_cast<vec16*>(dz + base + (size_t)p * C));
         }
     }
 }
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
         ov[i] = vec16{};
         if (p < KA_BOARD) {
             float u[P16], r[P16];
-            E::unpack(*reinterpret_cast<const vec16*>(y + base + (size_t)p * C), u);
-            if (res) E::unpack(*reinterpret_cast<const vec16*>(res + base + (size_t)p * C), r);
+            E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(y + base + (size_t)p * C)), u);
+            if (res) E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(res + base + (size_t)p * C)), r);
 #pragma unroll
             for (int e = 0; e < P16; ++e) {
                 float v = u[e];
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
                 sum[e] += v; mx[e] = fmaxf(mx[e], v);
             }
             ov[i] = E::pack(u);
-            if (!raw) *reinterpret_cast<vec16*>(out + base + (size_t)p * C) = ov[i];
+            if (!raw) __builtin_nontemporal_store(ov[i], reinterpret_cast<vec16*>(out + base + (size_t)p * C));
         }
     }
     if (!pool) return;
@@ -836,23 +836,23 @@ __global__ __launch_bounds__(NTHR) void block_dx16_kernel(
 #pragma unroll 3
     for (int p = slice; p < KA_BOARD; p += nsl) {
         float v[P16], g[P16];
-        E::unpack(*reinterpret_cast<const vec16*>(x + base + (size_t)p * C), v);
+        E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(x + base + (size_t)p * C)), v);
 #pragma unroll
         for (int e = 0; e < P16; ++e) g[e] = gm[e] + gs[e] * (v[e] - mean[e]) + (v[e] == mxx[e] ? gx[e] : 0.f);
         if (dxc) {
             float t[P16];
-            E::unpack(*reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C), t);
+            E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C)), t);
 #pragma unroll
             for (int e = 0; e < P16; ++e) g[e] += t[e];
         }
         if (dout) {
             float t[P16], o[P16];
-            E::unpack(*reinterpret_cast<const vec16*>(dout + base + (size_t)p * C), t);
-            E::unpack(*reinterpret_cast<const vec16*>(out + base + (size_t)p * C), o);
+            E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C)), t);
+            E::unpack(__builtin_nontemporal_load(reinterpret_cast<const vec16*>(out + base + (size_t)p * C)), o);
 #pragma unroll
             for (int e = 0; e < P16; ++e) g[e] += o[e] > 0.f ? t[e] : 0.f;
         }
-        *reinterpret_cast<vec16*>(dx + base + (size_t)p * C) = E::pack(g);
+        __builtin_nontemporal_store(E::pack(g), reinterpret_cast<vec16*>(dx + base + (size_t)p * C));
     }
 }
 

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                         const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
                         const size_t off = ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ;
                         if (pos < kRows && bb < a.B) {
-                            v[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) + off);
-                            w[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in2) + off);
+                            v[u] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) + off));
+                            w[u] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(static_cast<const char*>(a.in2) + off));
                         } else { v[u] = vec16{}; w[u] = vec16{}; }
                     }
 #pragma unroll
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                     const int pos = pos0 + u * sstep;
                     const int b = pos / KA_BOARD, p = pos - b * KA_BOARD, bb = b0 + b;
                     if (pos < kRows && bb < a.B)
-                        v[u] = *reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) +
-                                                               ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ);
+                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(static_cast<const char*>(a.in) +
+                                                               ((size_t)(bb * KA_BOARD + p) * a.Cin + c0) * ESZ));
                     else
                         v[u] = vec16{};
                 }

@@ -72,7 +72,18 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     auto Bs = [&](int buf) { return nt_smem + 2 * kBM * kLdsStride + buf * (kBN * kLdsStride); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (linear id L sits on XCD L % 8), each with its own
+    // L2.  The n-tiles of one m-tile read the same 128 rows of A: they are given consecutive slots of ONE XCD, so A comes
+    // from HBM once instead of once per XCD that happens to run one of its n-tiles (N = 1024: 8 n-tiles).  Placement only.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, L = by * gx + bx;
+        const int full = (gy / 8) * 8;                       // m-tiles covered by whole groups of 8
+        const int xcd = L & 7, slot = L >> 3;
+        const int mt = (slot / gx) * 8 + xcd;
+        if (L < full * gx && mt < full) { by = mt; bx = slot % gx; }
+    }
+    const int m0 = by * kBM, n0 = bx * kBN;
     const int kbeg = blockIdx.z * g.ksplit_len, kend = min(g.K, kbeg + g.ksplit_len);
     // staging role: 128 rows x 8 pieces (16 B) per operand tile = 1024 pieces, four per thread and operand
     const int srow = tid >> 3, spc = tid & 7;
@@ -211,8 +222,17 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs g) {
     auto Bs = [&](int buf) { return tn_smem + buf * (2 * kTnRows * kTnStride) + kTnRows * kTnStride; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
-    const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
-    const int mbeg = blockIdx.z * g.msplit_len, mend = min(g.M, mbeg + g.msplit_len);
+    // XCD-aware map (see gemm_nt_bf16_kernel): all output tiles of one token range read the same rows of A and B -- they
+    // are placed on ONE XCD, so each row comes from HBM once rather than once per XCD.  Placement only.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, tiles = gx * gy;
+        const int L = (bz * gy + by) * gx + bx, full = (gz / 8) * 8;
+        const int xcd = L & 7, slot = L >> 3, z2 = (slot / tiles) * 8 + xcd, t2 = slot % tiles;
+        if (L < full * tiles && z2 < full) { bz = z2; by = t2 / gx; bx = t2 - by * gx; }
+    }
+    const int n0 = by * 128, k0 = bx * 128;
+    const int mbeg = bz * g.msplit_len, mend = min(g.M, mbeg + g.msplit_len);
     // staging role: 64 rows x 16 pieces (16 B) per operand tile, four per thread and operand
     const int srow = tid >> 4, spc = tid & 15;
     const bool a_ok = n0 + spc * 8 < g.N, b_ok = k0 + spc * 8 < g.K;
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs g) {
         }
     }
     // lane (r, q) of tile (i, j): row n = i*16 + r, columns k = j*16 + 4q .. +3
-    float* C = g.C + (size_t)blockIdx.z * g.N * g.ldc;
+    float* C = g.C + (size_t)bz * g.N * g.ldc;
     const bool vec4 = (g.K & 3) == 0 && (g.ldc & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -250,6 +250,16 @@ int ka_rollout_append(const float* obs, const void* legal, const long long* acti
 int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream);
 int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A, void* stream);
 
+/* ---- the eval-mode residual tower in one launch (rollout inference, SURVEY 8 f2: katago_ppo.py:543-617 calling
+ * se_resnet.py:67-75 for every block under no_grad / eval()).  One workgroup carries one board through all blocks; the
+ * activations live in LDS.  x_in / x_out (B, 81, C) bf16, pool_in / pool_out (B, 4C) fp32 [mean|max|std|-]; blocks = device
+ * table of nblocks rows of 14 pointers: {conv1 pack, conv2 pack (ka_pack_conv3x3 mode 0), bn1 scale, bn1 shift, bn2 scale,
+ * bn2 shift (eval), global_fc[0].weight (G,3C), .bias, global_fc[2].weight (C,G), .bias, se_fc1.weight (R,C), .bias,
+ * se_fc2.weight (2C,R), .bias}. */
+int ka_tower_eval_supported(int C, int G, int R, int dtype);
+int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out, float* pool_out, const void* blocks, int nblocks, int B,
+                  int C, int G, int R, int dtype, void* stream);
+
 /* ---- transformer encoder path (BASELINE config 5; keisei/training/models/transformer.py:37-95: nn.Linear(50, d),
  * row/col nn.Embedding, nn.TransformerEncoder(nn.TransformerEncoderLayer(d, nhead, 4d, batch_first, norm_first), L),
  * nn.Linear(81 d, 11259), value head).  Tokens are (B*81, d) row-major, bf16 (autocast) or fp32 (parity mode; its linear

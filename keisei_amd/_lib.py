@@ -71,6 +71,8 @@ _SIGS = {
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",
     "ka_pack_mask_bits": "pp ii p",
+    "ka_tower_eval_supported": "iiii",
+    "ka_tower_eval": "ppppp iiiii i p",
     "ka_tf_gemm_nt": "ppppp iii iii iii f q p",
     "ka_tf_gemm_nt_slabs": "ii",
     "ka_tf_gemm_tn": "ppp iii iii i p",

@@ -60,6 +60,7 @@ class SEResNetEngine:
         self._row_ring = None
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
         self._evalc_sets = {}
+        self._tower_tabs = {}                       # pointer tables of the one-launch eval tower (kept: graphs read them)
         self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
         self._in_forward = False
@@ -165,6 +166,38 @@ class SEResNetEngine:
                   _lib.stream_ptr(device))
             ent["key"] = key
         return ent["packs"]
+
+    def _tower_table(self, T, device, packs):
+        """Device table of the one-launch eval tower (one row of 14 pointers per block), or None when that kernel does
+        not cover the configuration.  Rebuilt when any of the buffers it points at was re-allocated."""
+        m = self.model
+        if os.environ.get("KA_TOWER", "1") == "0" or self._evalc_live is None or T != torch.bfloat16:
+            return None
+        blk0 = m.blocks[0]
+        C, G, R = m.params.channels, blk0.global_fc[0].out_features, blk0.se_fc1.out_features
+        if not _lib.query("ka_tower_eval_supported", C, G, R, _lib.dtype_code(T)):
+            return None
+        rows = []
+        for i, blk in enumerate(m.blocks):
+            lins = (blk.global_fc[0], blk.global_fc[2], blk.se_fc1, blk.se_fc2)
+            if (id(blk.bn1) not in self._evalc_live or id(blk.bn2) not in self._evalc_live
+                    or any(l.bias is None or not l.weight.is_contiguous() or l.weight.dtype != torch.float32 for l in lins)):
+                return None
+            sc1, sh1 = self._evalc_live[id(blk.bn1)]
+            sc2, sh2 = self._evalc_live[id(blk.bn2)]
+            rows.append([packs[f"blocks.{i}.conv1"][0].data_ptr(), packs[f"blocks.{i}.conv2"][0].data_ptr(),
+                         sc1.data_ptr(), sh1.data_ptr(), sc2.data_ptr(), sh2.data_ptr(),
+                         lins[0].weight.data_ptr(), lins[0].bias.data_ptr(), lins[1].weight.data_ptr(), lins[1].bias.data_ptr(),
+                         lins[2].weight.data_ptr(), lins[2].bias.data_ptr(), lins[3].weight.data_ptr(), lins[3].bias.data_ptr()])
+        key = (str(device), tuple(map(tuple, rows)))
+        ent = self._tower_tabs.get(key)
+        if ent is None:
+            if len(self._tower_tabs) >= 4:               # buffers were re-allocated repeatedly: drop stale tables and
+                self._tower_tabs.clear()                 # the graphs that read them
+                self._graphs.clear()
+            ent = torch.tensor(rows, dtype=torch.int64).to(device)
+            self._tower_tabs[key] = ent
+        return ent
 
     def _eval_coeffs_all(self, device, st):
         """Eval-mode scale/shift of EVERY BatchNorm layer from the live running statistics in one launch (the rollout
@@ -437,9 +470,19 @@ class SEResNetEngine:
         sv.blocks = []
 
         # ---- tower
+        tower_tab = self._tower_table(T, dev, packs) if (not train and not keep and len(m.blocks) > 0) else None
+        if tower_tab is not None:
+            # eval mode: no tensor couples the boards, so ONE launch carries every board through all the blocks
+            # (csrc/tower.hip) instead of 2 conv + 2 FC-chain + 1 tail launch per block
+            blk0 = m.blocks[0]
+            out = new_act(C)
+            pool_out = torch.empty(B, 4 * C, device=dev)
+            _call("ka_tower_eval", x, pool, out, pool_out, tower_tab, len(m.blocks), B, C, blk0.global_fc[0].out_features,
+                  blk0.se_fc1.out_features, code, st)
+            x, pool = out, pool_out
         fside = self._wgrad_side(1, dev)[0] if self.overlap_wgrad else None
         main_f = torch.cuda.current_stream(dev)
-        for i, blk in enumerate(m.blocks):
+        for i, blk in enumerate(m.blocks if tower_tab is None else ()):
             # g = global_fc(pool(x)) is only needed by conv2: run its two small GEMMs on the side stream while conv1
             # occupies the main stream
             if fside is not None:

@@ -278,6 +278,30 @@ def test_bf16_backward_tracks_fp32_gradients():
     print("worst cosine", worst)
 
 
+@pytest.mark.parametrize("nb,B", [(3, 5), (40, 130)])
+def test_eval_tower_kernel_matches_the_per_layer_path(monkeypatch, nb, B):
+    """bf16 eval forward of a 256-channel model: the one-launch tower (csrc/tower.hip, the default in eval mode) against the
+    per-layer launch sequence (KA_TOWER=0).  Same rounding points (bf16 conv outputs, bf16 block outputs), so the two agree
+    to a few bf16 steps even after 40 blocks; both are held to the reference by test_models_bf16_bound."""
+    shape = orc.NetShape(nb, 256)
+    m = _build(shape, True).eval()
+    g = torch.Generator().manual_seed(nb * 100 + B)
+    obs = torch.randn(B, 50, 9, 9, generator=g).to(DEV)
+    monkeypatch.setenv("KA_EVAL_GRAPH", "0")
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("KA_TOWER", flag)
+        with torch.no_grad():
+            o = m(obs)
+        outs[flag] = (o.policy_logits.float().cpu(), o.value_logits.float().cpu(), o.score_lead.float().cpu())
+    for a, b, name in zip(outs["0"], outs["1"], ("policy", "value", "score")):
+        assert torch.isfinite(b).all(), name
+        scale = float(a.abs().max())
+        err = float((a - b).abs().max())
+        print(f"tower vs per-layer, {nb} blocks, {name}: max diff {err:.3e} of |max| {scale:.3e}")
+        assert err <= 0.02 * scale + 1e-3, (name, err, scale)
+
+
 def test_eval_graph_matches_eager_and_tracks_weights(monkeypatch):
     """The graph-captured eval forward (rollout inference) equals the eager launch sequence, is deterministic on
     replay, and sees in-place weight / running-statistics updates made after the capture."""

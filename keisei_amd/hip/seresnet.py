@@ -60,6 +60,7 @@ class SEResNetEngine:
         self._row_ring = None
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
         self._evalc_sets = {}
+        self._tensor_lists = None                   # [buffers, parameters, calls until re-read] of the eval-graph key
         self._tower_tabs = {}                       # pointer tables of the one-launch eval tower (kept: graphs read them)
         self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
@@ -404,8 +405,14 @@ class SEResNetEngine:
         if obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.float().contiguous()
         self._get_packs(T, dev)
+        # (the flat tensor lists are cached and re-read every 32 calls: walking the module tree costs more host time than
+        # the whole graph replay; the storage addresses themselves are checked on every call)
+        tl = self._tensor_lists
+        if tl is None or tl[2] <= 0:
+            tl = self._tensor_lists = [list(m.buffers()), list(m.parameters()), 32]
+        tl[2] -= 1
         key = (tuple(obs.shape), T, str(dev), self._pack_tkey,
-               tuple(b.data_ptr() for b in m.buffers()), tuple(q.data_ptr() for q in m.parameters()))
+               tuple(b.data_ptr() for b in tl[0]), tuple(q.data_ptr() for q in tl[1]))
         with self._graph_lock:
             ent = self._graphs.get(key)
             if ent is None:
@@ -824,12 +831,12 @@ def run_model(model: nn.Module, obs: torch.Tensor, idx: Optional[torch.Tensor] =
     elif model._amp_enabled:
         raise _lib.KeiseiHipError("the HIP path supports fp32 and bf16 autocast only")
     T = torch.bfloat16 if bf16 else torch.float32
+    if (not torch.is_grad_enabled() and not model.training and idx is None and obs.shape[0] <= 2048
+            and os.environ.get("KA_EVAL_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
+        with torch.autocast("cuda", enabled=False):      # (the rollout step: no walk over the parameters)
+            return engine.forward_eval_graphed(obs, T)
     named = [(n, p) for n, p in model.named_parameters()]
     keep = torch.is_grad_enabled() and any(p.requires_grad for _, p in named)
-    if (not keep and not model.training and idx is None and not torch.is_grad_enabled() and obs.shape[0] <= 2048
-            and os.environ.get("KA_EVAL_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
-        with torch.autocast("cuda", enabled=False):
-            return engine.forward_eval_graphed(obs, T)
     names = tuple(n for n, _ in named)
     with torch.autocast("cuda", enabled=False):
         return _SEResNetFunction.apply(engine, obs, idx, model.training, keep, T, names, *[p for _, p in named])

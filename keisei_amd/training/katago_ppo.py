@@ -420,7 +420,7 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                        ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         device = next(self.model.parameters()).device
         net = self.compiled_eval if self.compiled_eval is not None else self.forward_model
-        self.forward_model.eval()
+        self._set_training(False)              # = self.forward_model.eval() (katago_ppo.py:553)
         try:
             if device.type == "cuda":
                 start, end, stream = self._event_pair(device)
@@ -459,7 +459,20 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                 values = self.scalar_value(out.value_logits)
             return actions, log_probs, values
         finally:
-            self.forward_model.train()
+            self._set_training(True)           # = self.forward_model.train()
+
+    def _set_training(self, mode: bool) -> None:
+        """forward_model.train(mode) without walking the module tree on every rollout step: nn.Module.train() recurses
+        through ~450 modules with nn.Module.__setattr__ at each (about a millisecond per select_actions call at 40
+        blocks, twice per call); the flat module list is cached and re-read every 32 calls."""
+        fm = self.forward_model
+        ent = getattr(self, "_mode_cache", None)
+        if ent is None or ent[0] is not fm or ent[2] <= 0:
+            ent = [fm, list(fm.modules()), 32]
+            self._mode_cache = ent
+        ent[2] -= 1
+        for mod in ent[1]:
+            mod.__dict__["training"] = mode
 
     # ------------------------------------------------------------------ advantages
     def _advantages(self, data, buffer, next_values, device) -> torch.Tensor:

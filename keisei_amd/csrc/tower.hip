@@ -39,6 +39,7 @@ struct TowerBlock {              // device table row, 14 pointers (int64 each on
 struct TowerArgs {
     const uint16_t* x_in; const float* pool_in; uint16_t* x_out; float* pool_out;
     const TowerBlock* blocks; int nblocks, B, G, R;
+    int abl;                     // diagnostics only (KA_TOWER_ABL): 1 skip the global-pool chain, 2 skip the SE chain, 4 skip the image builds, 8 skip the MFMA steps
 };
 
 // pointers read from the device table are generic to the compiler: loads through them would be FLAT loads, which count on
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
             bf16x8 w0[2], w1[2], w2[2], w3[2];
             wfrag(kc, 0, w0); wfrag(kc, 1, w1); wfrag(kc, 2, w2);         // in flight across the image build
             __syncthreads();                                              // the image's previous readers are done; src is complete
-            for (int i = tid; i < KA_BOARD * 16; i += 512) {
+            if (!(a.abl & 4)) for (int i = tid; i < KA_BOARD * 16; i += 512) {
                 const int row = i >> 4, pc = i & 15;
                 *reinterpret_cast<uint4*>(smem + kImg + img_square(row) * kImgStride + pc * 16) =
                     *reinterpret_cast<const uint4*>(smem + src + row * kNatStride + kc * 256 + pc * 16);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 for (int mt = 0; mt < 6; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
             }
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {                           // weights of step s + 3 are requested before step s multiplies
+            for (int tap = 0; tap < ((a.abl & 8) ? 0 : 9); ++tap) {      // weights of step s + 3 are requested before step s multiplies
                 const int s0 = tap * 4;
                 wfrag(kc, s0 + 3, w3); __builtin_amdgcn_sched_barrier(0); mm(w0, fa, fb, s0 + 1); __builtin_amdgcn_sched_barrier(0);
                 wfrag(kc, s0 + 4, w0); __builtin_amdgcn_sched_barrier(0); mm(w1, fb, fa, s0 + 2); __builtin_amdgcn_sched_barrier(0);
@@ -147,29 +148,34 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
         const TowerBlock tb = a.blocks[blk];
         // ---- global-pool bias: hid = relu(W1 pooled + b1), one wave per row, lanes along the 3C inputs; four rows' loads are
         // in flight together (a dependent chain of L2 round trips per row is what this phase would otherwise be)
-        {
-            float pv[3 * kC / 64];
+        if (!(a.abl & 1)) {
+            // 16-byte loads, eight rows (24 loads per lane) in flight together: the phase is a chain of L2 round trips
+            typedef const __attribute__((address_space(1))) f32x4* gvec_ptr;
+            f32x4 pv[3];
 #pragma unroll
-            for (int k = 0; k < 3 * kC / 64; ++k) pv[k] = vec[kPooled + lane + 64 * k];
-            for (int jb = wave; jb < a.G; jb += 32) {
-                float s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 3; ++k) pv[k] = *reinterpret_cast<const f32x4*>(vec + kPooled + 4 * (lane + 64 * k));
+            for (int jb = wave; jb < a.G; jb += 64) {
+                f32x4 wv[8][3];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int j = min(jb + 8 * u, a.G - 1);
-                    gfloat_ptr wr = gf(tb.gw1) + (size_t)j * 3 * kC;
+                    gvec_ptr wr = (gvec_ptr)(tb.gw1 + (size_t)j * 3 * kC);
 #pragma unroll
-                    for (int k = 0; k < 3 * kC / 64; ++k) s[u] += wr[lane + 64 * k] * pv[k];
+                    for (int k = 0; k < 3; ++k) wv[u][k] = wr[lane + 64 * k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t += wv[u][k][0] * pv[k][0] + wv[u][k][1] * pv[k][1] + wv[u][k][2] * pv[k][2] + wv[u][k][3] * pv[k][3];
+                    t = wave_sum(t);
                     const int j = jb + 8 * u;
-                    const float t = wave_sum(s[u]);
                     if (lane == 0 && j < a.G) vec[kHid + j] = fmaxf(t + gf(tb.gb1)[j], 0.f);
                 }
             }
         }
         __syncthreads();
-        {   // g[c] = W2[c] . hid + b2[c]: two threads per channel, each a contiguous half of the row (16-byte loads)
+        if (!(a.abl & 1)) {   // g[c] = W2[c] . hid + b2[c]: two threads per channel, each a contiguous half of the row (16-byte loads)
             typedef const __attribute__((address_space(1))) f32x4* gvec_ptr;
             const int c = tid >> 1, half = tid & 1, n = a.G >> 1;
             gvec_ptr wr = (gvec_ptr)(tb.gw2 + (size_t)c * a.G + half * n);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
             }
         }
         __syncthreads();
-        {   // se hidden: one wave per row, the loads of all this wave's rows in flight together
+        if (!(a.abl & 2)) {   // se hidden: one wave per row, the loads of all this wave's rows in flight together
             float mv[kC / 64];
 #pragma unroll
             for (int k = 0; k < kC / 64; ++k) mv[k] = vec[kSeMean + lane + 64 * k];
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
             }
         }
         __syncthreads();
-        {
+        if (!(a.abl & 2)) {
             gfloat_ptr wr = gf(tb.sw2) + (size_t)tid * a.R;   // thread k < 2C = 512: gate logits | shifts
             float s = gf(tb.sb2)[tid];
             if ((a.R & 3) == 0) {
@@ -325,7 +331,8 @@ extern "C" int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out
     KA_REQUIRE(x_in && pool_in && x_out && pool_out && blocks && nblocks > 0 && B > 0, "tower_eval: bad arguments");
     KA_REQUIRE(ka_tower_eval_supported(C, G, R, dtype), "tower_eval: unsupported configuration C=%d G=%d R=%d dtype=%d", C, G, R, dtype);
     TowerArgs a{static_cast<const uint16_t*>(x_in), pool_in, static_cast<uint16_t*>(x_out), pool_out,
-                static_cast<const TowerBlock*>(blocks), nblocks, B, G, R};
+                static_cast<const TowerBlock*>(blocks), nblocks, B, G, R, 0};
+    if (const char* e = getenv("KA_TOWER_ABL")) a.abl = atoi(e);
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&tower_eval_kernel), done, "tower_eval")) return rc;
     hipLaunchKernelGGL(tower_eval_kernel, dim3(B), dim3(512), kTowerLds, static_cast<hipStream_t>(stream), a);

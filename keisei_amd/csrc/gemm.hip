@@ -21,8 +21,11 @@ struct GemmArgs {
     int a_vec, b_vec;            // rows of the operand are 16-byte (fp32) / 8-byte (bf16) aligned: 4-element vector loads
 };
 
+// (operand pointers may come from a device table -- the grouped weight-gradient launch -- where the compiler sees generic
+// pointers and would emit FLAT loads, which also count on the LDS counter; every access goes through global-space views)
+#define KA_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ float ldx(const void* p, size_t i, int bf16) {
-    return bf16 ? bf2f(static_cast<const uint16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+    return bf16 ? bf2f(((const KA_GLOBAL uint16_t*)p)[i]) : ((const KA_GLOBAL float*)p)[i];
 }
 
 // four consecutive elements of an fp32 / bf16 operand starting at element i, widened to fp32; `valid` (<= 0 .. >= 4) of
@@ -33,11 +36,13 @@ __device__ __forceinline__ f32x4 ld4(const void* base, size_t i, int bf16, int v
     if (valid <= 0) return v;
     if (vec && valid >= 4) {
         if (bf16) {
-            const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + i);
+            const uint32_t ux = ((const KA_GLOBAL uint32_t*)((const KA_GLOBAL uint16_t*)base + i))[0];
+            const uint32_t uy = ((const KA_GLOBAL uint32_t*)((const KA_GLOBAL uint16_t*)base + i))[1];
+            const uint2 u = {ux, uy};
             v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
             v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
         } else {
-            v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + i);
+            v = *(const KA_GLOBAL f32x4*)((const KA_GLOBAL float*)base + i);
         }
     } else {
 #pragma unroll
@@ -137,7 +142,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int bx, int by, int
     }
     // accumulator lane (r, q), element i: C[m = 16 wm + 4q + i][n = 16 j + r]
     const size_t slab = (size_t)bz * g.M * g.ldc;
-    float* C = static_cast<float*>(g.C);
+    KA_GLOBAL float* C = (KA_GLOBAL float*)g.C;
     if (!rows_live) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -147,11 +152,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int bx, int by, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 16 + 4 * q + i;
-                if (m < g.M) colsum_out[m] = acc[j][i];
+                if (m < g.M) ((KA_GLOBAL float*)colsum_out)[m] = acc[j][i];
             }
             continue;
         }
-        const float bv = g.bias ? g.bias[n] : 0.f;
+        const float bv = g.bias ? ((const KA_GLOBAL float*)g.bias)[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 16 + 4 * q + i;
@@ -159,7 +164,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int bx, int by, int
             float v = acc[j][i] + bv;
             if (g.relu) v = fmaxf(v, 0.f);
             const size_t o = slab + (size_t)m * g.ldc + n;
-            if (g.c_bf16) static_cast<uint16_t*>(g.C)[o] = f2bf(v);
+            if (g.c_bf16) ((KA_GLOBAL uint16_t*)g.C)[o] = f2bf(v);
             else C[o] = g.accumulate ? C[o] + v : v;
         }
     }

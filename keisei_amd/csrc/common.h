@@ -115,4 +115,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. it waits
+// for every global load in flight (a weight prefetch issued before the barrier) and for global stores to complete
+#define KA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

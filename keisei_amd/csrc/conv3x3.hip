@@ -571,12 +571,183 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     return ka_check_launch("conv3x3");
 }
 
+// ---------------------------------------------------------------- streaming form (bf16, Cin = Cout = 256, training batches)
+// The MFMA loop of the one-launch eval tower (tower.hip) as a training convolution: a persistent 512-thread workgroup
+// per CU walks its boards; 8 waves x (6 row tiles x 2 channel tiles), fragment-ordered weights through a four-slot
+// register ring three k-steps ahead, activation fragments double-buffered across k-steps with the issue order pinned --
+// that loop runs at the matrix-core issue rate (tower_bench: 239 us per 4096-board convolution), where the two
+// 256-thread workgroups of conv3x3_kernel spend 370 us.  What the second workgroup gave for free is done by hand here:
+// the NEXT board's input pieces are requested from HBM before this board's MFMA phases and written (input transform
+// applied) into the other natural-layout LDS buffer after them; the haloed 128-channel image is rebuilt LDS -> LDS per
+// chunk.  Same ConvArgs, same epilogue (conv_epilogue<bf16_t, 2>), same weight packs as conv3x3_kernel: bit-identical results.
+// Measured (B = 4096): 5 % faster than conv3x3_kernel alone (0.373 vs 0.393 ms; 15 % under sustained back-to-back launches),
+// 1 % SLOWER inside the training step (119.0 vs 117.7 ms: it fills every CU, so the side-stream FC chain of the forward no
+// longer runs beside conv1) -- opt-in (KA_CONV_T=1, forward convolutions only), conv3x3_kernel stays the default.
+constexpr int kStNat = KA_BOARD * 512;                     // natural [81][256] bf16
+constexpr int kStImgStride = 128 * 2 + 32;
+constexpr int kStImg = 2 * kStNat;
+constexpr int kStLds = kStImg + kImgSquares1 * kStImgStride;
+
+template <bool TWO>      // TWO: the two-tensor input of the data-gradient convolutions (and their optional masked epilogue)
+__global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int nwg = gridDim.x;
+    if ((int)blockIdx.x >= a.B) return;
+    for (int i = tid; i < kImgSquares1 * kStImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kStImg)[i] = uint4{0, 0, 0, 0};
+
+    // ---- staging role: piece i = tid + 512 u (u < 6) of a board = row i / 32, 16-byte piece i % 32 = tid % 32 (8 channels)
+    const int pc = tid & 31, ch0 = pc * 8;
+    const bool has_aff = a.in_scale != nullptr;
+    constexpr bool two = TWO;
+    if (!TWO) a.ep_y = nullptr;                              // (compile-time: the masked epilogue belongs to the data-gradient form)
+    bf16x8 pv[6], pw[TWO ? 6 : 1];
+    f32x4 pb[2];
+    auto request = [&](int bb) {                            // raw pieces of board bb into registers
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int i = tid + 512 * u;
+            pv[u] = bf16x8{};
+            if (TWO) pw[TWO ? u : 0] = bf16x8{};
+            if (i < KA_BOARD * 32) {
+                const size_t off = ((size_t)bb * KA_BOARD * 32 + i) * 16;
+                pv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
+                if (TWO) pw[TWO ? u : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
+            }
+        }
+        if (!TWO && a.in_bias) {
+            pb[0] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0);
+            pb[1] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0 + 4);
+        }
+    };
+    auto commit = [&](int bb, int buf) {                    // transform and write into natural buffer `buf`
+        float sc[8], sh[8], k3[8];                           // (re-read per board: cache-resident, and 24 registers fewer across the MFMAs)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
+            k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int i = tid + 512 * u;
+            if (i >= KA_BOARD * 32) continue;
+            bf16x8 v = pv[u];
+            if (two) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? u : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + ((size_t)bb * KA_BOARD * 32 + i) * 16) = v;
+            } else if (has_aff || a.relu || a.in_bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[e];
+                    if (has_aff) f = fmaf(f, sc[e], sh[e]);
+                    if (a.relu) f = fmaxf(f, 0.f);
+                    if (a.in_bias) f += pb[e >> 2][e & 3];
+                    v[e] = (__bf16)f;
+                }
+            }
+            *reinterpret_cast<bf16x8*>(smem + buf * kStNat + i * 16) = v;
+        }
+    };
+
+    int rowoff[kMTW];
+#pragma unroll
+    for (int mt = 0; mt < kMTW; ++mt) {
+        const int p = mt * 16 + r;
+        rowoff[mt] = kStImg + lds_square(0, p < KA_BOARD ? p : 0) * kStImgStride + q * 16;
+    }
+    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
+    auto wfrag = [&](int kc, int step, bf16x8 (&f)[2]) {   // step = tap*4 + ks4 within the 128-channel chunk (clamped)
+        step = min(step, 35);
+        const int tap = step >> 2, ks = kc * 4 + (step & 3);
+        const char* p = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
+        f[0] = *reinterpret_cast<const bf16x8*>(p);
+        f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+    };
+    auto toff_of = [&](int step) {
+        step = min(step, 35);
+        const int tap = step >> 2, ks = step & 3;
+        return ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kStImgStride + ks * 64;
+    };
+
+    int bb = blockIdx.x, it = 0;
+    request(bb);
+    commit(bb, 0);
+    for (; bb < a.B; bb += nwg, ++it) {
+        const int cur = it & 1, nb = bb + nwg;
+        f32x4 acc[kMTW][2];
+#pragma unroll
+        for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int abl = a.tune_stagger;                      // diagnostics (KA_CONV_T_ABL): 1 no epilogue, 2 no staging of the next board, 4 no MFMA steps, 8 no image builds
+        if (nb < a.B && !(abl & 2)) request(nb);             // the next board's pieces: in flight under this board's MFMAs
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 w0[2], w1[2], w2[2], w3[2];
+            wfrag(kc, 0, w0); wfrag(kc, 1, w1); wfrag(kc, 2, w2);
+            KA_LDS_BARRIER();                                // the image's previous readers are done; the natural buffer is complete
+            if (!(abl & 8)) for (int i = tid; i < KA_BOARD * 16; i += 512) {
+                const int row = i >> 4, p16 = i & 15;
+                *reinterpret_cast<uint4*>(smem + kStImg + lds_square(0, row) * kStImgStride + p16 * 16) =
+                    *reinterpret_cast<const uint4*>(smem + cur * kStNat + row * 512 + kc * 256 + p16 * 16);
+            }
+            KA_LDS_BARRIER();
+            auto mm = [&](const bf16x8 (&wf)[2], const bf16x8 (&ac)[kMTW], bf16x8 (&an)[kMTW], int next_step) {
+                const int toff = toff_of(next_step);
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    an[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            };
+            bf16x8 fa[kMTW], fb[kMTW];
+            {
+                const int toff = toff_of(0);
+#pragma unroll
+                for (int mt = 0; mt < kMTW; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+            }
+#pragma unroll 1
+            for (int tap = 0; tap < ((abl & 4) ? 0 : 9); ++tap) {
+                const int s0 = tap * 4;
+                wfrag(kc, s0 + 3, w3); __builtin_amdgcn_sched_barrier(0); mm(w0, fa, fb, s0 + 1); __builtin_amdgcn_sched_barrier(0);
+                wfrag(kc, s0 + 4, w0); __builtin_amdgcn_sched_barrier(0); mm(w1, fb, fa, s0 + 2); __builtin_amdgcn_sched_barrier(0);
+                wfrag(kc, s0 + 5, w1); __builtin_amdgcn_sched_barrier(0); mm(w2, fa, fb, s0 + 3); __builtin_amdgcn_sched_barrier(0);
+                wfrag(kc, s0 + 6, w2); __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nb < a.B && !(abl & 2)) commit(nb, cur ^ 1);     // (the other natural buffer: last read two boards ago)
+        if (!(abl & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
+    }
+}
+
+static int launch_conv_stream(ConvArgs a, hipStream_t st) {
+    a.tune_stagger = 0;
+    if (const char* e = getenv("KA_CONV_T_ABL")) a.tune_stagger = atoi(e);      // diagnostics only
+    static std::atomic<unsigned long long> done{0};
+    int grid = 256;
+    if (const char* e = getenv("KA_CONV_T_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
+    if (grid > a.B) grid = a.B;
+    // (the two-tensor data-gradient form, conv3x3_stream_kernel<true>, compiles but spills at 256 registers: not dispatched)
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_stream_kernel<false>), done, "conv3x3 (stream)")) return rc;
+    hipLaunchKernelGGL(conv3x3_stream_kernel<false>, dim3(grid), dim3(512), kStLds, st, a);
+    return ka_check_launch("conv3x3 (stream)");
+}
+
 template <typename T>
 int conv_dispatch(ConvArgs a, hipStream_t st) {
     typedef Elem<T> E;
     constexpr int CPK = 4 * E::kPer16;
     KA_REQUIRE(a.B > 0 && a.Cin % CPK == 0 && a.Cout % 16 == 0,
                "conv3x3: need Cin %% %d == 0 and Cout %% 16 == 0 (got Cin=%d Cout=%d)", CPK, a.Cin, a.Cout);
+    if constexpr (sizeof(T) == 2) {
+        // the streaming form: tower shapes at training batch sizes (opt-in while it is being measured: KA_CONV_T=1)
+        const char* e = getenv("KA_CONV_T");
+        if (e && atoi(e) != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 && !a.in2) return launch_conv_stream(a, st);
+    }
     // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
     int wm = 1;
     if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }   // experiments

@@ -98,13 +98,13 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
         for (int kc = 0; kc < 2; ++kc) {
             bf16x8 w0[2], w1[2], w2[2], w3[2];
             wfrag(kc, 0, w0); wfrag(kc, 1, w1); wfrag(kc, 2, w2);         // in flight across the image build
-            __syncthreads();                                              // the image's previous readers are done; src is complete
+            KA_LDS_BARRIER();                                              // the image's previous readers are done; src is complete
             if (!(a.abl & 4)) for (int i = tid; i < KA_BOARD * 16; i += 512) {
                 const int row = i >> 4, pc = i & 15;
                 *reinterpret_cast<uint4*>(smem + kImg + img_square(row) * kImgStride + pc * 16) =
                     *reinterpret_cast<const uint4*>(smem + src + row * kNatStride + kc * 256 + pc * 16);
             }
-            __syncthreads();
+            KA_LDS_BARRIER();
             auto toff_of = [&](int step) {
                 step = min(step, 35);
                 const int tap = step >> 2, ks = step & 3;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
         }
     };
 
-    __syncthreads();
+    KA_LDS_BARRIER();
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const TowerBlock tb = a.blocks[blk];
         // ---- global-pool bias: hid = relu(W1 pooled + b1), one wave per row, lanes along the 3C inputs; four rows' loads are
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 }
             }
         }
-        __syncthreads();
+        KA_LDS_BARRIER();
         if (!(a.abl & 1)) {   // g[c] = W2[c] . hid + b2[c]: two threads per channel, each a contiguous half of the row (16-byte loads)
             typedef const __attribute__((address_space(1))) f32x4* gvec_ptr;
             const int c = tid >> 1, half = tid & 1, n = a.G >> 1;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 if (r == 0) vec[kSeMean + c0 + e] = fmaf(t * (1.f / KA_BOARD), sc[e], sh[e]);   // mean_p bn2(y2)
             }
         }
-        __syncthreads();
+        KA_LDS_BARRIER();
         if (!(a.abl & 2)) {   // se hidden: one wave per row, the loads of all this wave's rows in flight together
             float mv[kC / 64];
 #pragma unroll
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 }
             }
         }
-        __syncthreads();
+        KA_LDS_BARRIER();
         if (!(a.abl & 2)) {
             gfloat_ptr wr = gf(tb.sw2) + (size_t)tid * a.R;   // thread k < 2C = 512: gate logits | shifts
             float s = gf(tb.sb2)[tid];
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
             }
             vec[kSeOut + tid] = tid < kC ? sigmoidf_(s) : s;
         }
-        __syncthreads();
+        KA_LDS_BARRIER();
         // ---- x' = relu(z * gate + shift + x) in place, and its pooled statistics (a wave owns all squares of its channels)
         {
             float gate[8], shf[8], sum[8], mx[8], mn[8];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 }
             }
         }
-        __syncthreads();
+        KA_LDS_BARRIER();
     }
     for (int i = tid; i < KA_BOARD * 32; i += 512)
         reinterpret_cast<uint4*>(a.x_out + (size_t)b * KA_BOARD * kC)[i] = reinterpret_cast<const uint4*>(smem + kXn)[i];

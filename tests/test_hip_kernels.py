@@ -756,3 +756,22 @@ def test_conv_g_opt_in_kernel_matches_torch_and_conv3x3(monkeypatch, B, transfor
     assert not torch.isnan(bsum1).any() and not torch.isnan(sq1).any()
     close(bsum1.cpu(), bsum0.cpu(), torch.float32, k=5)
     close(sq1.cpu(), sq0.cpu(), torch.float32, k=5)
+
+
+@pytest.mark.parametrize("transform", [False, True])
+def test_streaming_conv_is_bit_identical_to_the_default_kernel(monkeypatch, transform):
+    """The opt-in persistent form of the forward convolution (KA_CONV_T=1; the eval tower's MFMA loop with the next board
+    prefetched): same summation order and epilogue as conv3x3_kernel, so outputs and statistics agree bit for bit."""
+    dt, C, B = torch.bfloat16, 256, 771
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, C, 9, 9, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / 48
+    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
+    gb = 0.5 * torch.randn(B, C, generator=g)
+    args = (sc.to(DEV), sh.to(DEV), gb.to(DEV), 1) if transform else ()
+    xin, wp = to_nhwc(x, dt), pack(w, dt, 0, C, C)
+    monkeypatch.setenv("KA_CONV_T", "0")
+    out0, bsum0, sq0 = run_conv(xin, wp, B, C, C, dt, *args)
+    monkeypatch.setenv("KA_CONV_T", "1")
+    out1, bsum1, sq1 = run_conv(xin, wp, B, C, C, dt, *args)
+    assert torch.equal(out0, out1) and torch.equal(bsum0, bsum1) and torch.equal(sq0, sq1)

@@ -4,8 +4,8 @@ set -e
 A=$1; B=$2; steps=${3:-8}
 mkdir -p gpurun_out
 for round in 1 2; do
-  env $A timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline > gpurun_out/abe_a_$round.json 2> gpurun_out/abe_a_$round.err
-  env $B timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline > gpurun_out/abe_b_$round.json 2> gpurun_out/abe_b_$round.err
+  env $A timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-fp32 --no-kernel-events > gpurun_out/abe_a_$round.json 2> gpurun_out/abe_a_$round.err
+  env $B timeout -k 10 300 python bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-fp32 --no-kernel-events > gpurun_out/abe_b_$round.json 2> gpurun_out/abe_b_$round.err
 done
 python - "$A" "$B" <<'PY'
 import json, sys

@@ -1,10 +1,12 @@
-"""conv_g (GEMM-class conv) against conv3x3_kernel on the four launch kinds: outputs, statistics, stand-alone time.
-KA_CONV_G=0 selects the old kernel inside the same entry points."""
+"""An opt-in conv kernel against conv3x3_kernel on the four launch kinds: outputs, statistics, stand-alone time.
+CG_VAR names the switch (KA_CONV_G: the GEMM-class kernel, KA_CONV_T: the streaming form); =0 selects conv3x3_kernel
+inside the same entry points.  CG_KINDS = launch kinds (0 plain fwd, 1 transformed fwd, 2 masked dgrad, 3 plain dgrad)."""
 import os, sys
 sys.path.insert(0, '.')
 import torch
 from keisei_amd import _lib
 dev = 'cuda'
+VAR = os.environ.get('CG_VAR', 'KA_CONV_G')
 C = 256
 dt = torch.bfloat16
 def timeit(fn, n=20):
@@ -36,14 +38,14 @@ for B in sizes:
     for kind in (int(k) for k in os.environ.get('CG_KINDS', '0,1').split(',')):
         res = {}
         for flag in ("0", "1"):
-            os.environ["KA_CONV_G"] = flag
+            os.environ[VAR] = flag
             outs = [torch.full((B, 81, C), float("nan"), device=dev).to(dt), torch.full((B, C), float("nan"), device=dev), torch.full((B, C), float("nan"), device=dev),
                     torch.full((B, 81, C), float("nan"), device=dev).to(dt), torch.full((B, C), float("nan"), device=dev), torch.full((B, C), float("nan"), device=dev)]
             run(kind, outs); torch.cuda.synchronize()
             res[flag] = [outs, 1e9]
         for rnd in range(3):                      # alternating rounds in one process, best of three
             for flag in ("0", "1"):
-                os.environ["KA_CONV_G"] = flag
+                os.environ[VAR] = flag
                 res[flag][1] = min(res[flag][1], timeit(lambda: run(kind, res[flag][0])))
         o0, t0 = res["0"]; o1, t1 = res["1"]
         def rel(a, b):
@@ -52,5 +54,5 @@ for B in sizes:
             return ((a - b).abs().max() / (b.abs().max() + 1e-9)).item()
         diffs = [rel(o1[i], o0[i]) for i in range(6)]
         flop = 2.0 * B * 81 * 9 * C * C
-        print(f"B={B} {names[kind]:42s}: conv3x3 {t0:.4f} ms  conv_g {t1:.4f} ms ({flop / t1 / 1e9:.0f} TF)  rel diffs out/bsum/sq|s1/dy/s1|-/s2 "
+        print(f"B={B} {names[kind]:42s}: conv3x3 {t0:.4f} ms  {VAR} {t1:.4f} ms ({flop / t1 / 1e9:.0f} TF)  rel diffs out/bsum/sq|s1/dy/s1|-/s2 "
               + " ".join(f"{d:.1e}" for d in diffs), flush=True)

@@ -22,10 +22,10 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-for N in (128, 256, 512):
+for N in [int(v) for v in (sys.argv[1:] or ['128', '256', '512'])]:
     x = torch.randn(N, 81, 256, device=dev).bfloat16(); pool = torch.randn(N, 1024, device=dev)
     xo = torch.empty_like(x); po = torch.empty_like(pool)
-    for abl in [0] + ([1, 2, 3, 4, 8, 12, 15] if N == 128 else []):
+    for abl in [0] + ([1, 2, 3, 4, 8, 12, 15] if N in (128, 4096) else []):
         os.environ["KA_TOWER_ABL"] = str(abl)
         ms = timeit(lambda: _lib.call("ka_tower_eval", x, pool, xo, po, tab, 40, N, 256, 128, 16, 1, _lib.stream_ptr()))
         print(f"N={N} abl={abl:2d}: {ms * 1e3:8.1f} us per launch, {ms * 1e3 / 40:6.1f} us per block", flush=True)

@@ -57,6 +57,7 @@ struct NtArgs {
     void* C; const float* bias; const void* residual;     // C [M][ldc] bf16 or fp32; residual like C (same dtype as C)
     int M, N, K, lda, ldb, ldc;
     int c_bf16, relu, ksplit_len;              // ksplit_len < K: gridDim.z slabs of fp32 [z][M][ldc], no epilogue
+    int lds_epilogue;                          // full bf16 tiles leave through LDS as whole-row 16-byte pieces (KA_TF_LDS_EPI=0: off)
     float drop_p; unsigned long long seed;     // dropout on the (bias, relu)'d value before the residual add
 };
 
@@ -144,6 +145,48 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
     const uint32_t thresh = drop_thresh(g.drop_p);
     const bool vec4 = (g.N & 3) == 0 && (g.ldc & 3) == 0;      // (the C / residual / bias bases are whole allocations)
+    // full bf16 tiles with 8-element alignment: the accumulators go through LDS (the operand tiles are dead) so that a thread
+    // owns 8 consecutive columns of a row and 16 lanes write a whole 256-byte row piece -- one 16-byte store per piece
+    // instead of 32-byte pieces scattered over 16 rows per instruction; bias / residual likewise arrive as 16 / 32-byte pieces
+    if (!split && g.c_bf16 && (g.N & 7) == 0 && (g.ldc & 7) == 0 && m0 + kBM <= g.M && n0 + kBN <= g.N && g.lds_epilogue) {
+        constexpr int kEs = kBN * 4 + 16;                       // 528-byte rows: the 8-lane groups of a b128 write hit distinct banks
+        __syncthreads();                                        // every wave is done with the operand tiles
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(nt_smem + (wm * 64 + i * 16 + r) * kEs + (wn * 64 + j * 16 + 4 * q) * 4) = acc[i][j];
+        __syncthreads();
+        const int pc8 = tid & 15, row0 = tid >> 4;              // 16 pieces of 8 columns per row, 16 rows per pass
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) { b0 = *reinterpret_cast<const f32x4*>(g.bias + n0 + pc8 * 8); b1 = *reinterpret_cast<const f32x4*>(g.bias + n0 + pc8 * 8 + 4); }
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = row0 + 16 * pass;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(nt_smem + row * kEs + pc8 * 32);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(nt_smem + row * kEs + pc8 * 32 + 16);
+            float v[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3], v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+            const size_t ob = (size_t)(m0 + row) * g.ldc + n0 + pc8 * 8;
+            if (g.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (g.drop_p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= keep_scale(g.seed, ob + e, thresh, inv_keep);
+            }
+            if (g.residual) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(g.residual) + ob);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x8*>(static_cast<uint16_t*>(g.C) + ob) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r;
@@ -1285,7 +1328,8 @@ extern "C" int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float*
     int len = K;
     if (nsplit > 1) { len = ((K + kBK - 1) / kBK + nsplit - 1) / nsplit * kBK; nsplit = (K + len - 1) / len; }
     NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, M, N, K, lda, ldb, ldc,
-             c_bf16, relu, len, drop_p, seed};
+             c_bf16, relu, len, 1, drop_p, seed};
+    if (const char* e = getenv("KA_TF_LDS_EPI")) g.lds_epilogue = atoi(e);
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel), done, "tf_gemm_nt")) return rc;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256),

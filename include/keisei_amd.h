@@ -272,6 +272,10 @@ int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, cons
                   int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p, unsigned long long seed,
                   void* stream);
 int ka_tf_gemm_nt_slabs(int K, int nsplit);
+/* C (bf16) = (A B^T) * dropout_keep(seed, element) * [relu_act > 0]: the input-gradient GEMM of linear2 carrying the
+ * backward of the dropout and ReLU that follow linear1 in the forward (transformer.py:45-50 via nn.TransformerEncoderLayer) */
+int ka_tf_gemm_nt_masked(const void* A, const void* B, void* C, const void* relu_act, int M, int N, int K, int lda, int ldb,
+                         int ldc, float drop_p, unsigned long long seed, void* stream);
 /* dW = dY^T X straight from the row-major activations (weight gradient of nn.Linear, transformer.py:40-61): C[z][N][ldc]
  * fp32 slabs over token ranges (z < ka_tf_gemm_tn_slabs(M, nsplit); one slab = the result), A [M][lda] (N columns) and
  * B [M][ldb] (K columns) bf16, N / K / lda / ldb multiples of 8.  Operand fragments by LDS transpose reads: no transposed copies. */

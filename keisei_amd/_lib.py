@@ -75,6 +75,7 @@ _SIGS = {
     "ka_tower_eval": "ppppp iiiii i p",
     "ka_tf_gemm_nt": "ppppp iii iii iii f q p",
     "ka_tf_gemm_nt_slabs": "ii",
+    "ka_tf_gemm_nt_masked": "pppp iii iii f q p",
     "ka_tf_gemm_tn": "ppp iii iii i p",
     "ka_tf_gemm_tn_slabs": "ii",
     "ka_tf_transpose_pad": "pp iiii i p",

@@ -55,6 +55,7 @@ template <> __device__ __forceinline__ void stT<bf16_t>(bf16_t* p, size_t i, flo
 struct NtArgs {
     const uint16_t* A; const uint16_t* B;     // bf16 [M][lda], [N][ldb], K-contiguous, K % 32 == 0 (zero padded)
     void* C; const float* bias; const void* residual;     // C [M][ldc] bf16 or fp32; residual like C (same dtype as C)
+    const void* relu_act;                      // bf16 [M][ldc] or null: the output is zeroed where relu_act <= 0 (ReLU backward; bf16 C only)
     int M, N, K, lda, ldb, ldc;
     int c_bf16, relu, ksplit_len;              // ksplit_len < K: gridDim.z slabs of fp32 [z][M][ldc], no epilogue
     int lds_epilogue;                          // full bf16 tiles leave through LDS as whole-row 16-byte pieces (KA_TF_LDS_EPI=0: off)
@@ -175,6 +176,11 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= keep_scale(g.seed, ob + e, thresh, inv_keep);
             }
+            if (g.relu_act) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(g.relu_act) + ob);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)av[e] > 0.f ? v[e] : 0.f;
+            }
             if (g.residual) {
                 const bf16x8 rv = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(g.residual) + ob);
 #pragma unroll
@@ -209,6 +215,11 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
                     for (int e = 0; e < 4; ++e) v[e] *= keep_scale(g.seed, ob + e, thresh, inv_keep);
                 }
                 if (g.c_bf16) {
+                    if (g.relu_act) {
+                        const bf16x4 av = *reinterpret_cast<const bf16x4*>(static_cast<const uint16_t*>(g.relu_act) + ob);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)av[e] > 0.f ? v[e] : 0.f;
+                    }
                     if (g.residual) {
                         const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const uint16_t*>(g.residual) + ob);
 #pragma unroll
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (g.drop_p > 0.f) v *= keep_scale(g.seed, o, thresh, inv_keep);
                 if (g.c_bf16) {
+                    if (g.relu_act && !(bf2f(static_cast<const uint16_t*>(g.relu_act)[o]) > 0.f)) v = 0.f;
                     if (g.residual) v += bf2f(static_cast<const uint16_t*>(g.residual)[o]);
                     static_cast<uint16_t*>(g.C)[o] = f2bf(v);
                 } else {
@@ -1319,15 +1331,30 @@ inline int grid1d(size_t n, int cap) { const size_t b = (n + 255) / 256; return 
 // C[M][ldc] = epilogue(A[M][lda] * B[N][ldb]^T): bf16 operands (K % 32 == 0, 16-byte aligned rows), fp32 accumulation.
 // nsplit > 1: C receives nsplit fp32 slabs [nsplit][M][ldc] of partial sums over K ranges (no epilogue; reduce with
 // ka_reduce_slabs).  Replaces nn.Linear / its input- and weight-gradient GEMMs of transformer.py:40-61 under autocast.
+static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* relu_act,
+                           int M, int N, int K, int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p,
+                           unsigned long long seed, void* stream);
 extern "C" int ka_tf_gemm_nt(const void* A, const void* B, void* C, const float* bias, const void* residual, int M, int N, int K,
                              int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p, unsigned long long seed,
                              void* stream) {
+    return tf_gemm_nt_impl(A, B, C, bias, residual, nullptr, M, N, K, lda, ldb, ldc, c_bf16, relu, nsplit, drop_p, seed, stream);
+}
+// the input-gradient GEMM of a layer that is followed by ReLU + dropout in the forward (FFN linear1): the dropout mask of
+// (seed, element) and the ReLU mask of the saved activation are applied in the epilogue -- C = (A B^T) * keep * [relu_act > 0]
+extern "C" int ka_tf_gemm_nt_masked(const void* A, const void* B, void* C, const void* relu_act, int M, int N, int K, int lda,
+                                    int ldb, int ldc, float drop_p, unsigned long long seed, void* stream) {
+    KA_REQUIRE(relu_act, "tf_gemm_nt_masked: null activation");
+    return tf_gemm_nt_impl(A, B, C, nullptr, nullptr, relu_act, M, N, K, lda, ldb, ldc, 1, 0, 1, drop_p, seed, stream);
+}
+static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const void* residual, const void* relu_act,
+                           int M, int N, int K, int lda, int ldb, int ldc, int c_bf16, int relu, int nsplit, float drop_p,
+                           unsigned long long seed, void* stream) {
     KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "tf_gemm_nt: bad arguments");
     KA_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, "tf_gemm_nt: K %% 32 and lda/ldb %% 8 required (K=%d lda=%d ldb=%d)", K, lda, ldb);
     KA_REQUIRE(nsplit >= 1 && (nsplit == 1 || (!bias && !residual && !relu && !c_bf16 && drop_p == 0.f)), "tf_gemm_nt: split-K slabs carry no epilogue");
     int len = K;
     if (nsplit > 1) { len = ((K + kBK - 1) / kBK + nsplit - 1) / nsplit * kBK; nsplit = (K + len - 1) / len; }
-    NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, M, N, K, lda, ldb, ldc,
+    NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, relu_act, M, N, K, lda, ldb, ldc,
              c_bf16, relu, len, 1, drop_p, seed};
     if (const char* e = getenv("KA_TF_LDS_EPI")) g.lds_epilogue = atoi(e);
     static std::atomic<unsigned long long> done{0};

@@ -104,7 +104,7 @@ class TransformerEngine:
             _call("ka_tf_drop_apply", out, None, residual, out, out.numel(), float(drop_p), int(seed), _lib.DTYPE_F32, st)
         return out
 
-    def _lin_bwd(self, dy, x, name, w, grads, wname, bname, T, st, need_dx=True, dy_is_f32=False):
+    def _lin_bwd(self, dy, x, name, w, grads, wname, bname, T, st, need_dx=True, dy_is_f32=False, dx_mask=None):
         """dx = dy W, dW = dy^T x, db = colsum(dy) for y = x W^T + b.  dy (M, N) and x (M, Kx >= K) of dtype T (dy fp32 when
         dy_is_f32: the policy logits' gradient)."""
         M, N = dy.shape
@@ -158,7 +158,11 @@ class TransformerEngine:
                 else:
                     a, lda = dy, N
                 dx = torch.empty(M, K, dtype=T, device=dev)
-                _call("ka_tf_gemm_nt", a, wT16, dx, None, None, M, K, _r32(N), lda, wT16.shape[1], K, 1, 0, 1, 0.0, 0, st)
+                if dx_mask is not None:          # (act, p, seed): the ReLU + dropout that precede this layer, in the GEMM epilogue
+                    act, pm, sm = dx_mask
+                    _call("ka_tf_gemm_nt_masked", a, wT16, dx, act, M, K, _r32(N), lda, wT16.shape[1], K, float(pm), int(sm), st)
+                else:
+                    _call("ka_tf_gemm_nt", a, wT16, dx, None, None, M, K, _r32(N), lda, wT16.shape[1], K, 1, 0, 1, 0.0, 0, st)
         else:
             ns = max(1, min(256, (M + 511) // 512))
             if ns == 1:
@@ -292,8 +296,11 @@ class TransformerEngine:
             if p2 > 0:
                 g2 = torch.empty_like(dx)
                 _call("ka_tf_drop_apply", dx, None, None, g2, dx.numel(), p2, s_base + 4, code, st)
-            df = self._lin_bwd(g2, f, pre + "linear2", lyr.linear2.weight, grads, pre + "linear2.weight", pre + "linear2.bias", T, st)
-            _call("ka_tf_drop_apply", df, f, None, df, df.numel(), pf, s_base + 3, code, st)       # through dropout and ReLU
+            fused_mask = T == torch.bfloat16
+            df = self._lin_bwd(g2, f, pre + "linear2", lyr.linear2.weight, grads, pre + "linear2.weight", pre + "linear2.bias", T, st,
+                               dx_mask=(f, pf, s_base + 3) if fused_mask else None)
+            if not fused_mask:
+                _call("ka_tf_drop_apply", df, f, None, df, df.numel(), pf, s_base + 3, code, st)   # through dropout and ReLU
             dh2 = self._lin_bwd(df, h2, pre + "linear1", lyr.linear1.weight, grads, pre + "linear1.weight", pre + "linear1.bias", T, st)
             dxm = torch.empty_like(dx)
             dg, db = torch.empty(d, device=dev), torch.empty(d, device=dev)

@@ -60,6 +60,26 @@ def test_gemm_tn_bf16(M, N, K, ldb, split):
     assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(M) / 4)
 
 
+@pytest.mark.parametrize("M,N,K,p", [(300, 256, 96, 0.1), (130, 200, 64, 0.0), (257, 1024, 256, 0.3)])
+def test_masked_gemm_equals_gemm_then_dropout_relu_backward(M, N, K, p):
+    """ka_tf_gemm_nt_masked (dropout + ReLU backward in the epilogue of the input-gradient GEMM) against the two-launch
+    form it replaces: same (seed, element) mask, same activation test; full tiles take the LDS epilogue, ragged ones not."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    b = torch.randn(N, K, generator=g).bfloat16().to(DEV)
+    act = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    seed = 424242
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_tf_gemm_nt", a, b, ref, None, None, M, N, K, K, K, N, 1, 0, 1, 0.0, 0, st())
+    _lib.call("ka_tf_drop_apply", ref, act, None, ref, ref.numel(), p, seed, _lib.DTYPE_BF16, st())
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_tf_gemm_nt_masked", a, b, out, act, M, N, K, K, K, N, p, seed, st())
+    torch.cuda.synchronize()
+    r, o = ref.float().cpu(), out.float().cpu()
+    assert torch.equal(r == 0, o == 0) or float(((r == 0) != (o == 0)).float().mean()) < 1e-4      # same mask
+    assert float((r - o).abs().max()) <= 2e-2 * float(r.abs().max())
+
+
 def test_transpose_and_cast_pad():
     x = torch.randn(70, 45)
     out = torch.full((45, 96), 7.0, dtype=torch.bfloat16, device=DEV)

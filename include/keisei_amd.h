@@ -293,6 +293,11 @@ int ka_tf_layernorm_parts(long long M);
 int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const void* dres, void* dx, float* part, float* dgamma, float* dbeta, long long M, int d, int dtype,
                         void* stream);
+/* the same with a second output dx_drop = dx * dropout_keep(seed, element) (NULL: none): the gradient entering the sub-layer
+ * below through its dropout, written in the same pass */
+int ka_tf_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                             const void* dres, void* dx, void* dx_drop, float drop_p, unsigned long long seed, float* part,
+                             float* dgamma, float* dbeta, long long M, int d, int dtype, void* stream);
 /* out = in * keep [* (act > 0)] [+ res] */
 int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
                      unsigned long long seed, int dtype, void* stream);

@@ -85,6 +85,7 @@ _SIGS = {
     "ka_tf_layernorm_fwd": "pppppp q i f i p",
     "ka_tf_layernorm_parts": "q",
     "ka_tf_layernorm_bwd": "pppppp pppp q i i p",
+    "ka_tf_layernorm_bwd_drop": "pppppp pp f q ppp q i i p",
     "ka_tf_drop_apply": "pppp q f q i p",
     "ka_tf_colsum": "ppp q ii i p",
     "ka_tf_mean_pool": "pp ii i p",

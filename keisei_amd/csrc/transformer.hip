@@ -563,10 +563,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const T* __restrict__ dres,
                                                                 T* __restrict__ dx, float* __restrict__ part, long long M, int d,
-                                                                int rows_per_block, int L) {
+                                                                int rows_per_block, int L, T* __restrict__ dx_drop, float drop_p,
+                                                                unsigned long long seed) {
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int P = E::kPer16;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(drop_p);
     extern __shared__ float sm[];            // [4 waves][2][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / L, pl = lane - sub * L, rpw = 64 / L;
     float gm[P], dg[P], db[P];
@@ -607,7 +610,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
 #pragma unroll
                 for (int e = 0; e < P; ++e) v[e] += rr[e];
             }
-            *reinterpret_cast<vec16*>(dx + (size_t)row * d + pl * P) = E::pack(v);
+            const vec16 packed = E::pack(v);
+            *reinterpret_cast<vec16*>(dx + (size_t)row * d + pl * P) = packed;
+            if (dx_drop) {               // the same gradient through the dropout of the sub-layer below (its dY): mask of (seed, element)
+                float w[P];
+                E::unpack(packed, w);
+#pragma unroll
+                for (int e = 0; e < P; ++e) w[e] *= keep_scale(seed, (unsigned long long)row * d + pl * P + e, thresh, inv_keep);
+                *reinterpret_cast<vec16*>(dx_drop + (size_t)row * d + pl * P) = E::pack(w);
+            }
 #pragma unroll
             for (int e = 0; e < P; ++e) { dg[e] += dyv[e] * xh[e]; db[e] += dyv[e]; }
         }
@@ -1452,9 +1463,39 @@ extern "C" int ka_tf_layernorm_fwd(const void* x, const float* gamma, const floa
 }
 extern "C" int ka_tf_layernorm_parts(long long M) { const long long p = (M + 127) / 128; return (int)(p < 2048 ? p : 2048); }
 // dx = LayerNorm'(dy) [+ dres]; dgamma / dbeta [d] via part (ka_tf_layernorm_parts(M) * 2 * d floats)
+extern "C" int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
+                                unsigned long long seed, int dtype, void* stream);
+// sums of the [dgamma | dbeta] part rows straight into the two gradient tensors
+__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ part, float* __restrict__ outa, float* __restrict__ outb,
+                                                         int nparts, int d) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, g = threadIdx.x >> 5, n = 2 * d;
+    const int i = blockIdx.x * 32 + col;
+    const int per = (nparts + 7) / 8, lo = g * per, hi = min(nparts, lo + per);
+    float s = 0.f;
+    if (i < n) for (int p = lo; p < hi; ++p) s += part[(size_t)p * n + i];
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += red[u][col];
+        if (i < d) outa[i] = t; else outb[i - d] = t;
+    }
+}
+extern "C" int ka_tf_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                        const void* dres, void* dx, void* dx_drop, float drop_p, unsigned long long seed, float* part,
+                                        float* dgamma, float* dbeta, long long M, int d, int dtype, void* stream);
 extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                    const void* dres, void* dx, float* part, float* dgamma, float* dbeta, long long M, int d,
                                    int dtype, void* stream) {
+    return ka_tf_layernorm_bwd_drop(dy, x, gamma, mean, rstd, dres, dx, nullptr, 0.f, 0, part, dgamma, dbeta, M, d, dtype, stream);
+}
+// ... and, when dx_drop != NULL, a second output dx_drop = dx * dropout_keep(seed, element): the gradient entering the
+// sub-layer below through its dropout (the elementwise pass this saves read and wrote the token tensor once more)
+extern "C" int ka_tf_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                        const void* dres, void* dx, void* dx_drop, float drop_p, unsigned long long seed, float* part,
+                                        float* dgamma, float* dbeta, long long M, int d, int dtype, void* stream) {
     KA_REQUIRE(dy && x && gamma && mean && rstd && dx && part && dgamma && dbeta, "tf_layernorm_bwd: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nparts = ka_tf_layernorm_parts(M);
@@ -1463,15 +1504,18 @@ extern "C" int ka_tf_layernorm_bwd(const void* dy, const void* x, const float* g
                                               reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dx))) {
         KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_vec_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
                                                  static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
-                                                 static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb, L));
-    } else
-    KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
-                                             static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
-                                             static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb));
+                                                 static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb, L,
+                                                 static_cast<T*>(dx_drop), drop_p, seed));
+    } else {
+        KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nparts), dim3(256), 8 * d * sizeof(float), st,
+                                                 static_cast<const T*>(dy), static_cast<const T*>(x), gamma, mean, rstd,
+                                                 static_cast<const T*>(dres), static_cast<T*>(dx), part, M, d, rpb));
+        if (dx_drop) {               // (rows the 16-byte kernel does not cover: the mask as its own pass)
+            if (int rc = ka_tf_drop_apply(dx, nullptr, nullptr, dx_drop, M * d, drop_p, seed, dtype, stream)) return rc;
+        }
+    }
     // part rows are [dgamma | dbeta]
-    hipLaunchKernelGGL(sum_parts_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, part + (size_t)nparts * 2 * d, nparts, 2 * d);
-    (void)hipMemcpyAsync(dgamma, part + (size_t)nparts * 2 * d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbeta, part + (size_t)nparts * 2 * d + d, d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, dgamma, dbeta, nparts, d);
     return ka_check_launch("tf_layernorm_bwd");
 }
 

@@ -287,6 +287,7 @@ class TransformerEngine:
         # ---- encoder layers, last first
         nparts = _lib.query("ka_tf_layernorm_parts", M)
         lnws = self._buf("lnws", (nparts + 1) * 2 * d, torch.float32, dev)
+        g2_pre = None
         for i in range(len(sv.layers) - 1, -1, -1):
             lyr = m.encoder.layers[i]
             pre = f"encoder.layers.{i}."
@@ -294,8 +295,11 @@ class TransformerEngine:
             H = lyr.self_attn.num_heads
             g2 = dx
             if p2 > 0:
-                g2 = torch.empty_like(dx)
-                _call("ka_tf_drop_apply", dx, None, None, g2, dx.numel(), p2, s_base + 4, code, st)
+                if g2_pre is not None:           # written by the LayerNorm backward of the layer above, in the same pass as dx
+                    g2 = g2_pre
+                else:
+                    g2 = torch.empty_like(dx)
+                    _call("ka_tf_drop_apply", dx, None, None, g2, dx.numel(), p2, s_base + 4, code, st)
             fused_mask = T == torch.bfloat16
             df = self._lin_bwd(g2, f, pre + "linear2", lyr.linear2.weight, grads, pre + "linear2.weight", pre + "linear2.bias", T, st,
                                dx_mask=(f, pf, s_base + 3) if fused_mask else None)
@@ -304,12 +308,16 @@ class TransformerEngine:
             dh2 = self._lin_bwd(df, h2, pre + "linear1", lyr.linear1.weight, grads, pre + "linear1.weight", pre + "linear1.bias", T, st)
             dxm = torch.empty_like(dx)
             dg, db = torch.empty(d, device=dev), torch.empty(d, device=dev)
-            _call("ka_tf_layernorm_bwd", dh2, x_mid, lyr.norm2.weight, mu2, rs2, dx, dxm, lnws, dg, db, M, d, code, st)
+            fuse_ln = os.environ.get("KA_TF_LN_DROP", "1") != "0"
+            g1 = torch.empty_like(dxm) if (p1 > 0 and fuse_ln) else None   # dxm through the dropout after out_proj, same pass
+            _call("ka_tf_layernorm_bwd_drop", dh2, x_mid, lyr.norm2.weight, mu2, rs2, dx, dxm, g1, float(p1), int(s_base + 2),
+                  lnws, dg, db, M, d, code, st)
             grads[pre + "norm2.weight"], grads[pre + "norm2.bias"] = dg, db
-            g1 = dxm
-            if p1 > 0:
-                g1 = torch.empty_like(dxm)
-                _call("ka_tf_drop_apply", dxm, None, None, g1, dxm.numel(), p1, s_base + 2, code, st)
+            if g1 is None:
+                g1 = dxm
+                if p1 > 0:
+                    g1 = torch.empty_like(dxm)
+                    _call("ka_tf_drop_apply", dxm, None, None, g1, dxm.numel(), p1, s_base + 2, code, st)
             dattn = self._lin_bwd(g1, attn, pre + "self_attn.out_proj", lyr.self_attn.out_proj.weight, grads,
                                   pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", T, st)
             dqkv = torch.empty_like(qkv)
@@ -318,7 +326,14 @@ class TransformerEngine:
                                 pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias", T, st)
             dx_new = torch.empty_like(dx)
             dg, db = torch.empty(d, device=dev), torch.empty(d, device=dev)
-            _call("ka_tf_layernorm_bwd", dh1, x_in, lyr.norm1.weight, mu1, rs1, dxm, dx_new, lnws, dg, db, M, d, code, st)
+            g2_pre = None
+            p2_below, seed_below = 0.0, 0
+            if i > 0:
+                p2_below, seed_below = float(sv.layers[i - 1][12][2]), int(sv.layers[i - 1][13]) + 4
+                if p2_below > 0 and fuse_ln:
+                    g2_pre = torch.empty_like(dx)    # the layer below receives dx through the dropout after its linear2
+            _call("ka_tf_layernorm_bwd_drop", dh1, x_in, lyr.norm1.weight, mu1, rs1, dxm, dx_new, g2_pre, p2_below, seed_below,
+                  lnws, dg, db, M, d, code, st)
             grads[pre + "norm1.weight"], grads[pre + "norm1.bias"] = dg, db
             dx = dx_new
         # ---- embeddings and input projection

@@ -80,6 +80,39 @@ def test_masked_gemm_equals_gemm_then_dropout_relu_backward(M, N, K, p):
     assert float((r - o).abs().max()) <= 2e-2 * float(r.abs().max())
 
 
+@pytest.mark.parametrize("dtn,M,d", [("bf16", 500, 256), ("f32", 130, 64), ("bf16", 77, 24)])
+def test_layernorm_backward_second_output_is_the_dropped_gradient(dtn, M, d):
+    """ka_tf_layernorm_bwd_drop: dx as ka_tf_layernorm_bwd writes it, and dx_drop == ka_tf_drop_apply(dx) for the same
+    (seed, element) mask -- the 16-byte kernel (d = 256 bf16, d = 64 fp32) and the one-wave-per-row form (d = 24)."""
+    dt = torch.bfloat16 if dtn == "bf16" else torch.float32
+    code = _lib.dtype_code(dt)
+    g = torch.Generator().manual_seed(M + d)
+    dy = torch.randn(M, d, generator=g).to(dt).to(DEV); x = torch.randn(M, d, generator=g).to(dt).to(DEV)
+    dres = torch.randn(M, d, generator=g).to(dt).to(DEV)
+    gam = (torch.rand(d, generator=g) + 0.5).to(DEV)
+    mu = x.float().mean(1).contiguous(); rs = (x.float().var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    nparts = _lib.query("ka_tf_layernorm_parts", M)
+    part = torch.empty((nparts + 1) * 2 * d, device=DEV)
+    p, seed = 0.2, 991
+    outs = []
+    for fused in (False, True):
+        dx = torch.full((M, d), float("nan"), dtype=dt, device=DEV); dxd = torch.full((M, d), float("nan"), dtype=dt, device=DEV)
+        dg = torch.empty(d, device=DEV); db = torch.empty(d, device=DEV)
+        if fused:
+            _lib.call("ka_tf_layernorm_bwd_drop", dy, x, gam, mu, rs, dres, dx, dxd, p, seed, part, dg, db, M, d, code, st())
+        else:
+            _lib.call("ka_tf_layernorm_bwd", dy, x, gam, mu, rs, dres, dx, part, dg, db, M, d, code, st())
+            _lib.call("ka_tf_drop_apply", dx, None, None, dxd, dx.numel(), p, seed, code, st())
+        torch.cuda.synchronize()
+        outs.append((dx.float().cpu(), dxd.float().cpu(), dg.cpu(), db.cpu()))
+    (dx0, dd0, dg0, db0), (dx1, dd1, dg1, db1) = outs
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dd0 == 0, dd1 == 0)
+    assert float((dd0 - dd1).abs().max()) <= (1e-6 if dt == torch.float32 else 1e-2) * float(dd0.abs().max())
+    kept = float((dd1 != 0).float().mean())
+    assert abs(kept - (1 - p)) < 0.03
+
+
 def test_transpose_and_cast_pad():
     x = torch.randn(70, 45)
     out = torch.full((45, 96), 7.0, dtype=torch.bfloat16, device=DEV)

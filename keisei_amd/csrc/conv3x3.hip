@@ -397,7 +397,15 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
             }
                     }
         }
-        __syncthreads();
+        // the first k-step's weight fragments of this chunk are requested BEFORE the barrier that publishes the image and
+        // stay in flight across it (the barrier orders LDS traffic only): the MFMA phase no longer starts with an L2 round trip
+        vec16 bpre[NTW];
+        {
+            const char* wp = wbase + (size_t)(kc * (a.KC / CPK)) * ks_stride;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bpre[j] = *reinterpret_cast<const vec16*>(wp + (min(nt0 + j, NT - 1) - nt0) * 1024);
+        }
+        KA_LDS_BARRIER();
         if (a.stamps && tid == 0 && kc == 0) a.stamps[wg_lin * 8 + 1] = __builtin_amdgcn_s_memtime();
 
         // ---- MFMA phase: 9 taps x KS k-steps.  Weight fragments stream from L2 straight into registers,
@@ -449,11 +457,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                 }
             };
             vec16 b0[NTW], b1[NTW], a0[kMTW], a1[kMTW];
-            {
-                const char* wp = wptr(0);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) b0[j] = *reinterpret_cast<const vec16*>(wp + jofs[j]);
-            }
+            for (int j = 0; j < NTW; ++j) b0[j] = bpre[j];
             load_a(a0, lds_off(0));
             for (int it = 0; it < nsteps; it += 2) {
 #ifndef KA_DIAG_NO_W

@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     }
     const int nchunks = a.Cin / a.KC;
     for (int kc = 0; kc < nchunks; ++kc) {
-        if (kc > 0) __syncthreads();
+        // (the barrier that frees the image for the next chunk sits INSIDE the staging code, between the global loads of the
+        // first batch and their LDS writes: a wave that arrives early waits for the others with its loads already in flight)
         // ---- stage NB boards x KC channels into the haloed LDS tile (fused input transform)
         {
             const int c0 = kc * a.KC + sj * P16;
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                             w[u] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(static_cast<const char*>(a.in2) + off));
                         } else { v[u] = vec16{}; w[u] = vec16{}; }
                     }
+                    if (kc > 0 && pos0 == spos0) KA_LDS_BARRIER();      // every thread runs this first batch exactly once
 #pragma unroll
                     for (int u = 0; u < kU2; ++u) {
                         const int pos = pos0 + u * sstep;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                     else
                         v[u] = vec16{};
                 }
+                if (kc > 0 && pos0 == spos0) KA_LDS_BARRIER();          // every thread runs this first batch exactly once
 #pragma unroll
                 for (int u = 0; u < kUnr; ++u) {
                     const int pos = pos0 + u * sstep;

@@ -115,8 +115,18 @@ __global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __rest
     __shared__ double red[2][4][64];
     double s = 0.0, ss = 0.0;
     if (c < C) {
-        for (int r = slice; r < rowsA; r += nsl) s += (double)A[(size_t)r * C + c];
-        for (int r = slice; r < rowsB; r += nsl) ss += (double)Bp[(size_t)r * C + c];
+        // eight rows of each operand requested before the first is added (same order of additions: the loop was a chain of
+        // L2 round trips)
+        int r = slice;
+        for (; r + 7 * nsl < rowsA && r + 7 * nsl < rowsB; r += 8 * nsl) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { va[u] = A[(size_t)(r + u * nsl) * C + c]; vb[u] = Bp[(size_t)(r + u * nsl) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += (double)va[u]; ss += (double)vb[u]; }
+        }
+        for (int ra = r; ra < rowsA; ra += nsl) s += (double)A[(size_t)ra * C + c];
+        for (int rb = r; rb < rowsB; rb += nsl) ss += (double)Bp[(size_t)rb * C + c];
     }
     red[0][sub][threadIdx.x & 63] = s;
     red[1][sub][threadIdx.x & 63] = ss;

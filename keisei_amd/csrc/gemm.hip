@@ -394,7 +394,15 @@ __global__ __launch_bounds__(256) void rows_bn_sums_kernel(const float* __restri
     float s = 0.f, s2 = 0.f;
     if (n < N) {
         const float mu = mean[n], is = invstd[n];
-        for (int m = mbeg + sl; m < mend; m += 4) {
+        int m = mbeg + sl;
+        for (; m + 28 < mend; m += 32) {                 // eight rows in flight (same order of additions)
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = da[(size_t)(m + 4 * u) * N + n]; b[u] = in[(size_t)(m + 4 * u) * N + n]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += a[u]; s2 += a[u] * ((b[u] - mu) * is); }
+        }
+        for (; m < mend; m += 4) {
             const float a = da[(size_t)m * N + n];
             s += a; s2 += a * ((in[(size_t)m * N + n] - mu) * is);
         }
@@ -414,8 +422,17 @@ __global__ __launch_bounds__(256) void rows_sq_sums_kernel(const float* __restri
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     const int mbeg = blockIdx.y * rows_per, mend = min(M, mbeg + rows_per);
     float s = 0.f, s2 = 0.f;
-    if (n < N)
-        for (int m = mbeg + sl; m < mend; m += 4) { const float a = A[(size_t)m * N + n]; s += a; s2 += a * a; }
+    if (n < N) {
+        int m = mbeg + sl;
+        for (; m + 28 < mend; m += 32) {                 // eight rows in flight (same order of additions)
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = A[(size_t)(m + 4 * u) * N + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += a[u]; s2 += a[u] * a[u]; }
+        }
+        for (; m < mend; m += 4) { const float a = A[(size_t)m * N + n]; s += a; s2 += a * a; }
+    }
     red[0][sl][threadIdx.x & 63] = s; red[1][sl][threadIdx.x & 63] = s2;
     __syncthreads();
     if (sl == 0 && n < N) {

@@ -168,6 +168,13 @@ int ka_fc_chain_supported(int K1, int ldx, int H, int N2);
 int ka_fc_chain(const float* x, const float* in_scale, const float* in_shift, float in_alpha, const float* W1,
                 const float* b1, const float* W2, const float* b2, float* x_out, float* hidden_out, float* y, int M, int K1,
                 int ldx, int H, int N2, void* stream);
+/* backward of such a chain with respect to its input, one launch: dhidden = (dy W2) * [hidden > 0] (written: the dY of W1's
+ * weight gradient), dx = dhidden W1; W2T (H, N2) and W1T (K1, H) are transposed copies of the nn.Linear weights kept current
+ * by ka_transpose_multi (table rows {src, dst, rows, cols}).  Replaces autograd's input gradients of global_fc
+ * (se_resnet.py:62-63, 71). */
+int ka_fc_chain_bwd(const float* dy, const float* hidden, const float* W2T, const float* W1T, float* dhidden_out, float* dx,
+                    int M, int N2, int H, int K1, void* stream);
+int ka_transpose_multi(const void* table, int n, int max_tiles, void* stream);
 int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream);
 int ka_colsum(const float* A, const float* Bm, float* part, float* part2, int M, int N, int nsplit, void* stream);
 int ka_relu_mask(float* g, const float* h, long long n, void* stream);

@@ -67,6 +67,8 @@ _SIGS = {
     "ka_gemm_grouped_wgrad": "p ii p",
     "ka_fc_chain_supported": "iiii",
     "ka_fc_chain": "ppp f pppp ppp iiiii p",
+    "ka_fc_chain_bwd": "pppppp iiii p",
+    "ka_transpose_multi": "p ii p",
     "ka_mask_words": "i",
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",

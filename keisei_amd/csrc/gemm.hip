@@ -216,6 +216,7 @@ struct ChainArgs {
     float* hidden_out;   // optional (M,H): relu(W1 x' + b1)
     float* y;            // (M,N2)
     int M, K1, ldx, H, N2;
+    const float* hmask;  // optional (M,H): hidden = (W1 x') * [hmask > 0], no bias, no ReLU -- the backward of a chain (ReLU mask of the saved hidden)
 };
 
 __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
@@ -264,7 +265,11 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             if (ksplit == 1) {
                 const float bias = a.b1 ? a.b1[tile * 16 + r] : 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hs[(4 * q + i) * hs_ld + tile * 16 + r] = fmaxf(acc[i] + bias, 0.f);
+                for (int i = 0; i < 4; ++i) {
+                    float hv = fmaxf(acc[i] + bias, 0.f);
+                    if (a.hmask) hv = a.hmask[(size_t)min(m0 + 4 * q + i, a.M - 1) * a.H + tile * 16 + r] > 0.f ? acc[i] : 0.f;
+                    hs[(4 * q + i) * hs_ld + tile * 16 + r] = hv;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part[(kp * 16 + 4 * q + i) * a.H + tile * 16 + r] = acc[i];
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             const int row = i / a.H, n = i - row * a.H;
             float v = a.b1 ? a.b1[n] : 0.f;
             for (int kp = 0; kp < ksplit; ++kp) v += part[(kp * 16 + row) * a.H + n];
-            hs[row * hs_ld + n] = fmaxf(v, 0.f);
+            if (a.hmask) hs[row * hs_ld + n] = a.hmask[(size_t)min(m0 + row, a.M - 1) * a.H + n] > 0.f ? v : 0.f;
+            else hs[row * hs_ld + n] = fmaxf(v, 0.f);
         }
         __syncthreads();
     }
@@ -507,9 +513,69 @@ extern "C" int ka_fc_chain(const float* x, const float* in_scale, const float* i
     KA_REQUIRE(lds <= 160 * 1024, "fc_chain: LDS %zu B", lds);
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&fc_chain_kernel), attr_done, "fc_chain")) return rc;
-    ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2};
+    ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2, nullptr};
     hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("fc_chain");
+}
+
+// Backward of a two-layer chain y = W2 relu(W1 x + b1) + b2 with respect to x, in ONE launch:
+//     dhidden = (dy W2) * [hidden > 0]   (written to dhidden_out: the dY of W1's weight gradient)
+//     dx      = dhidden W1
+// W2T (H, N2) and W1T (K1, H) are the TRANSPOSED weights (ka_transpose_multi keeps such copies current): the kernel is the
+// forward chain kernel with the ReLU replaced by the saved-activation mask -- with nn.Linear's own [out, in] layout the
+// backward contraction runs along the strided axis (a fused form on that layout was slower than two GEMM launches).
+// Replaces autograd's input gradients of global_fc (se_resnet.py:62-63, 71): GEMM + mask + GEMM launches.
+extern "C" int ka_fc_chain_bwd(const float* dy, const float* hidden, const float* W2T, const float* W1T, float* dhidden_out,
+                               float* dx, int M, int N2, int H, int K1, void* stream) {
+    KA_REQUIRE(dy && hidden && W2T && W1T && dhidden_out && dx && M > 0, "fc_chain_bwd: null tensor");
+    // as a forward chain: input dy (M, N2) -> "hidden" width H -> output width K1
+    KA_REQUIRE(ka_fc_chain_supported(N2, N2, H, K1), "fc_chain_bwd: unsupported shape (N2=%d H=%d K1=%d)", N2, H, K1);
+    KA_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(W2T) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(W1T) & 15) == 0, "fc_chain_bwd: operands must be 16-byte aligned");
+    const int T1 = H / 16, ksplit = T1 >= 8 ? 1 : 8 / T1;
+    const size_t lds = (size_t)(16 * (N2 + 4) + 16 * (H + 4) + (ksplit > 1 ? ksplit * 16 * H : 0)) * sizeof(float);
+    KA_REQUIRE(lds <= 160 * 1024, "fc_chain_bwd: LDS %zu B", lds);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&fc_chain_kernel), attr_done, "fc_chain_bwd")) return rc;
+    ChainArgs a{dy, nullptr, nullptr, 1.f, W2T, nullptr, W1T, nullptr, nullptr, dhidden_out, dx, M, N2, N2, H, K1, hidden};
+    hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("fc_chain_bwd");
+}
+
+namespace {
+// table[n][4] (int64) = {src, dst, rows, cols}: dst (cols, rows) = src (rows, cols)^T, fp32; blockIdx.y picks the matrix
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const long long* __restrict__ table) {
+    __shared__ float tile[32][33];
+    const long long* t = table + (size_t)blockIdx.y * 4;
+    const KA_GLOBAL float* src = (const KA_GLOBAL float*)t[0];
+    KA_GLOBAL float* dst = (KA_GLOBAL float*)t[1];
+    const int R = (int)t[2], Cc = (int)t[3];
+    const int tiles_c = (Cc + 31) / 32, ntiles = ((R + 31) / 32) * tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k += 8) {
+            const int rr = r0 + ty + k, cc = c0 + tx;
+            tile[ty + k][tx] = (rr < R && cc < Cc) ? src[(size_t)rr * Cc + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k += 8) {
+            const int cc = c0 + ty + k, rr = r0 + tx;
+            if (cc < Cc && rr < R) dst[(size_t)cc * R + rr] = tile[tx][ty + k];
+        }
+    }
+}
+}  // namespace
+
+// n transposes in one launch (the transposed FC weight copies of ka_fc_chain_bwd, refreshed after an optimiser step)
+extern "C" int ka_transpose_multi(const void* table, int n, int max_tiles, void* stream) {
+    KA_REQUIRE(table && n > 0 && max_tiles > 0, "transpose_multi: bad arguments");
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(max_tiles < 64 ? max_tiles : 64, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const long long*>(table));
+    return ka_check_launch("transpose_multi");
 }
 
 extern "C" int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream) {

@@ -60,6 +60,7 @@ class SEResNetEngine:
         self._row_ring = None
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
         self._evalc_sets = {}
+        self._fc_tr_sets = {}                       # transposed global_fc weights of the backward chain
         self._tensor_lists = None                   # [buffers, parameters, calls until re-read] of the eval-graph key
         self._tower_tabs = {}                       # pointer tables of the one-launch eval tower (kept: graphs read them)
         self._evalc_live = None
@@ -309,6 +310,47 @@ class SEResNetEngine:
         _call("ka_fc_chain", x, sc, sh, float(alpha), lin1.weight, lin1.bias, lin2.weight, lin2.bias, xp, hidden, y,
               M, K1, ldx, H, N2, st)
         return xp, hidden, y
+
+    def _fc_transposed(self, device, st):
+        """Transposed copies of every block's global_fc weights for the one-launch backward chain (ka_fc_chain_bwd):
+        [(W2^T (G, C), W1^T (3C, G))] per block, refreshed by ONE launch when the weights changed."""
+        blocks = self.model.blocks
+        ptrs = tuple((b.global_fc[0].weight.data_ptr(), b.global_fc[2].weight.data_ptr()) for b in blocks)
+        ent = self._fc_tr_sets.get((str(device), ptrs))
+        if ent is None:
+            if len(self._fc_tr_sets) >= 4:
+                self._fc_tr_sets.clear()
+            views, rows, mt = [], [], 1
+            for b in blocks:
+                w1, w2 = b.global_fc[0].weight, b.global_fc[2].weight            # (G, 3C), (C, G)
+                w2t = torch.empty(w2.shape[1], w2.shape[0], device=device); w1t = torch.empty(w1.shape[1], w1.shape[0], device=device)
+                views.append((w2t, w1t))
+                for src, dst in ((w2, w2t), (w1, w1t)):
+                    rows.append([src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]])
+                    mt = max(mt, ((src.shape[0] + 31) // 32) * ((src.shape[1] + 31) // 32))
+            ent = {"views": views, "table": torch.tensor(rows, dtype=torch.int64).to(device), "n": len(rows), "mt": mt, "key": None}
+            self._fc_tr_sets[(str(device), ptrs)] = ent
+        key = (self.weights_epoch, sum(b.global_fc[0].weight._version + b.global_fc[2].weight._version for b in blocks))
+        if key != ent["key"]:
+            _call("ka_transpose_multi", ent["table"], ent["n"], ent["mt"], st)
+            ent["key"] = key
+        return ent["views"]
+
+    def _gpool_bwd(self, i, blk, dg, g1, bpool, grads, pre, st, tr):
+        """input gradient of the global-pool bias chain (+ its deferred weight / bias gradients): dg (B, C) -> dpool (B, 3C)"""
+        lin1, lin2 = blk.global_fc[0], blk.global_fc[2]
+        B = dg.shape[0]
+        if tr is not None:
+            w2t, w1t = tr[i]
+            dg1 = torch.empty(B, lin1.out_features, device=dg.device)
+            dpool_x = torch.empty(B, lin1.in_features, device=dg.device)
+            _call("ka_fc_chain_bwd", dg, g1, w2t, w1t, dg1, dpool_x, B, lin2.out_features, lin1.out_features, lin1.in_features, st)
+            self._linear_bwd(dg, g1, lin2, grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st, need_dx=False)
+            self._linear_bwd(dg1, bpool, lin1, grads, pre + "global_fc.0.weight", pre + "global_fc.0.bias", st, need_dx=False)
+            return dpool_x
+        dg1 = self._linear_bwd(dg, g1, lin2, grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
+        _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
+        return self._linear_bwd(dg1, bpool, lin1, grads, pre + "global_fc.0.weight", pre + "global_fc.0.bias", st)
 
     def _upload_rows(self, rows, device):
         """int64 table -> device through one of two rotating pinned buffers (the host never waits for the stream)."""
@@ -584,6 +626,13 @@ class SEResNetEngine:
         M = B * 81
         count = M
         self._fc_jobs = [] if os.environ.get("KA_FC_WGRAD_GROUPED", "1") != "0" else None
+        # the global-pool chain's input gradients in one launch per block (transposed weight copies, refreshed once per step)
+        fc_tr = None
+        if len(m.blocks) > 0 and os.environ.get("KA_FC_CHAIN_BWD", "1") != "0":
+            l1, l2 = m.blocks[0].global_fc[0], m.blocks[0].global_fc[2]
+            if (_lib.query("ka_fc_chain_supported", l2.out_features, l2.out_features, l1.out_features, l1.in_features)
+                    and all(b.global_fc[0].weight.is_contiguous() and b.global_fc[2].weight.is_contiguous() for b in m.blocks)):
+                fc_tr = self._fc_transposed(dev, st)
 
         def new_act(ch=C):
             return torch.empty(B, 81, ch, dtype=T, device=dev)
@@ -709,10 +758,7 @@ class SEResNetEngine:
                 dW2 = conv_grad(blk.conv2.weight, i, False)
                 self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
-                dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
-                _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
-                dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
-                                           pre + "global_fc.0.bias", st)
+                dpool_x = self._gpool_bwd(i, blk, dg, g1, bpool, grads, pre, st, fc_tr)
                 k1 = self._bn_backward(blk.bn1, ep1, ep2, rows, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
                 dy1, dxc = new_act(), new_act()
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dh, y1, k1, dy1, packs[pre + "conv1"][1], dxc, None,
@@ -729,10 +775,7 @@ class SEResNetEngine:
                 dW2 = conv_grad(blk.conv2.weight, i, False)
                 self._wgrad_launch(side, main, (dz, dW2), dz, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
-                dg1 = self._linear_bwd(dg, g1, blk.global_fc[2], grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st)
-                _call("ka_relu_mask", dg1, g1, dg1.numel(), st)
-                dpool_x = self._linear_bwd(dg1, bpool, blk.global_fc[0], grads, pre + "global_fc.0.weight",
-                                           pre + "global_fc.0.bias", st)
+                dpool_x = self._gpool_bwd(i, blk, dg, g1, bpool, grads, pre, st, fc_tr)
                 _call("ka_relu_bn_bwd_reduce", dh, y1, sc1, sh1, mu1, is1, dh, s1p, s2p, B, C, code, st)   # dh -> da1 in place
                 k1 = self._bn_backward(blk.bn1, s1p, s2p, B, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
                 _call("ka_bn_bwd_apply", dh, y1, k1, dh, B, C, code, st)                         # -> dy1 in place

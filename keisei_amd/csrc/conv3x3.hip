@@ -46,6 +46,7 @@ constexpr int kBoardStride = 193;            // squares between the two boards
 constexpr int kLdsSquares = kBoardStride + 11 * kPW;   // 380 (two boards)
 // single-board image: the squares any tap of any board square can address are 0 .. 10 * kPW + 10
 constexpr int kImgSquares1 = 10 * kPW + 11;            // 181
+constexpr int kZeroSquares = 2 * (kPW + 1) + 1;        // all-zero squares behind the image: the taps of its centre square (37)
 __device__ __forceinline__ int lds_square(int b, int p) { return b * kBoardStride + (p / 9 + 1) * kPW + (p % 9) + 1; }
 constexpr int kMTW = 6;                      // row tiles per wave: one board, 81 squares padded to 96 rows
 
@@ -275,9 +276,13 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < kMTW; ++mt) {
         int p = mt * 16 + r;                     // square of board `mhalf`
-        if (p >= KA_BOARD) p = 0;                // dummy rows read valid LDS; never stored
-        rowoff[mt] = lds_square(mhalf, p) * stride + q * 16;
+        // dummy rows (81 -> 96 padding; never stored) read an all-zero region behind the image: every tap offset of its
+        // centre square stays inside it.  Zero operands cost the matrix pipe less power than duplicates of square 0,
+        // and under this kernel the chip's clock is what the power budget leaves.
+        rowoff[mt] = (p >= KA_BOARD ? (kImgSquares + kPW + 1) : lds_square(mhalf, p)) * stride + q * 16;
     }
+    for (int i = tid; i < kZeroSquares * cpr; i += kThreads)
+        *reinterpret_cast<uint4*>(smem + (kImgSquares + i / cpr) * stride + (i % cpr) * 16) = uint4{0, 0, 0, 0};
 
     // zero the halo once (staging only ever writes interior squares)
     for (int i = tid; i < kImgSquares * cpr; i += kThreads) {
@@ -570,7 +575,7 @@ template <typename T, int NTW, int WM>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     typedef Elem<T> E;
     const int BN = 64 * NTW;
-    const size_t lds = (size_t)(WM == 2 ? kLdsSquares : kImgSquares1) * (a.KC * E::kSize + 32);
+    const size_t lds = (size_t)((WM == 2 ? kLdsSquares : kImgSquares1) + kZeroSquares) * (a.KC * E::kSize + 32);
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
     static std::atomic<unsigned long long> attr_done{0};   // per instantiation: devices already configured
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM>), attr_done, "conv3x3")) return rc;
@@ -594,7 +599,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 constexpr int kStNat = KA_BOARD * 512;                     // natural [81][256] bf16
 constexpr int kStImgStride = 128 * 2 + 32;
 constexpr int kStImg = 2 * kStNat;
-constexpr int kStLds = kStImg + kImgSquares1 * kStImgStride;
+constexpr int kStLds = kStImg + (kImgSquares1 + kZeroSquares) * kStImgStride;   // + the all-zero squares the padded rows read
 
 template <bool TWO>      // TWO: the two-tensor input of the data-gradient convolutions (and their optional masked epilogue)
 __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int nwg = gridDim.x;
     if ((int)blockIdx.x >= a.B) return;
-    for (int i = tid; i < kImgSquares1 * kStImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kStImg)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < (kImgSquares1 + kZeroSquares) * kStImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kStImg)[i] = uint4{0, 0, 0, 0};
 
     // ---- staging role: piece i = tid + 512 u (u < 6) of a board = row i / 32, 16-byte piece i % 32 = tid % 32 (8 channels)
     const int pc = tid & 31, ch0 = pc * 8;
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < kMTW; ++mt) {
         const int p = mt * 16 + r;
-        rowoff[mt] = kStImg + lds_square(0, p < KA_BOARD ? p : 0) * kStImgStride + q * 16;
+        rowoff[mt] = kStImg + (p < KA_BOARD ? lds_square(0, p) : kImgSquares1 + kPW + 1) * kStImgStride + q * 16;
     }
     const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
     auto wfrag = [&](int kc, int step, bf16x8 (&f)[2]) {   // step = tap*4 + ks4 within the 128-channel chunk (clamped)
@@ -766,7 +771,7 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     for (int steps = a.Cin / CPK; steps >= 1; --steps) {
         const int cand = steps * CPK;
         if (a.Cin % cand != 0 || 256 % (cand * E::kSize / 16) != 0) continue;
-        if ((size_t)img_squares * (cand * E::kSize + 32) > 150 * 1024) continue;
+        if ((size_t)(img_squares + kZeroSquares) * (cand * E::kSize + 32) > 150 * 1024) continue;
         kc = cand;
         break;
     }

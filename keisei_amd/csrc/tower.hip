@@ -25,7 +25,8 @@ constexpr int kImgSquares = 10 * kPW + 11;                // 181
 constexpr int kImgStride = kKC * 2 + 32;                  // 288 B: conflict-free 16-lane fragment reads
 constexpr int kNatStride = kC * 2;                        // natural [81][256] bf16
 constexpr int kXn = 0, kHn = kXn + KA_BOARD * kNatStride, kImg = kHn + KA_BOARD * kNatStride;
-constexpr int kVec = kImg + kImgSquares * kImgStride;     // float vectors
+constexpr int kZeroSquares = 2 * (kPW + 1) + 1;           // all-zero squares behind the image: what the padded rows (81 -> 96) read
+constexpr int kVec = kImg + (kImgSquares + kZeroSquares) * kImgStride;     // float vectors
 constexpr int kPooled = 0, kGbias = 3 * kC, kHid = kGbias + kC, kSeMean = kHid + 256, kSeHid = kSeMean + kC, kSeOut = kSeHid + 64;
 constexpr int kVecFloats = kSeOut + 2 * kC;
 constexpr int kTowerLds = kVec + kVecFloats * 4;
@@ -69,17 +70,18 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
     const int b = blockIdx.x;
     const int c0 = wave * 32 + q * 8;                     // this lane's 8 output channels
     // ---- board and its pooled statistics into LDS; the image halo is zeroed once
-    for (int i = tid; i < kImgSquares * kImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kImg)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < (kImgSquares + kZeroSquares) * kImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kImg)[i] = uint4{0, 0, 0, 0};
     for (int i = tid; i < KA_BOARD * 32; i += 512)
         reinterpret_cast<uint4*>(smem + kXn)[i] = reinterpret_cast<const uint4*>(a.x_in + (size_t)b * KA_BOARD * kC)[i];
     for (int i = tid; i < 3 * kC; i += 512) vec[kPooled + i] = a.pool_in[(size_t)b * 4 * kC + i];
 
-    // activation-fragment row offsets of this lane (6 row tiles; rows >= 81 read a valid square and are never stored)
+    // activation-fragment row offsets of this lane (6 row tiles; rows >= 81 are never stored)
     int rowoff[6];
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt) {
         const int p = mt * 16 + r;
-        rowoff[mt] = kImg + img_square(p < KA_BOARD ? p : 0) * kImgStride + q * 16;
+        // (padded rows read zeros: zero operands cost the matrix pipe less power, and the clock is what the power budget leaves)
+        rowoff[mt] = kImg + (p < KA_BOARD ? img_square(p) : kImgSquares + kPW + 1) * kImgStride + q * 16;
     }
     f32x4 acc[6][2];
 

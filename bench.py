@@ -411,10 +411,18 @@ def main() -> None:
         res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
         dist.all_reduce = real
         torch.cuda.synchronize()
+        # what the collectives of the N > 1 step cost on ONE rank (RCCL launch + stream hand-offs; no wire time): a few
+        # timed steps with them, to compare with the plain single-GPU line
+        t0 = time.perf_counter()
+        for i in range(5):
+            res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
+        torch.cuda.synchronize()
+        ms_with = (time.perf_counter() - t0) / 5 * 1e3
         m = res["algo"]._fused_end(res["fs"])
         if rank == 0:
             print(json.dumps({"dist_dry_run": True, "backend": backend, "world": world, "collectives_per_step": counts,
                               "overlapped_gradient_exchange": res["fs"]["reducer"] is not None,
+                              "ms_per_step_with_collectives_on_one_rank": round(ms_with, 2),
                               "train_metrics": {k: round(v, 5) for k, v in m.items()}}), flush=True)
         dist.destroy_process_group()
         return

@@ -413,16 +413,25 @@ def main() -> None:
         torch.cuda.synchronize()
         # what the collectives of the N > 1 step cost on ONE rank (RCCL launch + stream hand-offs; no wire time): a few
         # timed steps with them, to compare with the plain single-GPU line
-        t0 = time.perf_counter()
-        for i in range(5):
-            res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
-        torch.cuda.synchronize()
-        ms_with = (time.perf_counter() - t0) / 5 * 1e3
+        def timed5():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5):
+                res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 5 * 1e3
+        ms_with = timed5()
+        # the same with the SyncBN all-reduces turned into no-ops (their packing / coefficient kernels still run): what is
+        # left of the difference is the collective calls themselves
+        dist.all_reduce = lambda t, *a, **k: None if t.dtype == torch.float64 else real(t, *a, **k)
+        ms_nosync = timed5()
+        dist.all_reduce = real
         m = res["algo"]._fused_end(res["fs"])
         if rank == 0:
             print(json.dumps({"dist_dry_run": True, "backend": backend, "world": world, "collectives_per_step": counts,
                               "overlapped_gradient_exchange": res["fs"]["reducer"] is not None,
                               "ms_per_step_with_collectives_on_one_rank": round(ms_with, 2),
+                              "ms_per_step_with_syncbn_allreduce_as_noop": round(ms_nosync, 2),
                               "train_metrics": {k: round(v, 5) for k, v in m.items()}}), flush=True)
         dist.destroy_process_group()
         return

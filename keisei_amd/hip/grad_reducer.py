@@ -55,9 +55,10 @@ class OverlappedGradReducer:
         """a small gradient tensor: coalesced with the others into one collective at the end of the pass"""
         self._small.append(t)
 
-    def finish(self) -> None:
+    def finish(self):
         """end of the backward pass: coalesce the small tensors, wait (stream-ordered on the GPU) for every collective,
-        average."""
+        average.  Returns, for the tensors passed to add_small (same order), VIEWS of the reduced packed buffer: the caller
+        replaces its gradients by them (copying each of ~500 small tensors back cost ~500 launches per step)."""
         smalls, self._small = self._small, []
         packed = None
         if smalls:
@@ -70,13 +71,15 @@ class OverlappedGradReducer:
         self._pending = []
         if self.world > 1 and flats:
             torch._foreach_div_(flats, float(self.world))
+        views = []
         if packed is not None:
             off = 0
             for t in smalls:
                 n = t.numel()
-                t.copy_(packed[off:off + n].view_as(t))
+                views.append(packed[off:off + n].view_as(t))
                 off += n
         self.log.append(("finish", len(flats)))
+        return views
 
     @staticmethod
     def _event_now(t: torch.Tensor):

@@ -812,10 +812,12 @@ class SEResNetEngine:
                 lo, hi = fc_flat.data_ptr(), fc_flat.data_ptr() + 4 * fc_flat.numel()
                 in_flat = {n for n, t in grads.items() if lo <= t.data_ptr() < hi}
                 red.launch(fc_flat, "fc", red._event_now(fc_flat))
-            for n, t in grads.items():
-                if n not in in_flat and not (n.startswith("blocks.") and n.endswith(("conv1.weight", "conv2.weight"))):
-                    red.add_small(t)
-            red.finish()
+            small_names = [n for n, t in grads.items()
+                           if n not in in_flat and not (n.startswith("blocks.") and n.endswith(("conv1.weight", "conv2.weight")))]
+            for n in small_names:
+                red.add_small(grads[n])
+            for n, v in zip(small_names, red.finish()):
+                grads[n] = v                    # views of the reduced packed buffer (no per-tensor copy back)
         return grads
 
     def _linear_bwd_act(self, dy, x_act, lin, grads, wname, dx_act, bf, st):

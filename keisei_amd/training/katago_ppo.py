@@ -773,7 +773,15 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
         B, A = idx.shape[0], d["n_actions"]
         ht = fs.get("host_ms")                  # optional host-side (enqueue) timing per phase, no GPU sync (bench diagnostics)
         t0 = time.perf_counter() if ht is not None else 0.0
-        out = self.forward_model(d["obs"], gather_idx=idx)
+        ddp = fs.get("ddp")
+        if ddp is not None:
+            # DistributedDataParallel decides in ITS FORWARD whether its reducer will run in the coming backward
+            # (prepare_for_backward): the forward must already be under no_sync(), or DDP copies every gradient into its own
+            # buckets (one scaled-copy launch per parameter) and all-reduces them a second time beside the engine's exchange
+            with ddp.no_sync():
+                out = self.forward_model(d["obs"], gather_idx=idx)
+        else:
+            out = self.forward_model(d["obs"], gather_idx=idx)
         t1 = time.perf_counter() if ht is not None else 0.0
         logits = out.policy_logits.reshape(B, A)
         dlogits = torch.empty_like(logits)
@@ -787,7 +795,6 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
              float(self.current_entropy_coeff), fs["combined"], B, sp)
         self.optimizer.zero_grad(set_to_none=True)
         t2 = time.perf_counter() if ht is not None else 0.0
-        ddp = fs.get("ddp")
         if ddp is not None:
             # the engine exchanges gradient buckets DURING its backward (hip/grad_reducer.py); DDP's own post-backward
             # reduction is switched off for this pass

@@ -113,9 +113,9 @@ def _reducer_worker(rank: int, world: int, port: int, outdir: str) -> None:
     smalls = [torch.full((3,), float(rank)), torch.full((2, 2), 10.0 * rank)]
     for t in smalls:
         red.add_small(t)
-    red.finish()
+    smalls = red.finish()                                # views of the reduced packed buffer, in add_small order
     dist.all_reduce = real
-    torch.save({"buckets": buckets, "smalls": smalls, "calls": calls, "log": red.log, "collectives": red.collectives},
+    torch.save({"buckets": buckets, "smalls": [t.clone() for t in smalls], "calls": calls, "log": red.log, "collectives": red.collectives},
                os.path.join(outdir, f"red{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

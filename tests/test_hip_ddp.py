@@ -101,10 +101,14 @@ def _fused_worker(rank, world, port, outdir, overlap):
     if fs["reducer"] is not None:
         fs["reducer"].bucket_bytes = 4 * 2 * 9 * 32 * 32          # one block per bucket -> 3 conv buckets
     ddp.train()
+    # DistributedDataParallel arms its own reducer in its FORWARD: record what it saw there
+    sync_flags = []
+    hook = ddp.module.register_forward_pre_hook(lambda mod, inp: sync_flags.append(bool(ddp.require_backward_grad_sync)))
     algo._fused_step(fs, torch.arange(8, device="cuda:0"), torch.device("cuda:0"))
+    hook.remove()
     dist.all_reduce = real
     algo._fused_end(fs)
-    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "calls": calls,
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "calls": calls, "ddp_sync_in_forward": sync_flags,
                 "log": fs["reducer"].log if fs["reducer"] is not None else None}, os.path.join(outdir, f"f{int(overlap)}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -135,6 +139,9 @@ def test_fused_step_under_ddp_overlapped_exchange_equals_ddp_reducer():
     tags = [e[1] for e in on["log"] if e[0] == "launch"]
     assert tags == ["conv[2:3]", "conv[1:2]", "conv[0:1]", "fc", "small"], tags
     assert len(on["calls"]) == 2 * n_bn + 5
+    # with the engine-driven exchange DDP's own reducer must stay disarmed (its forward ran under no_sync): otherwise every
+    # gradient is copied into DDP's buckets and all-reduced a second time; without it, DDP's reducer is the exchange
+    assert on["ddp_sync_in_forward"] == [False] and off["ddp_sync_in_forward"] == [True]
 
 
 @pytest.mark.timeout(300)

@@ -137,30 +137,6 @@ __global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __rest
         part[(size_t)blockIdx.y * 2 * C + C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
     }
 }
-__global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* __restrict__ sums, int C2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C2) return;
-    double s = 0.0;
-    for (int k = 0; k < kRedSlices; ++k) s += part[(size_t)k * C2 + c];
-    sums[c] = s;
-}
-
-// SyncBatchNorm form of stage 2: the vector that travels through the cross-rank all-reduce is [2C sums | element count],
-// so the count is written here (no separate fill launch, no host-side scalar store), and the backward keeps an
-// un-reduced copy of the local sums (dgamma / dbeta are per-rank) without a clone launch.
-__global__ void colsum2_stage2_sync_kernel(const double* __restrict__ part, double* __restrict__ sums,
-                                           double* __restrict__ local_copy, double count, int C2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > C2) return;
-    double s = count;
-    if (c < C2) {
-        s = 0.0;
-        for (int k = 0; k < kRedSlices; ++k) s += part[(size_t)k * C2 + c];
-    }
-    sums[c] = s;
-    if (local_copy) local_copy[c] = s;
-}
-
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
 // `sums` is either the reduced [2C] vector (nparts == 1) or the stage-1 partials [nparts][2C], summed here in slice order
@@ -179,6 +155,27 @@ __device__ __forceinline__ double sum_parts(const double* __restrict__ p, int np
     for (; k < nparts; ++k) s += p[(size_t)k * stride + c];
     return s;
 }
+__global__ void colsum2_stage2_kernel(const double* __restrict__ part, double* __restrict__ sums, int C2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C2) return;
+    sums[c] = sum_parts(part, kRedSlices, C2, c);      // (16 partials in flight at a time, slice order)
+}
+
+// SyncBatchNorm form of stage 2: the vector that travels through the cross-rank all-reduce is [2C sums | element count],
+// so the count is written here (no separate fill launch, no host-side scalar store), and the backward keeps an
+// un-reduced copy of the local sums (dgamma / dbeta are per-rank) without a clone launch.
+__global__ void colsum2_stage2_sync_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                           double* __restrict__ local_copy, double count, int C2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > C2) return;
+    double s = count;
+    if (c < C2) {
+        s = sum_parts(part, kRedSlices, C2, c);        // (16 partials in flight at a time, slice order)
+    }
+    sums[c] = s;
+    if (local_copy) local_copy[c] = s;
+}
+
 __global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps,

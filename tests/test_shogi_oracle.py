@@ -1,0 +1,288 @@
+"""Pins oracle/shogi_oracle.c to the known answers the reference's own tests hold.  No Rust toolchain
+exists here, so these fixtures -- positions and expected outcomes restated from shogi-core/src/{game,rules}.rs and
+shogi-gym/src/{vec_env,observation,katago_observation,spatial_action_mapper}.rs test modules -- are the pin."""
+import numpy as np
+import pytest
+
+from oracle import shogi as S
+from oracle.shogi import BISHOP, GOLD, KING, LANCE, PAWN, ROOK, SILVER, WHITE, OracleVecEnv, sq
+
+
+def _env(board, hands, side, max_ply=500):
+    e = OracleVecEnv(1, max_ply)
+    e.set_state(0, board, hands, side)
+    return e
+
+
+def test_perft_from_the_start_position():
+    # game.rs:1225-1243 (30, 900, 25 470); 719 731 is the published depth-4 count for shogi
+    e = OracleVecEnv(1)
+    assert [e.perft(d) for d in (1, 2, 3)] == [30, 900, 25470]
+    assert e.perft(4) == 719731
+
+
+def test_start_position_mask_and_observation():
+    # vec_env.rs:1083-1101, 1590-1626; observation.rs / katago_observation.rs start-position tests
+    e = OracleVecEnv(3)
+    obs, mask = e.reset()
+    assert obs.shape == (3, 50, 9, 9) and mask.shape == (3, 11259)
+    assert mask.sum(axis=1).tolist() == [30, 30, 30]
+    o = obs[0]
+    assert o[0].sum() == 9 and o[14].sum() == 9                      # nine pawns a side
+    assert np.all(o[0][6] == 1) and np.all(o[14][2] == 1)            # own pawns on row 6, the opponent's on row 2
+    assert o[7][8, 4] == 1 and o[21][0, 4] == 1                      # kings
+    assert o[5][7, 1] == 1 and o[6][7, 7] == 1                       # own bishop / rook
+    assert o[19][1, 7] == 1 and o[20][1, 1] == 1                     # the opponent's bishop / rook
+    assert np.all(o[8:14] == 0) and np.all(o[22:28] == 0)            # nothing promoted
+    assert np.all(o[28:42] == 0)                                     # empty hands
+    assert np.all(o[42] == 1) and np.all(o[43] == 0)                 # Black to move, ply 0
+    assert np.all(o[44:50] == 0)                                     # no repetition, no check, reserved plane
+    assert not np.isnan(obs).any()
+
+
+def test_observation_flips_for_white_and_counts_ply():
+    e = OracleVecEnv(1, max_ply=100)
+    _, mask = e.reset()
+    a = S.encode(sq(6, 2), sq(5, 2))                                 # Black pushes the pawn on column 2
+    assert mask[0, a]
+    r = e.step([a])
+    o = r["observations"][0]
+    assert r["current_players"][0] == 1 and np.all(o[42] == 0)
+    assert np.all(o[43] == np.float32(1) / np.float32(100))
+    # seen from White the board is turned by 180 degrees: White's own pawns sit on row 6 again, and the pushed
+    # Black pawn (5,2) appears at (3,6)
+    assert np.all(o[0][6] == 1) and o[14][3, 6] == 1 and o[14][2, 6] == 0
+    assert r["legal_masks"][0].sum() == 30
+    assert r["step_metadata"]["ply_count"][0] == 1 if "step_metadata" in r else r["ply_count"][0] == 1
+    assert r["material_balance"][0] == 0 and r["captured_piece"][0] == 255 and r["rewards"][0] == 0
+
+
+def test_action_index_contract():
+    # spatial_action_mapper.rs:376-389 (flat index = square * 139 + move type; N, distance 4 -> slot 3)
+    assert S.encode(40, 40 - 4 * 9) == 40 * 139 + 3
+    seen = set()
+    for white in (False, True):
+        for to in range(81):
+            for h in range(1, 8):
+                idx = S.encode(0, to, drop=h, white=white)
+                assert 132 <= idx % 139 <= 138
+                assert S.decode(idx, white) == (0, to, 0, h)
+                if not white:
+                    seen.add(idx)
+    assert len(seen) == 81 * 7
+    for d, (dr, dc) in enumerate(zip(S_DR, S_DC)):                  # sliding round trip from the centre, :417-443
+        for dist in range(1, 9):
+            r, c = 4 + dr * dist, 4 + dc * dist
+            if not (0 <= r < 9 and 0 <= c < 9):
+                continue
+            for promote in (0, 1):
+                idx = S.encode(40, sq(r, c), promote)
+                assert idx == 40 * 139 + promote * 64 + d * 8 + dist - 1
+                assert S.decode(idx) == (40, sq(r, c), promote, 0)
+    for to, slot in ((sq(2, 3), 128), (sq(2, 5), 130)):              # knight jumps, :445-464
+        for promote in (0, 1):
+            idx = S.encode(40, to, promote)
+            assert idx == 40 * 139 + slot + promote
+            assert S.decode(idx) == (40, to, promote, 0)
+    # perspectives, :466-494: the same move has different indices for the two colours and both round-trip
+    ib, iw = S.encode(20, 11), S.encode(20, 11, white=True)
+    assert ib != iw and S.decode(ib) == (20, 11, 0, 0) and S.decode(iw, True) == (20, 11, 0, 0)
+    # a White knight moves down the board; seen from White it is the same forward jump
+    assert S.encode(sq(0, 1), sq(2, 2), white=True) % 139 in (128, 130)
+    assert S.decode(11259) is None
+    assert S.decode(0 * 139 + 0) is None                             # N from row 0 leaves the board
+
+
+S_DR = (-1, -1, 0, 1, 1, 1, 0, -1)
+S_DC = (0, 1, 1, 1, 0, -1, -1, -1)
+
+
+def _ufz_position(pinned_gold=False):
+    b, h = S.empty_board()
+    b[sq(0, 0)] = KING | WHITE
+    b[sq(8, 8)] = KING
+    b[sq(0, 8)] = ROOK
+    b[sq(2, 1)] = GOLD
+    b[sq(8, 0)] = LANCE
+    if pinned_gold:
+        b[sq(0, 1)] = GOLD | WHITE
+    h[0, 0] = 1
+    return b, h
+
+
+def test_pawn_drop_mate_fixtures():
+    # rules.rs:575-617 positive; :622-650 king escapes; :654-684 no check; :1356-1416 pinned defender;
+    # :1420-1468 White drops; :1472-1504 the king takes the pawn
+    e = _env(*_ufz_position(), 0)
+    assert e.uchi_fu_zume(0, sq(1, 0), 0)
+    _, mask = e.observe(0)
+    assert not mask[S.encode(0, sq(1, 0), drop=PAWN)]                # and so the drop is not in the legal mask
+    e = _env(*_ufz_position(pinned_gold=True), 0)
+    assert e.uchi_fu_zume(0, sq(1, 0), 0)
+
+    b, h = S.empty_board()
+    b[sq(0, 4)] = KING | WHITE; b[sq(8, 4)] = KING; h[0, 0] = 1
+    e = _env(b, h, 0)
+    assert not e.uchi_fu_zume(0, sq(1, 4), 0)
+    _, mask = e.observe(0)
+    assert mask[S.encode(0, sq(1, 4), drop=PAWN)] and not mask[S.encode(0, sq(0, 3), drop=PAWN)]   # (last rank: dead drop)
+
+    b, h = S.empty_board()
+    b[sq(0, 0)] = KING | WHITE; b[sq(8, 8)] = KING; h[0, 0] = 1
+    e = _env(b, h, 0)
+    assert not e.uchi_fu_zume(0, sq(4, 4), 0)
+
+    b, h = S.empty_board()
+    b[sq(8, 8)] = KING; b[sq(0, 0)] = KING | WHITE; b[sq(8, 0)] = ROOK | WHITE; b[sq(6, 7)] = GOLD | WHITE
+    b[sq(0, 8)] = LANCE | WHITE; h[1, 0] = 1
+    e = _env(b, h, 1)
+    assert e.uchi_fu_zume(0, sq(7, 8), 1)
+
+
+def _two_kings():
+    b, h = S.empty_board()
+    b[sq(8, 4)] = KING; b[sq(0, 4)] = KING | WHITE
+    return b, h
+
+
+def test_repetition_fixtures():
+    # rules.rs:692-752 (fourfold by king shuttle = Repetition), :756-810 (threefold is not enough)
+    cycle = ((sq(8, 4), sq(7, 4)), (sq(0, 4), sq(1, 4)), (sq(7, 4), sq(8, 4)), (sq(1, 4), sq(0, 4)))
+    e = _env(*_two_kings(), 0)
+    for _ in range(2):
+        for f, t in cycle:
+            e.play(0, f, t)
+    assert e.sennichite() == (S.R_PROGRESS, -1) and e.repetition_count() == 3
+    for f, t in cycle:
+        e.play(0, f, t)
+    assert e.sennichite() == (S.R_REPETITION, -1) and e.repetition_count() == 4
+    obs, _ = e.observe(0)
+    assert np.all(obs[46] == 1) and np.all(obs[44] == 0) and np.all(obs[45] == 0) and np.all(obs[47] == 0)
+
+
+def test_perpetual_check_fixtures():
+    # rules.rs:827-905: Black's rook chases the White king; White, the side being checked, wins.  :1508-1585 mirrored.
+    b, h = S.empty_board()
+    b[sq(0, 0)] = KING | WHITE; b[sq(8, 8)] = KING; b[sq(0, 8)] = ROOK
+    e = _env(b, h, 1)
+    assert e.in_check(0, 1)
+    for _ in range(3):
+        e.play(0, sq(0, 0), sq(1, 0)); e.play(0, sq(0, 8), sq(1, 8)); e.play(0, sq(1, 0), sq(0, 0)); e.play(0, sq(1, 8), sq(0, 8))
+    assert e.sennichite() == (S.R_PERPETUAL, 1)
+
+    b, h = S.empty_board()
+    b[sq(8, 8)] = KING; b[sq(0, 0)] = KING | WHITE; b[sq(8, 0)] = ROOK | WHITE
+    e = _env(b, h, 0)
+    assert e.in_check(0, 0)
+    for _ in range(3):
+        e.play(0, sq(8, 8), sq(7, 8)); e.play(0, sq(8, 0), sq(7, 0)); e.play(0, sq(7, 8), sq(8, 8)); e.play(0, sq(7, 0), sq(8, 0))
+    assert e.sennichite() == (S.R_PERPETUAL, 0)
+
+
+def _impasse_position(black_pawns, black_rooks, white_pawns, white_rooks):
+    # rules.rs:1190-1236 make_impasse_position
+    b, h = S.empty_board()
+    b[sq(0, 4)] = KING; b[sq(8, 4)] = KING | WHITE
+    n = 0
+    for r in range(3):
+        for c in range(9):
+            if (r, c) != (0, 4) and n < black_pawns:
+                b[sq(r, c)] = PAWN; n += 1
+    n = 0
+    for r in range(6, 9):
+        for c in range(9):
+            if (r, c) != (8, 4) and n < white_pawns:
+                b[sq(r, c)] = PAWN | WHITE; n += 1
+    h[0, 6], h[1, 6] = black_rooks, white_rooks
+    return b, h
+
+
+def test_impasse_fixtures():
+    # rules.rs:474-481 (start position: 27 points a side, nobody in the zone), :1254-1330
+    e = OracleVecEnv(1)
+    assert e.impasse_score(0, 0) == 27 and e.impasse_score(0, 1) == 27
+    assert e.zone_count(0, 0) == 0 and e.zone_count(0, 1) == 0 and e.impasse() == (S.R_PROGRESS, -1)
+    e = _env(*_impasse_position(9, 3, 9, 0), 0)
+    assert e.zone_count(0, 0) == 10 and e.zone_count(0, 1) == 10 and e.impasse_score(0, 0) == 24 and e.impasse_score(0, 1) == 9
+    assert e.impasse() == (S.R_IMPASSE, 0)
+    assert _env(*_impasse_position(9, 0, 9, 3), 0).impasse() == (S.R_IMPASSE, 1)
+    assert _env(*_impasse_position(9, 0, 9, 0), 0).impasse() == (S.R_PROGRESS, -1)
+    assert _env(*_impasse_position(9, 3, 9, 3), 0).impasse() == (S.R_IMPASSE, -1)
+    b, h = S.empty_board()                                           # :1588-1650 promoted pieces keep their base value
+    b[sq(4, 4)] = PAWN | S.PROM; b[sq(4, 5)] = BISHOP | S.PROM; b[sq(8, 4)] = KING; b[sq(0, 4)] = KING | WHITE
+    e = _env(b, h, 0)
+    assert e.impasse_score(0, 0) == 6
+
+
+def test_material_balance_and_rewards():
+    # rules.rs:957-1055; vec_env.rs:986-1060
+    e = OracleVecEnv(1)
+    assert e.material(0, 0) == 0 and e.material(0, 1) == 0
+    b, h = S.empty_board()
+    b[sq(8, 4)] = KING; b[sq(0, 4)] = KING | WHITE; b[sq(4, 4)] = ROOK
+    e = _env(b, h, 0)
+    assert e.material(0, 0) == 10 and e.material(0, 1) == -10
+    b[sq(4, 4)] = ROOK | S.PROM; h[1, 0] = 2; h[0, 3] = 1
+    e = _env(b, h, 0)
+    assert e.material(0, 0) == 12 - 2 + 5
+    assert S.reward(S.R_CHECKMATE, 0, 0) == 1 and S.reward(S.R_CHECKMATE, 0, 1) == -1
+    assert S.reward(S.R_PERPETUAL, 1, 1) == 1 and S.reward(S.R_PERPETUAL, 1, 0) == -1
+    assert S.reward(S.R_IMPASSE, 0, 0) == 1 and S.reward(S.R_IMPASSE, 0, 1) == -1 and S.reward(S.R_IMPASSE, -1, 0) == 0
+    for r in (S.R_REPETITION, S.R_MAXMOVES, S.R_PROGRESS):
+        assert S.reward(r, -1, 0) == 0
+
+
+def test_max_ply_truncation_auto_reset_and_counters():
+    # vec_env.rs:1261-1378: two plies with max_ply = 2 truncate, the env restarts from the start position, the terminal
+    # observation keeps the finished game, the counters move
+    e = OracleVecEnv(2, max_ply=2)
+    obs0, mask = e.reset()
+    rng = np.random.default_rng(0)
+    r = e.step([int(rng.choice(np.flatnonzero(m))) for m in mask])
+    assert not r["truncated"].any() and not r["terminated"].any() and r["ply_count"].tolist() == [1, 1]
+    r2 = e.step([int(rng.choice(np.flatnonzero(m))) for m in r["legal_masks"]])
+    assert r2["truncated"].all() and not r2["terminated"].any()
+    assert r2["termination_reason"].tolist() == [S.R_MAXMOVES] * 2 and r2["rewards"].tolist() == [0, 0]
+    assert r2["ply_count"].tolist() == [2, 2]
+    np.testing.assert_array_equal(r2["observations"], obs0)
+    assert r2["legal_masks"].sum(axis=1).tolist() == [30, 30] and r2["current_players"].tolist() == [0, 0]
+    assert np.all(r2["terminal_observations"][:, 43] == 1.0)         # ply / max_ply = 1 in the game that ended
+    st = e.stats()
+    assert st == dict(episodes_completed=2, episodes_drawn=0, episodes_truncated=2, total_episode_ply=4)
+
+
+def test_an_illegal_action_is_refused_before_anything_moves():
+    # vec_env.rs:651-690
+    e = OracleVecEnv(2)
+    _, mask = e.reset()
+    good = int(np.flatnonzero(mask[0])[0])
+    bad = int(np.flatnonzero(~mask[1])[0])
+    before = e.state(0)
+    with pytest.raises(RuntimeError, match="env 1"):
+        e.step([good, bad])
+    with pytest.raises(RuntimeError, match="env 0"):
+        e.step([-1, good])
+    after = e.state(0)
+    assert all(np.array_equal(x, y) for x, y in zip(before, after))
+
+
+def test_random_playouts_keep_the_invariants():
+    """Every piece is somewhere (40 in all), masks are never empty while a game runs, mates score +1 for the mover."""
+    e = OracleVecEnv(8, max_ply=200)
+    _, mask = e.reset()
+    rng = np.random.default_rng(1)
+    ends = 0
+    for _ in range(400):
+        acts = [int(rng.choice(np.flatnonzero(m))) for m in mask]
+        r = e.step(acts)
+        mask = r["legal_masks"]
+        assert mask.any(axis=1).all()
+        for i in range(8):
+            board, hands, side, ply = e.state(i)
+            assert (board != 0).sum() + hands.sum() == 40
+            assert side == r["current_players"][i]
+        done = r["terminated"] | r["truncated"]
+        ends += int(done.sum())
+        mate = r["termination_reason"] == S.R_CHECKMATE
+        assert np.all(r["rewards"][mate] == 1.0)
+    assert ends > 0 and e.stats()["episodes_completed"] == ends

@@ -267,6 +267,31 @@ int ka_tower_eval_supported(int C, int G, int R, int dtype);
 int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out, float* pool_out, const void* blocks, int nblocks, int B,
                   int C, int G, int R, int dtype, void* stream);
 
+/* ---- the vectorised shogi environment on the device (shogi-engine/crates/shogi-gym/src/vec_env.rs:556-855
+ * VecEnv(num_envs, max_ply, "katago", "spatial"), with the rules of shogi-core/src/{movegen,attack,rules,game}.rs, the
+ * observation planes of shogi-gym/src/katago_observation.rs:41-92 + observation.rs:81-153 and the action indices of
+ * spatial_action_mapper.rs:138-279).  One wave per game; all buffers are device memory owned by the caller:
+ *   state  n x ka_shogi_env_state_bytes() bytes: board[81] (piece.rs:10-19 bytes) hands[2][7] side in_check - ply key reps
+ *   keys   n x max(max_ply,1) u64, checks n x max(max_ply,1) u8: position key / "mover stood in check" of every ply
+ *   obs (n,50,9,9) fp32; mask (n,11259) bool bytes and/or mask_bits (n,352) u32 (bit j of word w = action 32w+j; at
+ *   least one of the two); current_players (n) u8.
+ * ka_shogi_env_reset: VecEnv::reset (vec_env.rs:617-645) -- or, with refresh != 0, derive key / check / masks from the
+ *   board, hands and side the caller has written into `state` (test fixtures; ply and history start at 0).
+ * ka_shogi_env_step: VecEnv::step (vec_env.rs:651-700, apply_moves :340-460).  Phase 1 checks every action against
+ *   prev_mask / prev_mask_bits (the masks of the previous call); *err = n - i for the first refused env i, and then NO
+ *   game moves (the reference raises before mutating).  Phase 2: make_move, check_termination (game.rs:355-387: move
+ *   limit, fourfold repetition / perpetual check, 24-point impasse, no legal move), rewards for the mover
+ *   (vec_env.rs:98-124), captured hand-type (255 none), TerminationReason, ply, material balance, episode counters
+ *   stats[4] u64 {completed, drawn, truncated, total ply}; finished games write terminal_obs (other rows are left as they
+ *   were) and restart from the start position; then observation and masks of every game's position to move. */
+int ka_shogi_env_state_bytes(void);
+int ka_shogi_env_reset(void* state, void* keys, void* checks, int n, int max_ply, float* obs, void* mask, void* mask_bits,
+                       void* current_players, int refresh, void* stream);
+int ka_shogi_env_step(void* state, void* keys, void* checks, const long long* actions, int n, int max_ply,
+                      const void* prev_mask, const void* prev_mask_bits, int* err, float* obs, void* mask, void* mask_bits,
+                      float* rewards, void* terminated, void* truncated, float* terminal_obs, void* current_players,
+                      void* captured, void* term_reason, void* ply_count, int* material, void* stats, void* stream);
+
 /* ---- transformer encoder path (BASELINE config 5; keisei/training/models/transformer.py:37-95: nn.Linear(50, d),
  * row/col nn.Embedding, nn.TransformerEncoder(nn.TransformerEncoderLayer(d, nhead, 4d, batch_first, norm_first), L),
  * nn.Linear(81 d, 11259), value head).  Tokens are (B*81, d) row-major, bf16 (autocast) or fp32 (parity mode; its linear

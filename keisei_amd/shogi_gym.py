@@ -1,0 +1,265 @@
+"""Device-resident mirror of the reference's `shogi_gym.VecEnv`.
+
+Reference: shogi-engine/crates/shogi-gym/src/vec_env.rs:556-855 (the PyO3 class), step_result.rs:31-97 (result types).
+Same constructor, `reset()` / `step(actions)`, result attributes, counters and error behaviour -- but the N games live in
+HBM and a step is two launches of `shogi_env.hip` (C ABI `ka_shogi_env_*`, include/keisei_amd.h).  Only the modes the
+KataGo loop asks for (katago_loop.py:580-585: observation_mode="katago", action_mode="spatial") exist on the device.
+
+`output="numpy"` (default) returns host arrays like the reference does; `output="torch"` returns the device tensors
+themselves (observations and masks alternate between two buffers, so a result stays intact until the step after the
+next one) -- the form `select_actions` and the device rollout store consume without a host round trip.
+There is no CPU fallback: without the HIP library or a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACTION_SPACE = 81 * 139
+OBS_CHANNELS = 50
+MASK_WORDS = (ACTION_SPACE + 31) // 32
+
+_SFEN = {1: "P", 2: "L", 3: "N", 4: "S", 5: "G", 6: "B", 7: "R", 8: "K"}
+
+
+@dataclass
+class StepMetadata:          # step_result.rs:31-47
+    captured_piece: Any
+    termination_reason: Any
+    ply_count: Any
+    material_balance: Any
+
+
+@dataclass
+class StepResult:            # step_result.rs:50-83
+    observations: Any
+    legal_masks: Any
+    rewards: Any
+    terminated: Any
+    truncated: Any
+    terminal_observations: Any
+    current_players: Any
+    step_metadata: StepMetadata
+    legal_mask_bits: Any = None      # (N, 352) int32 packed rows (torch output only): the device rollout store's column
+
+
+@dataclass
+class ResetResult:           # step_result.rs:86-97
+    observations: Any
+    legal_masks: Any
+    legal_mask_bits: Any = None
+
+
+class VecEnv:
+    def __init__(self, num_envs: int = 512, max_ply: int = 500, observation_mode: str = "default",
+                 action_mode: str = "default", *, device: Optional[torch.device] = None, output: str = "numpy",
+                 check_actions: bool = True):
+        if observation_mode not in ("default", "katago"):
+            raise ValueError(f"Unknown observation_mode '{observation_mode}'. Valid: 'default', 'katago'")
+        if action_mode not in ("default", "spatial"):
+            raise ValueError(f"Unknown action_mode '{action_mode}'. Valid: 'default', 'spatial'")
+        if observation_mode != "katago" or action_mode != "spatial":
+            raise NotImplementedError("the device VecEnv implements observation_mode='katago' with action_mode='spatial' "
+                                      "(what the KataGo loop uses, katago_loop.py:580-585); the 46-plane / 13 527-action "
+                                      "modes were not built")
+        if output not in ("numpy", "torch"):
+            raise ValueError("output must be 'numpy' or 'torch'")
+        if num_envs <= 0 or max_ply < 0 or max_ply > 65535:
+            raise ValueError("num_envs must be positive and 0 <= max_ply <= 65535")
+        _lib._load()                                          # raises KeiseiHipError when the library is missing
+        if not torch.cuda.is_available():
+            raise _lib.KeiseiHipError("keisei_amd.shogi_gym.VecEnv needs a GPU (there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._n, self._max_ply, self._output, self._check = int(num_envs), int(max_ply), output, bool(check_actions)
+        n, dev, hist = self._n, self.device, max(self._max_ply, 1)
+        z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=dev)
+        self._state = z(n, _lib.query("ka_shogi_env_state_bytes"), dtype=torch.uint8)
+        self._keys = z(n, hist, dtype=torch.int64)
+        self._checks = z(n, hist, dtype=torch.uint8)
+        self._obs = [z(n, OBS_CHANNELS, 9, 9, dtype=torch.float32) for _ in range(2)]
+        self._mask = [z(n, ACTION_SPACE, dtype=torch.bool) for _ in range(2)]
+        self._bits = [z(n, MASK_WORDS, dtype=torch.int32) for _ in range(2)]
+        self._cur = 0
+        self._rewards = z(n, dtype=torch.float32)
+        self._terminated = z(n, dtype=torch.bool)
+        self._truncated = z(n, dtype=torch.bool)
+        self._terminal_obs = z(n, OBS_CHANNELS, 9, 9, dtype=torch.float32)
+        self._players = z(n, dtype=torch.uint8)
+        self._captured = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+        self._reason = z(n, dtype=torch.uint8)
+        self._ply = z(n, dtype=torch.int16)                   # u16 payload (max_ply <= 65535); viewed as uint16 on the host
+        self._material = z(n, dtype=torch.int32)
+        self._stats = z(4, dtype=torch.int64)
+        self._err = z(1, dtype=torch.int32)
+        self._actions = z(n, dtype=torch.int64)
+        self._started = False
+
+    # ------------------------------------------------------------------ core
+    def reset(self) -> ResetResult:
+        """vec_env.rs:617-645: every game back to the start position; observations and masks of the first move."""
+        with torch.cuda.device(self.device):
+            self._cur = 0
+            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._obs[0],
+                      self._mask[0], self._bits[0], self._players, 0, _lib.stream_ptr())
+        self._started = True
+        return ResetResult(self._out(self._obs[0]), self._out(self._mask[0]),
+                           self._bits[0] if self._output == "torch" else None)
+
+    def step(self, actions) -> StepResult:
+        """vec_env.rs:651-790.  `actions`: N action indices (list, numpy array or tensor; a CUDA int64 tensor is used in place)."""
+        if not self._started:
+            self.reset()
+        n = self._n
+        if isinstance(actions, torch.Tensor):
+            if actions.numel() != n:
+                raise ValueError(f"expected {n} actions, got {actions.numel()}")
+            act = actions.reshape(n)
+            if act.device != self.device or act.dtype != torch.int64 or not act.is_contiguous():
+                self._actions.copy_(act.to(torch.int64), non_blocking=True)
+                act = self._actions
+        else:
+            a = np.asarray(actions, dtype=np.int64).reshape(-1)
+            if a.shape[0] != n:
+                raise ValueError(f"expected {n} actions, got {a.shape[0]}")
+            self._actions.copy_(torch.from_numpy(a), non_blocking=False)
+            act = self._actions
+        prev, nxt = self._cur, self._cur ^ 1
+        with torch.cuda.device(self.device):
+            _lib.call("ka_shogi_env_step", self._state, self._keys, self._checks, act, n, self._max_ply,
+                      self._mask[prev], self._bits[prev], self._err, self._obs[nxt], self._mask[nxt], self._bits[nxt],
+                      self._rewards, self._terminated, self._truncated, self._terminal_obs, self._players,
+                      self._captured, self._reason, self._ply, self._material, self._stats, _lib.stream_ptr())
+        if self._check:
+            self.raise_if_refused(act)
+        self._cur = nxt
+        o = self._out
+        ply = self._ply if self._output == "torch" else self._ply.cpu().numpy().view(np.uint16)
+        meta = StepMetadata(o(self._captured), o(self._reason), ply, o(self._material))
+        return StepResult(o(self._obs[nxt]), o(self._mask[nxt]), o(self._rewards), o(self._terminated), o(self._truncated),
+                          o(self._terminal_obs), o(self._players), meta, self._bits[nxt] if self._output == "torch" else None)
+
+    def raise_if_refused(self, actions: Optional[torch.Tensor] = None) -> None:
+        """The reference refuses a step before anything moves (vec_env.rs:660-690); so does the kernel, and this reads
+        its flag (one 4-byte copy).  With check_actions=False call it whenever convenient; a refused step is a no-op."""
+        e = int(self._err.item())
+        if e == 0:
+            return
+        i = self._n - e
+        a = int((actions if actions is not None else self._actions)[i].item())
+        if a < 0:
+            raise ValueError(f"env {i}: negative action index {a}")
+        raise RuntimeError(f"env {i}: action index {a} is not legal")
+
+    def _out(self, t: torch.Tensor):
+        return t if self._output == "torch" else t.cpu().numpy()
+
+    # ------------------------------------------------------------------ properties (vec_env.rs:793-870)
+    @property
+    def action_space_size(self) -> int:
+        return ACTION_SPACE
+
+    @property
+    def observation_channels(self) -> int:
+        return OBS_CHANNELS
+
+    @property
+    def num_envs(self) -> int:
+        return self._n
+
+    def _stat(self, i: int) -> int:
+        return int(self._stats[i].item())
+
+    @property
+    def episodes_completed(self) -> int:
+        return self._stat(0)
+
+    @property
+    def episodes_drawn(self) -> int:
+        return self._stat(1)
+
+    @property
+    def episodes_truncated(self) -> int:
+        return self._stat(2)
+
+    @property
+    def draw_rate(self) -> float:
+        c = self._stat(0)
+        return 0.0 if c == 0 else self._stat(1) / c
+
+    @property
+    def mean_episode_length(self) -> float:
+        c = self._stat(0)
+        return 0.0 if c == 0 else self._stat(3) / c
+
+    @property
+    def truncation_rate(self) -> float:
+        c = self._stat(0)
+        return 0.0 if c == 0 else self._stat(2) / c
+
+    def reset_stats(self) -> None:
+        self._stats.zero_()
+
+    # ------------------------------------------------------------------ positions
+    def get_state(self, game_id: int):
+        """(board[81] piece bytes, hands[2][7], side to move, ply) of one game (piece bytes: piece.rs:10-19)."""
+        if not 0 <= game_id < self._n:
+            raise IndexError(f"game_id {game_id} out of range for {self._n} environments")
+        raw = self._state[game_id].cpu().numpy()
+        return raw[:81].copy(), raw[81:95].reshape(2, 7).copy(), int(raw[95]), int(raw[100:104].view(np.uint32)[0])
+
+    def set_state(self, game_id: int, board, hands, side: int) -> None:
+        """Place a position in one game (ply and history restart at 0) and refresh every game's observation and masks --
+        the rule fixtures of the reference's tests build their positions square by square (rules.rs:575-1790)."""
+        raw = np.zeros(self._state.shape[1], np.uint8)
+        raw[:81] = np.asarray(board, np.uint8).reshape(81)
+        raw[81:95] = np.asarray(hands, np.uint8).reshape(14)
+        raw[95] = side
+        self._state[game_id].copy_(torch.from_numpy(raw))
+        others = [self.get_state(i) for i in range(self._n) if i != game_id]
+        if any(p != 0 for *_, p in others):
+            raise RuntimeError("set_state refreshes all games from ply 0: call it right after reset()")
+        with torch.cuda.device(self.device):
+            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._obs[self._cur],
+                      self._mask[self._cur], self._bits[self._cur], self._players, 1, _lib.stream_ptr())
+        self._started = True
+
+    def current(self) -> ResetResult:
+        """Observation and masks of the positions to move (what the last reset / step / set_state wrote)."""
+        c = self._cur
+        return ResetResult(self._out(self._obs[c]), self._out(self._mask[c]), self._bits[c] if self._output == "torch" else None)
+
+    def get_sfen(self, game_id: int) -> str:
+        """vec_env.rs:873-882 / sfen.rs:93-171."""
+        board, hands, side, _ = self.get_state(game_id)
+        rows = []
+        for r in range(9):
+            s, empty = "", 0
+            for c in range(9):
+                p = int(board[r * 9 + c])
+                if not p:
+                    empty += 1
+                    continue
+                if empty:
+                    s, empty = s + str(empty), 0
+                ch = _SFEN[p & 15]
+                s += ("+" if p & 0x20 else "") + (ch.lower() if p & 0x10 else ch)
+            rows.append(s + (str(empty) if empty else ""))
+        hs = ""
+        for color in (0, 1):
+            for h in (6, 5, 4, 3, 2, 1, 0):                   # R B G S N L P
+                cnt = int(hands[color, h])
+                if cnt:
+                    ch = _SFEN[h + 1]
+                    hs += (str(cnt) if cnt > 1 else "") + (ch.lower() if color else ch)
+        return f"{'/'.join(rows)} {'w' if side else 'b'} {hs or '-'} 1"
+
+    def get_sfens(self) -> List[str]:
+        return [self.get_sfen(i) for i in range(self._n)]
+
+    def get_spectator_data(self):
+        raise NotImplementedError("spectator dictionaries belong to the reference's web UI (out of scope, DESIGN.md §7)")

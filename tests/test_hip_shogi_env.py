@@ -1,0 +1,272 @@
+"""SURVEY §8 f3 parity: the device VecEnv (shogi_env.hip behind keisei_amd.shogi_gym.VecEnv) against the CPU oracle
+(oracle/shogi_oracle.c, pinned by tests/test_shogi_oracle.py) -- bit for bit, every output of every step."""
+import numpy as np
+import pytest
+import torch
+
+from keisei_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from keisei_amd.shogi_gym import VecEnv  # noqa: E402
+from oracle import shogi as S  # noqa: E402
+from oracle.shogi import BISHOP, GOLD, KING, LANCE, PAWN, ROOK, SILVER, WHITE, OracleVecEnv, sq  # noqa: E402
+
+FIELDS = ("observations", "legal_masks", "rewards", "terminated", "truncated", "terminal_observations", "current_players")
+META = ("captured_piece", "termination_reason", "ply_count", "material_balance")
+
+
+def _env(n, max_ply, **kw):
+    return VecEnv(num_envs=n, max_ply=max_ply, observation_mode="katago", action_mode="spatial", **kw)
+
+
+def _compare_step(dev, ref, tag):
+    for k in FIELDS:
+        a, b = getattr(dev, k), ref[k]
+        assert a.dtype == b.dtype and a.shape == b.shape, (tag, k, a.dtype, b.dtype, a.shape, b.shape)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError(f"{tag}: {k} differs at {bad[:5].tolist()} ({len(bad)} entries)")
+    for k in META:
+        a, b = getattr(dev.step_metadata, k), ref[k]
+        assert a.dtype == b.dtype and np.array_equal(a, b), (tag, k, a[:8], b[:8])
+
+
+def _playout(n, max_ply, steps, seed, compare_states_every=25):
+    dev, ref = _env(n, max_ply), OracleVecEnv(n, max_ply)
+    r0, (obs, mask) = dev.reset(), ref.reset()
+    assert np.array_equal(r0.observations, obs) and np.array_equal(r0.legal_masks, mask)
+    rng = np.random.default_rng(seed)
+    reasons = np.zeros(6, int)
+    for s in range(steps):
+        acts = np.array([rng.choice(np.flatnonzero(m)) for m in mask], dtype=np.int64)
+        rd, rr = dev.step(acts), ref.step(acts)
+        _compare_step(rd, rr, f"step {s}")
+        mask = rr["legal_masks"]
+        done = rr["terminated"] | rr["truncated"]
+        for x in rr["termination_reason"][done]:
+            reasons[x] += 1
+        if s % compare_states_every == 0:
+            for i in range(0, n, max(1, n // 8)):
+                bd, hd, sd, pd = dev.get_state(i)
+                bo, ho, so, po = ref.state(i)
+                assert np.array_equal(bd, bo) and np.array_equal(hd, ho) and (sd, pd) == (so, po)
+    st = ref.stats()
+    assert (dev.episodes_completed, dev.episodes_drawn, dev.episodes_truncated) == (
+        st["episodes_completed"], st["episodes_drawn"], st["episodes_truncated"])
+    assert dev.mean_episode_length == (st["total_episode_ply"] / st["episodes_completed"] if st["episodes_completed"] else 0.0)
+    return reasons
+
+
+def test_reset_matches_the_oracle_and_the_reference_facts():
+    dev = _env(5, 500)
+    r = dev.reset()
+    obs, mask = OracleVecEnv(5, 500).reset()
+    assert r.observations.dtype == np.float32 and r.observations.shape == (5, 50, 9, 9)
+    assert r.legal_masks.dtype == np.bool_ and r.legal_masks.shape == (5, 11259)
+    assert np.array_equal(r.observations, obs) and np.array_equal(r.legal_masks, mask)
+    assert r.legal_masks.sum(axis=1).tolist() == [30] * 5                         # vec_env.rs:1083-1101
+    assert dev.action_space_size == 11259 and dev.observation_channels == 50 and dev.num_envs == 5
+    assert dev.get_sfen(0) == "lnsgkgsnl/1r5b1/ppppppppp/9/9/9/PPPPPPPPP/1B5R1/LNSGKGSNL b - 1"
+
+
+def test_random_playouts_short_games():
+    """max_ply 40: many truncations and restarts; every output of 300 steps x 64 games is identical."""
+    reasons = _playout(64, 40, 300, seed=1)
+    assert reasons[S.R_MAXMOVES] > 100
+
+
+def test_random_playouts_long_games():
+    """max_ply 300: captures, drops, promotions, mates (random play mates in roughly a tenth of the games)."""
+    reasons = _playout(96, 300, 700, seed=2)
+    assert reasons[S.R_CHECKMATE] > 0
+
+
+def test_odd_env_counts_and_mask_alignment():
+    # rows of 11 259 bytes start at every alignment: 1, 3 and 17 games cover head / body / tail of the byte writer
+    for n in (1, 3, 17):
+        _playout(n, 30, 45, seed=n)
+
+
+def test_packed_masks_are_the_bool_masks():
+    dev = _env(9, 50, output="torch")
+    r = dev.reset()
+    for _ in range(20):
+        m = r.legal_masks
+        bits = r.legal_mask_bits.cpu().numpy().view(np.uint32)
+        ref = np.zeros((9, 352 * 32), bool); ref[:, :11259] = m.cpu().numpy()
+        assert np.array_equal(np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little").astype(bool), ref)
+        probs = m.float()
+        acts = torch.multinomial(probs, 1).squeeze(1)
+        r = dev.step(acts)
+    assert r.observations.is_cuda and r.step_metadata.material_balance.dtype == torch.int32
+
+
+def _fixture(board, hands, side, max_ply=500):
+    dev, ref = _env(1, max_ply), OracleVecEnv(1, max_ply)
+    dev.reset(); ref.reset()
+    dev.set_state(0, board, hands, side); ref.set_state(0, board, hands, side)
+    return dev, ref
+
+
+def _same_view(dev, ref):
+    cur = dev.current()
+    obs, mask = ref.observe(0)
+    assert np.array_equal(cur.observations[0], obs), np.argwhere(cur.observations[0] != obs)[:5]
+    if not np.array_equal(cur.legal_masks[0], mask):
+        d = np.flatnonzero(cur.legal_masks[0] != mask)
+        raise AssertionError(f"mask differs at {[(int(i) // 139, int(i) % 139) for i in d[:8]]}")
+    return mask
+
+
+def _ufz(pinned=False):
+    b, h = S.empty_board()
+    b[sq(0, 0)] = KING | WHITE; b[sq(8, 8)] = KING; b[sq(0, 8)] = ROOK; b[sq(2, 1)] = GOLD; b[sq(8, 0)] = LANCE
+    if pinned:
+        b[sq(0, 1)] = GOLD | WHITE
+    h[0, 0] = 1
+    return b, h
+
+
+def test_rule_fixture_positions_give_the_same_masks():
+    """The reference's pawn-drop-mate / pin / escape fixtures (rules.rs:575-684, 1356-1504), plus a few positions with
+    checks, pins, promotions zones and full hands."""
+    cases = [(*_ufz(), 0), (*_ufz(True), 0)]
+    b, h = S.empty_board(); b[sq(0, 4)] = KING | WHITE; b[sq(8, 4)] = KING; h[0, 0] = 1
+    cases.append((b, h, 0))
+    b, h = S.empty_board()
+    b[sq(8, 8)] = KING; b[sq(0, 0)] = KING | WHITE; b[sq(8, 0)] = ROOK | WHITE; b[sq(6, 7)] = GOLD | WHITE; b[sq(0, 8)] = LANCE | WHITE
+    h[1, 0] = 1
+    cases.append((b, h, 1))
+    # Black in check from a rook with a pinned silver and pieces to interpose from hand
+    b, h = S.empty_board()
+    b[sq(8, 4)] = KING; b[sq(0, 4)] = KING | WHITE; b[sq(3, 4)] = ROOK | WHITE; b[sq(7, 3)] = SILVER; b[sq(5, 1)] = BISHOP | WHITE
+    b[sq(6, 0)] = PAWN; b[sq(2, 2)] = PAWN | WHITE
+    h[0] = [2, 1, 1, 1, 1, 1, 0]; h[1] = [3, 0, 2, 0, 1, 0, 1]
+    cases.append((b, h, 0)); cases.append((b, h, 1))
+    # promotion zones, must-promote ranks, knights on the edge, promoted pieces of both colours
+    b, h = S.empty_board()
+    b[sq(8, 0)] = KING; b[sq(0, 8)] = KING | WHITE
+    b[sq(1, 2)] = PAWN; b[sq(2, 3)] = LANCE; b[sq(2, 0)] = S.KNIGHT; b[sq(3, 8)] = S.KNIGHT; b[sq(3, 5)] = SILVER; b[sq(2, 6)] = BISHOP
+    b[sq(4, 4)] = ROOK | S.PROM; b[sq(5, 5)] = BISHOP | S.PROM | WHITE; b[sq(7, 6)] = PAWN | WHITE; b[sq(6, 3)] = LANCE | WHITE
+    b[sq(6, 8)] = S.KNIGHT | WHITE; b[sq(5, 0)] = S.KNIGHT | WHITE; b[sq(6, 1)] = SILVER | S.PROM | WHITE; b[sq(1, 7)] = GOLD | WHITE
+    h[0] = [1, 1, 1, 0, 0, 0, 0]; h[1] = [1, 1, 1, 1, 0, 0, 0]
+    cases.append((b, h, 0)); cases.append((b, h, 1))
+    for board, hands, side in cases:
+        dev, ref = _fixture(board, hands, side)
+        mask = _same_view(dev, ref)
+        # and one step from there with every legal action in turn (at most 24 of them): same outputs
+        for a in np.flatnonzero(mask)[:24]:
+            d2, r2 = _fixture(board, hands, side)
+            _compare_step(d2.step([int(a)]), r2.step([int(a)]), f"action {a}")
+
+
+def _drive(dev, ref, moves, white_first=False):
+    out = None
+    for k, (f, t) in enumerate(moves):
+        white = (k % 2 == 1) != white_first
+        a = S.encode(f, t, white=white)
+        rd, rr = dev.step([a]), ref.step([a])
+        _compare_step(rd, rr, f"move {k}")
+        out = rr
+    return out
+
+
+def test_repetition_and_perpetual_check_through_the_step_api():
+    # rules.rs:692-752: king shuttle, fourth occurrence = Repetition (a draw: reward 0, counted as drawn)
+    b, h = S.empty_board(); b[sq(8, 4)] = KING; b[sq(0, 4)] = KING | WHITE
+    cycle = [(sq(8, 4), sq(7, 4)), (sq(0, 4), sq(1, 4)), (sq(7, 4), sq(8, 4)), (sq(1, 4), sq(0, 4))]
+    dev, ref = _fixture(b, h, 0)
+    last = _drive(dev, ref, cycle * 3)
+    assert last["termination_reason"][0] == S.R_REPETITION and last["terminated"][0] and last["rewards"][0] == 0
+    assert dev.episodes_drawn == 1 and np.all(last["terminal_observations"][0, 46] == 1)
+    # rules.rs:827-905: the rook chases the king; the checked side (White) wins, and White made the last move
+    b, h = S.empty_board(); b[sq(0, 0)] = KING | WHITE; b[sq(8, 8)] = KING; b[sq(0, 8)] = ROOK
+    dev, ref = _fixture(b, h, 1)
+    chase = [(sq(0, 0), sq(1, 0)), (sq(0, 8), sq(1, 8)), (sq(1, 0), sq(0, 0)), (sq(1, 8), sq(0, 8))]
+    last = _drive(dev, ref, chase * 3, white_first=True)
+    assert last["termination_reason"][0] == S.R_PERPETUAL and last["rewards"][0] == -1.0      # Black moved last and loses
+
+
+def test_impasse_through_the_step_api():
+    # rules.rs:1190-1290: both kings entered, ten pieces each in the zone, Black reaches 24 points with three rooks in hand
+    b, h = S.empty_board()
+    b[sq(0, 4)] = KING; b[sq(8, 4)] = KING | WHITE
+    n = 0
+    for r in range(3):
+        for c in range(9):
+            if (r, c) != (0, 4) and n < 9:
+                b[sq(r, c)] = PAWN | S.PROM; n += 1
+    n = 0
+    for r in range(6, 9):
+        for c in range(9):
+            if (r, c) != (8, 4) and n < 9:
+                b[sq(r, c)] = PAWN | S.PROM | WHITE; n += 1
+    h[0, 6] = 3
+    b[sq(4, 0)] = GOLD                                                  # a quiet move to make
+    dev, ref = _fixture(b, h, 0)
+    a = S.encode(sq(4, 0), sq(3, 0))
+    rd, rr = dev.step([a]), ref.step([a])
+    _compare_step(rd, rr, "impasse")
+    assert rr["termination_reason"][0] == S.R_IMPASSE and rr["rewards"][0] == 1.0
+
+
+def test_refused_actions_raise_like_the_reference_and_move_nothing():
+    dev = _env(4, 100)
+    r = dev.reset()
+    good = [int(np.flatnonzero(m)[0]) for m in r.legal_masks]
+    bad = int(np.flatnonzero(~r.legal_masks[2])[0])
+    before = [dev.get_state(i) for i in range(4)]
+    with pytest.raises(RuntimeError, match=r"env 2: action index \d+ is not legal"):
+        dev.step(good[:2] + [bad] + good[3:])
+    with pytest.raises(ValueError, match="env 1: negative action index -5"):
+        dev.step([good[0], -5, good[2], good[3]])
+    with pytest.raises(RuntimeError, match="env 0"):
+        dev.step([11259] + good[1:])
+    with pytest.raises(ValueError, match="expected 4 actions, got 3"):
+        dev.step(good[:3])
+    after = [dev.get_state(i) for i in range(4)]
+    for x, y in zip(before, after):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2:] == y[2:]
+    r2 = dev.step(good)                                                 # and the env still works
+    assert r2.step_metadata.ply_count.tolist() == [1, 1, 1, 1]
+    with pytest.raises(NotImplementedError):
+        VecEnv(num_envs=2)
+    with pytest.raises(ValueError, match="Unknown observation_mode"):
+        VecEnv(num_envs=2, observation_mode="x")
+
+
+def test_full_size_invariants_on_the_device():
+    """4096 games x 300 steps with on-device sampling (no oracle at this size): 40 pieces in every game, never an empty
+    mask, planes agree with the stored boards, finished games restart at the start position, counters add up."""
+    n, steps = 4096, 300
+    dev = _env(n, 120, output="torch", check_actions=False)
+    r = dev.reset()
+    start_obs = r.observations[0].clone()
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    ends = 0
+    for s in range(steps):
+        acts = torch.multinomial(r.legal_masks.float(), 1, generator=g).squeeze(1)
+        r = dev.step(acts)
+        assert bool(r.legal_masks.any(dim=1).all())
+        done = r.terminated | r.truncated
+        ends += int(done.sum())
+        if s % 50 == 49:
+            dev.raise_if_refused()
+            st = dev._state
+            pieces = (st[:, :81] != 0).sum(1) + st[:, 81:95].sum(1)
+            assert bool((pieces == 40).all())
+            occ = r.observations[:, :28].sum(dim=1).reshape(n, 81)     # one plane per piece: occupancy, turned for White
+            board_occ = (st[:, :81] != 0).float()
+            white = st[:, 95].bool()
+            board_occ[white] = board_occ[white].flip(1)
+            assert torch.equal(occ, board_occ)
+            if bool(done.any()):
+                assert torch.equal(r.observations[done][0], start_obs)
+                assert bool((r.current_players[done] == 0).all())
+            mate = r.step_metadata.termination_reason == S.R_CHECKMATE
+            assert bool((r.rewards[mate] == 1).all())
+    assert dev.episodes_completed == ends and ends > n

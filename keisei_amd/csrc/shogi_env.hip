@@ -24,11 +24,12 @@ constexpr int WHITE_BIT = 0x10, PROM_BIT = 0x20;
 enum { R_PROGRESS = 0, R_CHECKMATE, R_REPETITION, R_PERPETUAL, R_IMPASSE, R_MAXMOVES };   // step_result.rs:9-16
 
 // directions: N NE E SE S SW W NW (spatial_action_mapper.rs:31-40); "N" is toward row 0
-__constant__ int8_t kDR[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
-__constant__ int8_t kDC[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+// (row, column) steps as 2-bit fields of two immediates: the tables are on dependent-load chains of the ray walks
+__device__ __forceinline__ int dir_dr(int d) { return ((0x1A90 >> (2 * d)) & 3) - 1; }      // -1 -1 0 1 1 1 0 -1
+__device__ __forceinline__ int dir_dc(int d) { return ((0x01A9 >> (2 * d)) & 3) - 1; }      //  0  1 1 1 0 -1 -1 -1
 
 // step (low byte) and slide (high byte) direction sets of every piece byte, in board directions (attack.rs:56-113)
-constexpr unsigned dirs_of(int pc) {
+__host__ __device__ constexpr unsigned dirs_of(int pc) {
     const unsigned N = 1, NE = 2, E = 4, SE = 8, S = 16, SW = 32, W = 64, NW = 128, gold = N | NE | NW | E | W | S;
     const int t = pc & 15;
     const bool pr = pc & PROM_BIT, wh = pc & WHITE_BIT;
@@ -49,9 +50,6 @@ constexpr unsigned dirs_of(int pc) {
     if (wh) { st = ((st << 4) | (st >> 4)) & 255; sl = ((sl << 4) | (sl >> 4)) & 255; }
     return st | (sl << 8);
 }
-struct DirTable { uint16_t v[64]; };
-constexpr DirTable make_dirs() { DirTable t{}; for (int i = 0; i < 64; ++i) t.v[i] = (uint16_t)dirs_of(i); return t; }
-__constant__ DirTable kDirs = make_dirs();
 
 struct EnvArgs {
     uint8_t* state; unsigned long long* keys; uint8_t* checks;
@@ -64,7 +62,8 @@ struct EnvArgs {
 
 // the board in LDS (explicit address space: these helpers are not always inlined) with up to two squares replaced
 typedef const __attribute__((address_space(3))) uint8_t* lds_board;
-struct View { lds_board b; int o1, p1, o2, p2; };
+typedef const __attribute__((address_space(3))) uint16_t* lds_dirs;      // dirs_of() of every piece byte, in LDS
+struct View { lds_board b; lds_dirs dirs; int o1, p1, o2, p2; };
 __device__ __forceinline__ int at(const View& v, int sq) { return sq == v.o1 ? v.p1 : sq == v.o2 ? v.p2 : v.b[sq]; }
 
 // is `sq` attacked by a piece of colour `by`?  Looks outward from the square: the first piece met along each of the
@@ -73,14 +72,14 @@ __device__ bool attacked(const View& v, int sq, int by) {
     const int r = sq / 9, c = sq % 9;
 #pragma unroll 1
     for (int d = 0; d < 8; ++d) {
-        const int dr = kDR[d], dc = kDC[d];
+        const int dr = dir_dr(d), dc = dir_dc(d);
         const unsigned need = 1u << ((d + 4) & 7);
         int rr = r + dr, cc = c + dc, k = 1;
         while ((unsigned)rr < 9u && (unsigned)cc < 9u) {
             const int p = at(v, rr * 9 + cc);
             if (p) {
                 if (((p >> 4) & 1) == by) {
-                    const unsigned m = kDirs.v[p & 63];
+                    const unsigned m = v.dirs[p & 63];
                     if ((k == 1 && (m & need)) || ((m >> 8) & need)) return true;
                 }
                 break;
@@ -106,8 +105,8 @@ __device__ bool attacks(const View& v, int from, int pc, int target) {
     const int ur = (dr > 0) - (dr < 0), uc = (dc > 0) - (dc < 0), dist = adr > adc ? adr : adc;
     int d = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (kDR[i] == ur && kDC[i] == uc) d = i;
-    const unsigned m = kDirs.v[pc & 63], bit = 1u << d;
+    for (int i = 0; i < 8; ++i) if (dir_dr(i) == ur && dir_dc(i) == uc) d = i;
+    const unsigned m = v.dirs[pc & 63], bit = 1u << d;
     if (dist == 1 && (m & bit)) return true;
     if (!((m >> 8) & bit)) return false;
     for (int k = 1; k < dist; ++k) if (at(v, (fr + ur * k) * 9 + fc + uc * k)) return false;
@@ -115,10 +114,10 @@ __device__ bool attacks(const View& v, int from, int pc, int target) {
 }
 
 // rules.rs:18-131: would a pawn of `me` dropped on `to` leave the other king attacked with no way out?
-__device__ bool pawn_drop_mates(lds_board board, int to, int me, int opp_king) {
+__device__ bool pawn_drop_mates(lds_board board, lds_dirs dirs, int to, int me, int opp_king) {
     if (opp_king < 0) return false;
     const int opp = me ^ 1, pawn = PAWN | (me ? WHITE_BIT : 0);
-    const View v{board, to, pawn, -1, 0};
+    const View v{board, dirs, to, pawn, -1, 0};
     if (!attacked(v, opp_king, me)) return false;
     const int kr = opp_king / 9, kc = opp_king % 9;
     for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {          // the king steps aside or takes
@@ -134,7 +133,7 @@ __device__ bool pawn_drop_mates(lds_board board, int to, int me, int opp_king) {
         const int pc = at(v, sq);
         if (!pc || ((pc >> 4) & 1) != opp || (pc & 15) == KING) continue;
         if (!attacks(v, sq, pc, to)) continue;
-        const View w{board, sq, 0, to, pc};
+        const View w{board, dirs, sq, 0, to, pc};
         if (!attacked(w, opp_king, me)) return false;
     }
     return true;
@@ -180,12 +179,14 @@ __device__ __forceinline__ int piece_value(int t, bool pr) {  // rules.rs:333-35
     return pr ? prom[t] : plain[t];
 }
 
-__global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void shogi_env_kernel(EnvArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_board[96];
     __shared__ uint8_t s_hands[16];
+    __shared__ uint16_t s_dirs[64];
     __shared__ uint32_t s_bits[kWords + 2];
     __shared__ uint32_t s_cand[1024];
-    __shared__ int s_ncand, s_nlegal;
+    __shared__ int s_ncand, s_np, s_nh;
+    __shared__ uint8_t s_plist[48], s_hlist[8];
     __shared__ float s_plane[22];
 
     const int env = blockIdx.x, lane = threadIdx.x;
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
     uint8_t* checks = a.checks + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
 
     const lds_board brd = (lds_board)s_board;
+    const lds_dirs drs = (lds_dirs)s_dirs;
+    s_dirs[lane] = (uint16_t)dirs_of(lane);
     int side, ply, reps, in_check;
     unsigned long long key;
     auto load_board = [&]() {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
     auto side_in_check = [&](int color) {                      // game.rs:98-105 (wave-uniform result)
         const int k = king_of(color);
         int r = 0;
-        if (lane == 0 && k >= 0) { const View v{brd, -1, 0, -1, 0}; r = attacked(v, k, color ^ 1); }
+        if (lane == 0 && k >= 0) { const View v{brd, drs, -1, 0, -1, 0}; r = attacked(v, k, color ^ 1); }
         return __shfl(r, 0);
     };
 
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
                 if (slot < 128) {
                     promote = slot >= 64;
                     const int b = slot & 63, d = b >> 3, dist = (b & 7) + 1;
-                    to_p = (sq_p / 9 + kDR[d] * dist) * 9 + sq_p % 9 + kDC[d] * dist;
+                    to_p = (sq_p / 9 + dir_dr(d) * dist) * 9 + sq_p % 9 + dir_dc(d) * dist;
                 } else {
                     const int k = slot - 128;
                     promote = k & 1; to_p = (sq_p / 9 - 2) * 9 + sq_p % 9 + ((k >> 1) ? 1 : -1);
@@ -361,51 +364,59 @@ __global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
     for (int pass = 0; pass < 2; ++pass) {
         if (terminal == R_PROGRESS) {
             for (int i = lane; i < kWords + 2; i += 64) s_bits[i] = 0;
-            if (lane == 0) { s_ncand = 0; s_nlegal = 0; }
+            if (lane == 0) { s_ncand = 0; s_np = 0; s_nh = 0; }
             __syncthreads();
             const int me = side, mine = me ? WHITE_BIT : 0;
-            // candidates: 648 rays, 162 knight jumps, 567 drops, all in the mover's perspective (movegen.rs:112-203)
-            for (int task = lane; task < 648 + 162 + 567; task += 64) {
-                if (task < 648) {
-                    const int sq_p = task >> 3, d_p = task & 7;
-                    const int from = me ? 80 - sq_p : sq_p, d = me ? (d_p + 4) & 7 : d_p;
+            // candidates in the mover's perspective (movegen.rs:112-203): the mover's pieces are compacted first, then one
+            // task per (piece, direction or knight side) and one per (hand type held, square)
+            for (int sq = lane; sq < 81; sq += 64) {
+                const int p = s_board[sq];
+                if (p && (p & WHITE_BIT) == mine) s_plist[atomicAdd(&s_np, 1)] = (uint8_t)sq;
+            }
+            if (lane < 7 && s_hands[me * 7 + lane]) s_hlist[atomicAdd(&s_nh, 1)] = (uint8_t)lane;
+            __syncthreads();
+            const int nboard = s_np * 10, ntask = nboard + s_nh * 81;
+            for (int task = lane; task < ntask; task += 64) {
+                if (task < nboard) {
+                    const int from = s_plist[task / 10], d_p = task % 10;
+                    const int sq_p = me ? 80 - from : from;
                     const int p = s_board[from];
-                    if (!p || (p & WHITE_BIT) != mine) continue;
-                    const unsigned m = kDirs.v[p & 63];
-                    const bool slide = (m >> 8) & (1u << d);
-                    if (!slide && !(m & (1u << d))) continue;
-                    const int t = p & 15;
-                    const bool can = !(p & PROM_BIT) && t != GOLD && t != KING;
-                    const int fr_p = sq_p / 9, dr = kDR[d], dc = kDC[d], drp = kDR[d_p];
-                    int rr = from / 9 + dr, cc = from % 9 + dc;
-                    for (int k = 1; k <= (slide ? 8 : 1) && (unsigned)rr < 9u && (unsigned)cc < 9u; ++k, rr += dr, cc += dc) {
-                        const int to = rr * 9 + cc, q = s_board[to];
-                        if (q && (q & WHITE_BIT) == mine) break;
-                        const int to_row_p = fr_p + drp * k;
-                        const bool must = can && (t == PAWN || t == LANCE) && to_row_p == 0;      // movegen.rs:33-45
-                        const bool opt = can && !must && (fr_p <= 2 || to_row_p <= 2);
+                    if (d_p < 8) {
+                        const int d = me ? (d_p + 4) & 7 : d_p;
+                        const unsigned m = s_dirs[p & 63];
+                        const bool slide = (m >> 8) & (1u << d);
+                        if (!slide && !(m & (1u << d))) continue;
+                        const int t = p & 15;
+                        const bool can = !(p & PROM_BIT) && t != GOLD && t != KING;
+                        const int fr_p = sq_p / 9, dr = dir_dr(d), dc = dir_dc(d), drp = dir_dr(d_p);
+                        int rr = from / 9 + dr, cc = from % 9 + dc;
+                        for (int k = 1; k <= (slide ? 8 : 1) && (unsigned)rr < 9u && (unsigned)cc < 9u; ++k, rr += dr, cc += dc) {
+                            const int to = rr * 9 + cc, q = s_board[to];
+                            if (q && (q & WHITE_BIT) == mine) break;
+                            const int to_row_p = fr_p + drp * k;
+                            const bool must = can && (t == PAWN || t == LANCE) && to_row_p == 0;      // movegen.rs:33-45
+                            const bool opt = can && !must && (fr_p <= 2 || to_row_p <= 2);
+                            const unsigned base = (unsigned)from | ((unsigned)to << 7);
+                            const int act = sq_p * kTypes + d_p * 8 + k - 1;
+                            if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
+                            if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 64) << 18);
+                            if (q) break;
+                        }
+                    } else {
+                        if (p != (KNIGHT | mine)) continue;
+                        const int sd = d_p - 8;
+                        const int tr_p = sq_p / 9 - 2, tc_p = sq_p % 9 + (sd ? 1 : -1);
+                        if (tr_p < 0 || (unsigned)tc_p >= 9u) continue;
+                        const int to_p = tr_p * 9 + tc_p, to = me ? 80 - to_p : to_p, q = s_board[to];
+                        if (q && (q & WHITE_BIT) == mine) continue;
+                        const bool must = tr_p <= 1, opt = !must && tr_p <= 2;
                         const unsigned base = (unsigned)from | ((unsigned)to << 7);
-                        const int act = sq_p * kTypes + d_p * 8 + k - 1;
+                        const int act = sq_p * kTypes + 128 + sd * 2;
                         if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
-                        if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 64) << 18);
-                        if (q) break;
+                        if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 1) << 18);
                     }
-                } else if (task < 648 + 162) {
-                    const int u = task - 648, sq_p = u >> 1, s = u & 1;
-                    const int from = me ? 80 - sq_p : sq_p;
-                    if (s_board[from] != (KNIGHT | mine)) continue;
-                    const int tr_p = sq_p / 9 - 2, tc_p = sq_p % 9 + (s ? 1 : -1);
-                    if (tr_p < 0 || (unsigned)tc_p >= 9u) continue;
-                    const int to_p = tr_p * 9 + tc_p, to = me ? 80 - to_p : to_p, q = s_board[to];
-                    if (q && (q & WHITE_BIT) == mine) continue;
-                    const bool must = tr_p <= 1, opt = !must && tr_p <= 2;
-                    const unsigned base = (unsigned)from | ((unsigned)to << 7);
-                    const int act = sq_p * kTypes + 128 + s * 2;
-                    if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
-                    if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 1) << 18);
                 } else {
-                    const int u = task - 810, sq_p = u / 7, h = u % 7;
-                    if (!s_hands[me * 7 + h]) continue;
+                    const int u = task - nboard, h = s_hlist[u / 81], sq_p = u % 81;
                     const int to = me ? 80 - sq_p : sq_p;
                     if (s_board[to]) continue;
                     const int row_p = sq_p / 9;
@@ -422,24 +433,35 @@ __global__ __launch_bounds__(64) void shogi_env_kernel(EnvArgs a) {
             __syncthreads();
             const int my_king = king_of(me), opp_king = king_of(me ^ 1);
             const int nc = s_ncand;
+            // King safety.  A move can only uncover the king when the moving piece stands on one of the king's eight
+            // lines, and a drop never does; so unless the mover is in check already, only king moves and moves of aligned
+            // pieces take the full test (the moved piece gone from `from`, present on `to`, look outward from the king).
+            const int kr = my_king / 9, kc = my_king % 9;
             for (int i = lane; i < nc; i += 64) {
                 const unsigned c = s_cand[i];
                 const int from = c & 127, to = (c >> 7) & 127, promote = (c >> 14) & 1, drop = (c >> 15) & 7, act = c >> 18;
-                bool ok;
+                bool ok = my_king >= 0;
                 if (drop) {
-                    const View v{brd, to, drop | mine, -1, 0};
-                    ok = my_king >= 0 && !attacked(v, my_king, me ^ 1);
-                    if (ok && drop == PAWN) ok = !pawn_drop_mates(brd, to, me, opp_king);
-                } else {
+                    if (ok && in_check) { const View v{brd, drs, to, drop | mine, -1, 0}; ok = !attacked(v, my_king, me ^ 1); }
+                    if (ok && drop == PAWN) ok = !pawn_drop_mates(brd, drs, to, me, opp_king);
+                } else if (ok) {
                     const int pc = s_board[from];
-                    const View v{brd, from, 0, to, promote ? pc | PROM_BIT : pc};
-                    const int k = (pc & 15) == KING ? to : my_king;
-                    ok = k >= 0 && !attacked(v, k, me ^ 1);
+                    const bool king = (pc & 15) == KING;
+                    const int dr = from / 9 - kr, dc = from % 9 - kc;
+                    const bool aligned = dr == 0 || dc == 0 || dr == dc || dr == -dc;
+                    if (king || in_check || aligned) {
+                        const View v{brd, drs, from, 0, to, promote ? pc | PROM_BIT : pc};
+                        ok = !attacked(v, king ? to : my_king, me ^ 1);
+                    }
                 }
-                if (ok) { atomicOr(&s_bits[act >> 5], 1u << (act & 31)); atomicAdd(&s_nlegal, 1); }
+                if (ok) atomicOr(&s_bits[act >> 5], 1u << (act & 31));
             }
             __syncthreads();
-            if (pass == 0 && a.mode == 1 && s_nlegal == 0) { terminal = R_CHECKMATE; winner = side ^ 1; }   // game.rs:374-386
+            unsigned any = 0;
+            for (int w = lane; w < kWords; w += 64) any |= s_bits[w];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
+            if (pass == 0 && a.mode == 1 && any == 0) { terminal = R_CHECKMATE; winner = side ^ 1; }   // game.rs:374-386
         }
         if (terminal == R_PROGRESS) break;
         // the game ended with this move (vec_env.rs:395-423)

@@ -215,14 +215,25 @@ class VecEnv:
     def set_state(self, game_id: int, board, hands, side: int) -> None:
         """Place a position in one game (ply and history restart at 0) and refresh every game's observation and masks --
         the rule fixtures of the reference's tests build their positions square by square (rules.rs:575-1790)."""
-        raw = np.zeros(self._state.shape[1], np.uint8)
-        raw[:81] = np.asarray(board, np.uint8).reshape(81)
-        raw[81:95] = np.asarray(hands, np.uint8).reshape(14)
-        raw[95] = side
-        self._state[game_id].copy_(torch.from_numpy(raw))
         others = [self.get_state(i) for i in range(self._n) if i != game_id]
         if any(p != 0 for *_, p in others):
             raise RuntimeError("set_state refreshes all games from ply 0: call it right after reset()")
+        raw = self._state.cpu().numpy()
+        raw[game_id, :81] = np.asarray(board, np.uint8).reshape(81)
+        raw[game_id, 81:95] = np.asarray(hands, np.uint8).reshape(14)
+        raw[game_id, 95] = side
+        self._refresh(raw)
+
+    def set_states(self, boards, hands, sides) -> None:
+        """All games at once: boards (N,81), hands (N,2,7) or (N,14), sides (N,); ply and history restart at 0."""
+        raw = np.zeros(tuple(self._state.shape), np.uint8)
+        raw[:, :81] = np.asarray(boards, np.uint8).reshape(self._n, 81)
+        raw[:, 81:95] = np.asarray(hands, np.uint8).reshape(self._n, 14)
+        raw[:, 95] = np.asarray(sides, np.uint8).reshape(self._n)
+        self._refresh(raw)
+
+    def _refresh(self, raw: np.ndarray) -> None:
+        self._state.copy_(torch.from_numpy(raw))
         with torch.cuda.device(self.device):
             _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._obs[self._cur],
                       self._mask[self._cur], self._bits[self._cur], self._players, 1, _lib.stream_ptr())

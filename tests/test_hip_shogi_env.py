@@ -214,6 +214,74 @@ def test_impasse_through_the_step_api():
     assert rr["termination_reason"][0] == S.R_IMPASSE and rr["rewards"][0] == 1.0
 
 
+def _random_positions(count, seed):
+    """Scattered pieces with both kings, no dead pieces, no doubled pawns, the side not to move not in check (the one thing
+    legal play guarantees that the generators rely on); pins, multiple checks, full hands and crowded zones all occur."""
+    rng = np.random.default_rng(seed)
+    probe = OracleVecEnv(1, 500)
+    out = []
+    stock = {PAWN: 18, LANCE: 4, S.KNIGHT: 4, SILVER: 4, GOLD: 4, BISHOP: 2, ROOK: 2}
+    while len(out) < count:
+        b, h = S.empty_board()
+        ks = rng.choice(81, 2, replace=False)
+        b[ks[0]] = KING; b[ks[1]] = KING | WHITE
+        left = dict(stock)
+        pawn_cols = [set(), set()]
+        for _ in range(int(rng.integers(4, 34))):
+            t = int(rng.choice(list(left)))
+            if left[t] == 0:
+                continue
+            sqr = int(rng.integers(81))
+            if b[sqr]:
+                continue
+            color, prom = int(rng.integers(2)), bool(rng.integers(3) == 0) and t != GOLD
+            row = sqr // 9
+            if not prom:
+                last = row == (8 if color else 0)
+                last2 = row >= 7 if color else row <= 1
+                if (t in (PAWN, LANCE) and last) or (t == S.KNIGHT and last2):
+                    continue
+                if t == PAWN:
+                    if sqr % 9 in pawn_cols[color]:
+                        continue
+                    pawn_cols[color].add(sqr % 9)
+            b[sqr] = t | (WHITE if color else 0) | (S.PROM if prom else 0)
+            left[t] -= 1
+        for t in left:
+            k = int(rng.integers(0, left[t] + 1)) if rng.integers(2) else 0
+            kb = int(rng.integers(0, k + 1))
+            h[0, t - 1], h[1, t - 1] = kb, k - kb
+        side = int(rng.integers(2))
+        probe.set_state(0, b, h, side)
+        if probe.in_check(0, side ^ 1) or probe.legal_count(0) == 0:
+            continue
+        out.append((b, h, side))
+    return out
+
+
+def test_random_positions_masks_observations_and_one_step():
+    n = 384
+    pos = _random_positions(n, seed=5)
+    dev, ref = _env(n, 500), OracleVecEnv(n, 500)
+    dev.reset(); ref.reset()
+    dev.set_states([p[0] for p in pos], [p[1] for p in pos], [p[2] for p in pos])
+    for i, (b, h, sd) in enumerate(pos):
+        ref.set_state(i, b, h, sd)
+    cur = dev.current()
+    rng = np.random.default_rng(6)
+    acts, checks = np.zeros(n, np.int64), 0
+    for i in range(n):
+        obs, mask = ref.observe(i)
+        assert np.array_equal(cur.observations[i], obs), (i, np.argwhere(cur.observations[i] != obs)[:4])
+        if not np.array_equal(cur.legal_masks[i], mask):
+            d = np.flatnonzero(cur.legal_masks[i] != mask)
+            raise AssertionError(f"position {i} ({dev.get_sfen(i)}): mask differs at {[(int(j) // 139, int(j) % 139) for j in d[:8]]}")
+        checks += int(obs[48, 0, 0])
+        acts[i] = rng.choice(np.flatnonzero(mask))
+    assert checks > 10                                   # plenty of positions with the mover in check
+    _compare_step(dev.step(acts), ref.step(acts), "step from random positions")
+
+
 def test_refused_actions_raise_like_the_reference_and_move_nothing():
     dev = _env(4, 100)
     r = dev.reset()

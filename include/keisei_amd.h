@@ -273,8 +273,10 @@ int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out, float* po
  * spatial_action_mapper.rs:138-279).  One wave per game; all buffers are device memory owned by the caller:
  *   state  n x ka_shogi_env_state_bytes() bytes: board[81] (piece.rs:10-19 bytes) hands[2][7] side in_check - ply key reps
  *   keys   n x max(max_ply,1) u64, checks n x max(max_ply,1) u8: position key / "mover stood in check" of every ply
- *   obs (n,50,9,9) fp32; mask (n,11259) bool bytes and/or mask_bits (n,352) u32 (bit j of word w = action 32w+j; at
- *   least one of the two); current_players (n) u8.
+ *   obs_mode 1 = "katago" 50 planes, 0 = "default" 46 planes (observation.rs:1-15); action_mode 1 = "spatial" A = 11 259,
+ *   0 = "default" A = 81*80*2 + 81*7 = 13 527 (action_mapper.rs:17-110); ka_shogi_env_action_space(mode) = A.
+ *   obs (n,planes,9,9) fp32; mask (n,A) bool bytes and/or mask_bits (n,ceil(A/32)) u32 (bit j of word w = action 32w+j;
+ *   at least one of the two); current_players (n) u8.
  * ka_shogi_env_reset: VecEnv::reset (vec_env.rs:617-645) -- or, with refresh != 0, derive key / check / masks from the
  *   board, hands and side the caller has written into `state` (test fixtures; ply and history start at 0).
  * ka_shogi_env_step: VecEnv::step (vec_env.rs:651-700, apply_moves :340-460).  Phase 1 checks every action against
@@ -285,10 +287,11 @@ int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out, float* po
  *   stats[4] u64 {completed, drawn, truncated, total ply}; finished games write terminal_obs (other rows are left as they
  *   were) and restart from the start position; then observation and masks of every game's position to move. */
 int ka_shogi_env_state_bytes(void);
-int ka_shogi_env_reset(void* state, void* keys, void* checks, int n, int max_ply, float* obs, void* mask, void* mask_bits,
-                       void* current_players, int refresh, void* stream);
-int ka_shogi_env_step(void* state, void* keys, void* checks, const long long* actions, int n, int max_ply,
-                      const void* prev_mask, const void* prev_mask_bits, int* err, float* obs, void* mask, void* mask_bits,
+int ka_shogi_env_action_space(int action_mode);
+int ka_shogi_env_reset(void* state, void* keys, void* checks, int n, int max_ply, int obs_mode, int action_mode, float* obs,
+                       void* mask, void* mask_bits, void* current_players, int refresh, void* stream);
+int ka_shogi_env_step(void* state, void* keys, void* checks, const long long* actions, int n, int max_ply, int obs_mode,
+                      int action_mode, const void* prev_mask, const void* prev_mask_bits, int* err, float* obs, void* mask, void* mask_bits,
                       float* rewards, void* terminated, void* truncated, float* terminal_obs, void* current_players,
                       void* captured, void* term_reason, void* ply_count, int* material, void* stats, void* stream);
 

@@ -76,8 +76,9 @@ _SIGS = {
     "ka_tower_eval_supported": "iiii",
     "ka_tower_eval": "ppppp iiiii i p",
     "ka_shogi_env_state_bytes": "",
-    "ka_shogi_env_reset": "ppp ii pppp i p",
-    "ka_shogi_env_step": "pppp ii ppp ppp ppp pp ppp pp p",
+    "ka_shogi_env_action_space": "i",
+    "ka_shogi_env_reset": "ppp ii ii pppp i p",
+    "ka_shogi_env_step": "pppp ii ii ppp ppp ppp pp ppp pp p",
     "ka_tf_gemm_nt": "ppppp iii iii iii f q p",
     "ka_tf_gemm_nt_slabs": "ii",
     "ka_tf_gemm_nt_masked": "pppp iii iii f q p",

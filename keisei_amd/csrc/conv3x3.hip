@@ -686,13 +686,17 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
     int bb = blockIdx.x, it = 0;
     request(bb);
     commit(bb, 0);
+    // The pieces of board n+1 are requested right after board n's pieces have been written to LDS -- i.e. BEFORE the
+    // epilogue of board n-1 -- not at the top of board n's MFMA phases: vector-memory returns are counted in order, so
+    // the first wait for a weight fragment is also a wait for that request, and the epilogue + image build in between
+    // give HBM its 2-3 us.
+    if (bb + nwg < a.B && !(a.tune_stagger & 2)) request(bb + nwg);
     for (; bb < a.B; bb += nwg, ++it) {
         const int cur = it & 1, nb = bb + nwg;
         f32x4 acc[kMTW][2];
 #pragma unroll
         for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const int abl = a.tune_stagger;                      // diagnostics (KA_CONV_T_ABL): 1 no epilogue, 2 no staging of the next board, 4 no MFMA steps, 8 no image builds
-        if (nb < a.B && !(abl & 2)) request(nb);             // the next board's pieces: in flight under this board's MFMAs
         for (int kc = 0; kc < 2; ++kc) {
             bf16x8 w0[2], w1[2], w2[2], w3[2];
             wfrag(kc, 0, w0); wfrag(kc, 1, w1); wfrag(kc, 2, w2);
@@ -732,7 +736,10 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
                 wfrag(kc, s0 + 6, w2); __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (nb < a.B && !(abl & 2)) commit(nb, cur ^ 1);     // (the other natural buffer: last read two boards ago)
+        if (nb < a.B && !(abl & 2)) {
+            commit(nb, cur ^ 1);                             // (the other natural buffer: last read two boards ago)
+            if (nb + nwg < a.B) request(nb + nwg);
+        }
         if (!(abl & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
     }
 }

@@ -17,7 +17,11 @@
 
 namespace {
 
-constexpr int kA = 11259, kTypes = 139, kWords = 352, kObs = 50 * 81;
+constexpr int kTypes = 139, kBoardMoves = 81 * 80 * 2;
+// action spaces: spatial 81 x 139 = 11 259 (spatial_action_mapper.rs), default 81 x 80 x 2 + 81 x 7 = 13 527 (action_mapper.rs:17-19);
+// observation planes: katago 50 (katago_observation.rs), default 46 (observation.rs: planes 44-45 reserved)
+constexpr int kMaxWords = (13527 + 31) / 32;
+__host__ __device__ constexpr int action_space(int amode) { return amode ? 81 * kTypes : kBoardMoves + 81 * 7; }
 constexpr int kStateBytes = 128;      // board[81] hands[14] side in_check pad[3] | ply u32 @100 | key u64 @104 | reps u32 @112
 enum { PAWN = 1, LANCE, KNIGHT, SILVER, GOLD, BISHOP, ROOK, KING };
 constexpr int WHITE_BIT = 0x10, PROM_BIT = 0x20;
@@ -57,6 +61,7 @@ struct EnvArgs {
     float* obs; uint8_t* mask; uint32_t* mask_bits;
     float* rewards; uint8_t* terminated; uint8_t* truncated; float* terminal_obs; uint8_t* current_players;
     uint8_t* captured; uint8_t* term_reason; uint16_t* ply_out; int* material; unsigned long long* stats;
+    int amode, obs_ch;               // action mode 1 spatial / 0 default; observation planes 50 (katago) / 46 (default)
     int n, max_ply, mode;            // mode 0 reset, 1 step, 2 refresh (derive everything from board / hands / side as placed)
 };
 
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ __attribute__((aligned(16))) uint8_t s_board[96];
     __shared__ uint8_t s_hands[16];
     __shared__ uint16_t s_dirs[64];
-    __shared__ uint32_t s_bits[kWords + 2];
+    __shared__ uint32_t s_bits[kMaxWords + 2];
     __shared__ uint32_t s_cand[1024];
     __shared__ int s_ncand, s_np, s_nh;
     __shared__ uint8_t s_plist[48], s_hlist[8];
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
     const int env = blockIdx.x, lane = threadIdx.x;
     if (env >= a.n) return;
+    const int kA = action_space(a.amode), kWords = (kA + 31) >> 5, kObs = a.obs_ch * 81;
     if (a.mode == 1 && *a.err != 0) return;                   // an action was refused: nothing moves (vec_env.rs:651-690)
     uint8_t* st = a.state + (size_t)env * kStateBytes;
     unsigned long long* keys = a.keys + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
@@ -245,29 +251,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         // ---- make_move (game.rs:107-188); the position before the move and whether its mover stood in check are history
         if (lane == 0) { keys[ply] = key; checks[ply] = (uint8_t)in_check; }
         const int act = (int)a.actions[env];
-        const int sq_p = act / kTypes, slot = act % kTypes;
         if (lane == 0) {
-            const int real = side ? 80 - sq_p : sq_p;
-            if (slot < 132) {
-                int to_p, promote;
+            // decode in the mover's perspective (spatial_action_mapper.rs:188-279 / action_mapper.rs:79-110)
+            int from_p, to_p, promote = 0, drop = -1;
+            if (a.amode) {
+                const int slot = act % kTypes;
+                from_p = act / kTypes;
                 if (slot < 128) {
                     promote = slot >= 64;
                     const int b = slot & 63, d = b >> 3, dist = (b & 7) + 1;
-                    to_p = (sq_p / 9 + dir_dr(d) * dist) * 9 + sq_p % 9 + dir_dc(d) * dist;
-                } else {
+                    to_p = (from_p / 9 + dir_dr(d) * dist) * 9 + from_p % 9 + dir_dc(d) * dist;
+                } else if (slot < 132) {
                     const int k = slot - 128;
-                    promote = k & 1; to_p = (sq_p / 9 - 2) * 9 + sq_p % 9 + ((k >> 1) ? 1 : -1);
-                }
-                const int to = side ? 80 - to_p : to_p;
+                    promote = k & 1; to_p = (from_p / 9 - 2) * 9 + from_p % 9 + ((k >> 1) ? 1 : -1);
+                } else { drop = slot - 132; to_p = from_p; }
+            } else if (act < kBoardMoves) {
+                from_p = act / 160;
+                const int rem = act % 160, off = rem >> 1;
+                promote = rem & 1; to_p = off >= from_p ? off + 1 : off;
+            } else { drop = (act - kBoardMoves) % 7; to_p = from_p = (act - kBoardMoves) / 7; }
+            const int to = side ? 80 - to_p : to_p;
+            if (drop < 0) {
+                const int real = side ? 80 - from_p : from_p;
                 const int pc = s_board[real];
                 cap = s_board[to];
                 if (cap) s_hands[side * 7 + (cap & 15) - 1]++;
                 s_board[real] = 0;
                 s_board[to] = (uint8_t)(promote ? pc | PROM_BIT : pc);
             } else {
-                const int h = slot - 132;
-                s_hands[side * 7 + h]--;
-                s_board[real] = (uint8_t)((h + 1) | (side ? WHITE_BIT : 0));
+                s_hands[side * 7 + drop]--;
+                s_board[to] = (uint8_t)((drop + 1) | (side ? WHITE_BIT : 0));
             }
         }
         cap = __shfl(cap, 0);
@@ -329,8 +342,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             s_plane[lane] = __fdiv_rn((float)s_hands[who * 7 + lane % 7], mx);
         } else if (lane == 14) s_plane[14] = side == 0 ? 1.f : 0.f;
         else if (lane == 15) s_plane[15] = a.max_ply == 0 ? 0.f : fminf(fmaxf(__fdiv_rn((float)ply, (float)a.max_ply), 0.f), 1.f);
-        else if (lane < 20) { const int prior = reps - 1, ch = lane - 16; s_plane[lane] = (ch < 3 ? prior == ch + 1 : prior >= 4) ? 1.f : 0.f; }
-        else if (lane == 20) s_plane[20] = in_check ? 1.f : 0.f;
+        else if (lane < 20) { const int prior = reps - 1, ch = lane - 16; s_plane[lane] = (a.obs_ch == 50 && (ch < 3 ? prior == ch + 1 : prior >= 4)) ? 1.f : 0.f; }
+        else if (lane == 20) s_plane[20] = (a.obs_ch == 50 && in_check) ? 1.f : 0.f;
         else if (lane == 21) s_plane[21] = 0.f;
         __syncthreads();
         f32x2* o2 = reinterpret_cast<f32x2*>(out);
@@ -397,9 +410,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                             const bool must = can && (t == PAWN || t == LANCE) && to_row_p == 0;      // movegen.rs:33-45
                             const bool opt = can && !must && (fr_p <= 2 || to_row_p <= 2);
                             const unsigned base = (unsigned)from | ((unsigned)to << 7);
-                            const int act = sq_p * kTypes + d_p * 8 + k - 1;
+                            const int to_p = me ? 80 - to : to;
+                            const int act = a.amode ? sq_p * kTypes + d_p * 8 + k - 1 : sq_p * 160 + (to_p > sq_p ? to_p - 1 : to_p) * 2;
+                            const int pstep = a.amode ? 64 : 1;
                             if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
-                            if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 64) << 18);
+                            if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + pstep) << 18);
                             if (q) break;
                         }
                     } else {
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         if (q && (q & WHITE_BIT) == mine) continue;
                         const bool must = tr_p <= 1, opt = !must && tr_p <= 2;
                         const unsigned base = (unsigned)from | ((unsigned)to << 7);
-                        const int act = sq_p * kTypes + 128 + sd * 2;
+                        const int act = a.amode ? sq_p * kTypes + 128 + sd * 2 : sq_p * 160 + (to_p > sq_p ? to_p - 1 : to_p) * 2;
                         if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
                         if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 1) << 18);
                     }
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         if (nifu) continue;
                     }
                     s_cand[atomicAdd(&s_ncand, 1)] = ((unsigned)to << 7) | ((unsigned)(h + 1) << 15) |
-                                                     ((unsigned)(sq_p * kTypes + 132 + h) << 18);
+                                                     ((unsigned)(a.amode ? sq_p * kTypes + 132 + h : kBoardMoves + sq_p * 7 + h) << 18);
                 }
             }
             __syncthreads();
@@ -528,7 +543,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
 // an action is accepted when it is inside the action space and set in the mask handed out last (vec_env.rs:651-690);
 // err = n - (index of the first refused env), 0 when every action stands
-__global__ void shogi_validate_kernel(const long long* actions, const uint8_t* mask, const uint32_t* bits, int n, int* err) {
+__global__ void shogi_validate_kernel(const long long* actions, const uint8_t* mask, const uint32_t* bits, int n, int kA, int* err) {
+    const int kWords = (kA + 31) >> 5;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long act = actions[i];
@@ -547,19 +563,23 @@ static int launch_env(EnvArgs a, hipStream_t st) {
     return ka_check_launch("shogi_env");
 }
 
-extern "C" int ka_shogi_env_reset(void* state, void* keys, void* checks, int n, int max_ply, float* obs, void* mask,
-                                  void* mask_bits, void* current_players, int refresh, void* stream) {
+extern "C" int ka_shogi_env_action_space(int action_mode) { return action_space(action_mode); }
+
+extern "C" int ka_shogi_env_reset(void* state, void* keys, void* checks, int n, int max_ply, int obs_mode, int action_mode,
+                                  float* obs, void* mask, void* mask_bits, void* current_players, int refresh, void* stream) {
     KA_REQUIRE(state && keys && checks && obs && n > 0 && max_ply >= 0 && (mask || mask_bits), "shogi_env_reset: bad arguments");
+    KA_REQUIRE((obs_mode == 0 || obs_mode == 1) && (action_mode == 0 || action_mode == 1), "shogi_env_reset: modes are 0 (default) or 1 (katago / spatial)");
     EnvArgs a{};
     a.state = static_cast<uint8_t*>(state); a.keys = static_cast<unsigned long long*>(keys); a.checks = static_cast<uint8_t*>(checks);
     a.obs = obs; a.mask = static_cast<uint8_t*>(mask); a.mask_bits = static_cast<uint32_t*>(mask_bits);
     a.current_players = static_cast<uint8_t*>(current_players);
+    a.amode = action_mode; a.obs_ch = obs_mode ? 50 : 46;
     a.n = n; a.max_ply = max_ply; a.mode = refresh ? 2 : 0;
     return launch_env(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ka_shogi_env_step(void* state, void* keys, void* checks, const long long* actions, int n, int max_ply,
-                                 const void* prev_mask, const void* prev_mask_bits, int* err,
+                                 int obs_mode, int action_mode, const void* prev_mask, const void* prev_mask_bits, int* err,
                                  float* obs, void* mask, void* mask_bits, float* rewards, void* terminated, void* truncated,
                                  float* terminal_obs, void* current_players, void* captured, void* term_reason,
                                  void* ply_count, int* material, void* stats, void* stream) {
@@ -567,10 +587,11 @@ extern "C" int ka_shogi_env_step(void* state, void* keys, void* checks, const lo
                current_players && captured && term_reason && ply_count && material && stats && n > 0 && max_ply >= 0,
                "shogi_env_step: bad arguments");
     KA_REQUIRE((mask || mask_bits) && (prev_mask || prev_mask_bits), "shogi_env_step: needs the bool or the packed masks");
+    KA_REQUIRE((obs_mode == 0 || obs_mode == 1) && (action_mode == 0 || action_mode == 1), "shogi_env_step: modes are 0 (default) or 1 (katago / spatial)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) { ka_set_error("shogi_env_step: memset failed"); return KA_ERR_HIP; }
     hipLaunchKernelGGL(shogi_validate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, actions,
-                       static_cast<const uint8_t*>(prev_mask), static_cast<const uint32_t*>(prev_mask_bits), n, err);
+                       static_cast<const uint8_t*>(prev_mask), static_cast<const uint32_t*>(prev_mask_bits), n, action_space(action_mode), err);
     EnvArgs a{};
     a.state = static_cast<uint8_t*>(state); a.keys = static_cast<unsigned long long*>(keys); a.checks = static_cast<uint8_t*>(checks);
     a.actions = actions; a.err = err;
@@ -579,6 +600,7 @@ extern "C" int ka_shogi_env_step(void* state, void* keys, void* checks, const lo
     a.terminal_obs = terminal_obs; a.current_players = static_cast<uint8_t*>(current_players);
     a.captured = static_cast<uint8_t*>(captured); a.term_reason = static_cast<uint8_t*>(term_reason);
     a.ply_out = static_cast<uint16_t*>(ply_count); a.material = material; a.stats = static_cast<unsigned long long*>(stats);
+    a.amode = action_mode; a.obs_ch = obs_mode ? 50 : 46;
     a.n = n; a.max_ply = max_ply; a.mode = 1;
     return launch_env(a, st);
 }

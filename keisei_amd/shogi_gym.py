@@ -2,8 +2,10 @@
 
 Reference: shogi-engine/crates/shogi-gym/src/vec_env.rs:556-855 (the PyO3 class), step_result.rs:31-97 (result types).
 Same constructor, `reset()` / `step(actions)`, result attributes, counters and error behaviour -- but the N games live in
-HBM and a step is two launches of `shogi_env.hip` (C ABI `ka_shogi_env_*`, include/keisei_amd.h).  Only the modes the
-KataGo loop asks for (katago_loop.py:580-585: observation_mode="katago", action_mode="spatial") exist on the device.
+HBM and a step is two launches of `shogi_env.hip` (C ABI `ka_shogi_env_*`, include/keisei_amd.h).  Both observation modes
+("default" 46 planes, "katago" 50) and both action modes ("default" 13 527 actions, "spatial" 11 259) exist; the KataGo loop
+asks for katago + spatial (katago_loop.py:580-585).  `DefaultActionMapper` / `SpatialActionMapper` are the index arithmetic of
+action_mapper.rs / spatial_action_mapper.rs on the host.
 
 `output="numpy"` (default) returns host arrays like the reference does; `output="torch"` returns the device tensors
 themselves (observations and masks alternate between two buffers, so a result stays intact until the step after the
@@ -20,9 +22,94 @@ import torch
 
 from . import _lib
 
-ACTION_SPACE = 81 * 139
-OBS_CHANNELS = 50
+ACTION_SPACE = 81 * 139            # spatial
+DEFAULT_ACTION_SPACE = 81 * 80 * 2 + 81 * 7
+OBS_CHANNELS = 50                  # katago
+DEFAULT_OBS_CHANNELS = 46
 MASK_WORDS = (ACTION_SPACE + 31) // 32
+_DIRS = ((-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1))     # spatial_action_mapper.rs:31-40
+
+
+def _sq(v: int, what: str) -> int:
+    if not 0 <= v < 81:
+        raise ValueError(f"invalid square index: {v}")
+    return v
+
+
+class SpatialActionMapper:
+    """spatial_action_mapper.rs:138-356: flat index = square * 139 + move type, in the mover's perspective."""
+
+    action_space_size = ACTION_SPACE
+
+    def encode_board_move(self, from_sq: int, to_sq: int, promote: bool, is_white: bool) -> int:
+        f, t = _sq(from_sq, "from"), _sq(to_sq, "to")
+        if f == t:
+            raise ValueError("from_sq and to_sq must be different")
+        if is_white:
+            f, t = 80 - f, 80 - t
+        dr, dc = t // 9 - f // 9, t % 9 - f % 9
+        if dr == 0 or dc == 0 or abs(dr) == abs(dc):
+            unit = ((dr > 0) - (dr < 0), (dc > 0) - (dc < 0))
+            return f * 139 + (64 if promote else 0) + _DIRS.index(unit) * 8 + max(abs(dr), abs(dc)) - 1
+        if abs(dr) == 2 and abs(dc) == 1:
+            same = (dr > 0) == (dc > 0)
+            return f * 139 + 128 + (0 if same else 1) * 2 + (1 if promote else 0)
+        raise ValueError(f"Cannot encode board move from ({f // 9},{f % 9}) to ({t // 9},{t % 9}) — not a valid direction, "
+                         "distance, or knight move")
+
+    def encode_drop_move(self, to_sq: int, piece_type_idx: int, is_white: bool) -> int:
+        t = _sq(to_sq, "to")
+        if not 0 <= piece_type_idx < 7:
+            raise ValueError(f"piece_type_idx {piece_type_idx} out of range (max 6)")
+        return (80 - t if is_white else t) * 139 + 132 + piece_type_idx
+
+    def decode(self, idx: int, is_white: bool) -> dict:
+        if not 0 <= idx < ACTION_SPACE:
+            raise ValueError(f"action index {idx} out of range (max {ACTION_SPACE - 1})")
+        s, slot = divmod(idx, 139)
+        flip = (lambda q: 80 - q) if is_white else (lambda q: q)
+        if slot >= 132:
+            return {"type": "drop", "to_sq": flip(s), "piece_type_idx": slot - 132}
+        if slot < 128:
+            promote, b = slot >= 64, slot & 63
+            dr, dc = _DIRS[b // 8]
+            r, c = s // 9 + dr * (b % 8 + 1), s % 9 + dc * (b % 8 + 1)
+        else:
+            promote, (r, c) = bool((slot - 128) & 1), (s // 9 - 2, s % 9 + (-1 if (slot - 128) // 2 == 0 else 1))
+        if not (0 <= r < 9 and 0 <= c < 9):
+            raise ValueError(f"decoded move goes off board: from ({s // 9},{s % 9}) slot={slot}")
+        return {"type": "board", "from_sq": flip(s), "to_sq": flip(r * 9 + c), "promote": promote}
+
+
+class DefaultActionMapper:
+    """action_mapper.rs:17-222: from * 160 + (to skipping from) * 2 + promote, then 81 x 7 drops."""
+
+    action_space_size = DEFAULT_ACTION_SPACE
+
+    def encode_board_move(self, from_sq: int, to_sq: int, promote: bool, is_white: bool) -> int:
+        f, t = _sq(from_sq, "from"), _sq(to_sq, "to")
+        if f == t:
+            raise ValueError("from_sq and to_sq must be different")
+        if is_white:
+            f, t = 80 - f, 80 - t
+        return f * 160 + (t - 1 if t > f else t) * 2 + (1 if promote else 0)
+
+    def encode_drop_move(self, to_sq: int, piece_type_idx: int, is_white: bool) -> int:
+        t = _sq(to_sq, "to")
+        if not 0 <= piece_type_idx < 7:
+            raise ValueError(f"piece_type_idx {piece_type_idx} is out of range (max 6)")
+        return 81 * 160 + (80 - t if is_white else t) * 7 + piece_type_idx
+
+    def decode(self, idx: int, is_white: bool) -> dict:
+        if not 0 <= idx < DEFAULT_ACTION_SPACE:
+            raise ValueError(f"action index {idx} is out of range (max {DEFAULT_ACTION_SPACE - 1})")
+        flip = (lambda q: 80 - q) if is_white else (lambda q: q)
+        if idx >= 81 * 160:
+            t, h = divmod(idx - 81 * 160, 7)
+            return {"type": "drop", "to_sq": flip(t), "piece_type_idx": h}
+        f, rem = divmod(idx, 160)
+        off = rem // 2
+        return {"type": "board", "from_sq": flip(f), "to_sq": flip(off + 1 if off >= f else off), "promote": bool(rem & 1)}
 
 _SFEN = {1: "P", 2: "L", 3: "N", 4: "S", 5: "G", 6: "B", 7: "R", 8: "K"}
 
@@ -63,10 +150,9 @@ class VecEnv:
             raise ValueError(f"Unknown observation_mode '{observation_mode}'. Valid: 'default', 'katago'")
         if action_mode not in ("default", "spatial"):
             raise ValueError(f"Unknown action_mode '{action_mode}'. Valid: 'default', 'spatial'")
-        if observation_mode != "katago" or action_mode != "spatial":
-            raise NotImplementedError("the device VecEnv implements observation_mode='katago' with action_mode='spatial' "
-                                      "(what the KataGo loop uses, katago_loop.py:580-585); the 46-plane / 13 527-action "
-                                      "modes were not built")
+        self._omode, self._amode = int(observation_mode == "katago"), int(action_mode == "spatial")
+        self._A = ACTION_SPACE if self._amode else DEFAULT_ACTION_SPACE
+        self._C = OBS_CHANNELS if self._omode else DEFAULT_OBS_CHANNELS
         if output not in ("numpy", "torch"):
             raise ValueError("output must be 'numpy' or 'torch'")
         if num_envs <= 0 or max_ply < 0 or max_ply > 65535:
@@ -81,14 +167,14 @@ class VecEnv:
         self._state = z(n, _lib.query("ka_shogi_env_state_bytes"), dtype=torch.uint8)
         self._keys = z(n, hist, dtype=torch.int64)
         self._checks = z(n, hist, dtype=torch.uint8)
-        self._obs = [z(n, OBS_CHANNELS, 9, 9, dtype=torch.float32) for _ in range(2)]
-        self._mask = [z(n, ACTION_SPACE, dtype=torch.bool) for _ in range(2)]
-        self._bits = [z(n, MASK_WORDS, dtype=torch.int32) for _ in range(2)]
+        self._obs = [z(n, self._C, 9, 9, dtype=torch.float32) for _ in range(2)]
+        self._mask = [z(n, self._A, dtype=torch.bool) for _ in range(2)]
+        self._bits = [z(n, (self._A + 31) // 32, dtype=torch.int32) for _ in range(2)]
         self._cur = 0
         self._rewards = z(n, dtype=torch.float32)
         self._terminated = z(n, dtype=torch.bool)
         self._truncated = z(n, dtype=torch.bool)
-        self._terminal_obs = z(n, OBS_CHANNELS, 9, 9, dtype=torch.float32)
+        self._terminal_obs = z(n, self._C, 9, 9, dtype=torch.float32)
         self._players = z(n, dtype=torch.uint8)
         self._captured = torch.full((n,), 255, dtype=torch.uint8, device=dev)
         self._reason = z(n, dtype=torch.uint8)
@@ -97,23 +183,24 @@ class VecEnv:
         self._stats = z(4, dtype=torch.int64)
         self._err = z(1, dtype=torch.int32)
         self._actions = z(n, dtype=torch.int64)
-        self._started = False
+        # as in the reference's constructor (vec_env.rs:574-612): the games stand at the start position, the mask buffer
+        # is still all-false -- a step() before reset() is refused ("action index ... is not legal")
+        self.reset()
+        for t in (self._obs[0], self._mask[0], self._bits[0]):
+            t.zero_()
 
     # ------------------------------------------------------------------ core
     def reset(self) -> ResetResult:
         """vec_env.rs:617-645: every game back to the start position; observations and masks of the first move."""
         with torch.cuda.device(self.device):
             self._cur = 0
-            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._obs[0],
-                      self._mask[0], self._bits[0], self._players, 0, _lib.stream_ptr())
-        self._started = True
+            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._omode,
+                      self._amode, self._obs[0], self._mask[0], self._bits[0], self._players, 0, _lib.stream_ptr())
         return ResetResult(self._out(self._obs[0]), self._out(self._mask[0]),
                            self._bits[0] if self._output == "torch" else None)
 
     def step(self, actions) -> StepResult:
         """vec_env.rs:651-790.  `actions`: N action indices (list, numpy array or tensor; a CUDA int64 tensor is used in place)."""
-        if not self._started:
-            self.reset()
         n = self._n
         if isinstance(actions, torch.Tensor):
             if actions.numel() != n:
@@ -130,7 +217,7 @@ class VecEnv:
             act = self._actions
         prev, nxt = self._cur, self._cur ^ 1
         with torch.cuda.device(self.device):
-            _lib.call("ka_shogi_env_step", self._state, self._keys, self._checks, act, n, self._max_ply,
+            _lib.call("ka_shogi_env_step", self._state, self._keys, self._checks, act, n, self._max_ply, self._omode, self._amode,
                       self._mask[prev], self._bits[prev], self._err, self._obs[nxt], self._mask[nxt], self._bits[nxt],
                       self._rewards, self._terminated, self._truncated, self._terminal_obs, self._players,
                       self._captured, self._reason, self._ply, self._material, self._stats, _lib.stream_ptr())
@@ -161,11 +248,11 @@ class VecEnv:
     # ------------------------------------------------------------------ properties (vec_env.rs:793-870)
     @property
     def action_space_size(self) -> int:
-        return ACTION_SPACE
+        return self._A
 
     @property
     def observation_channels(self) -> int:
-        return OBS_CHANNELS
+        return self._C
 
     @property
     def num_envs(self) -> int:
@@ -235,9 +322,8 @@ class VecEnv:
     def _refresh(self, raw: np.ndarray) -> None:
         self._state.copy_(torch.from_numpy(raw))
         with torch.cuda.device(self.device):
-            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._obs[self._cur],
-                      self._mask[self._cur], self._bits[self._cur], self._players, 1, _lib.stream_ptr())
-        self._started = True
+            _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._omode,
+                      self._amode, self._obs[self._cur], self._mask[self._cur], self._bits[self._cur], self._players, 1, _lib.stream_ptr())
 
     def current(self) -> ResetResult:
         """Observation and masks of the positions to move (what the last reset / step / set_state wrote)."""

@@ -14,8 +14,8 @@ HERE = Path(__file__).resolve().parent
 SRC = HERE / "shogi_oracle.c"
 LIB = HERE / "_build" / "libshogi_oracle.so"
 
-A_SIZE = 81 * 139
-OBS_LEN = 50 * 81
+A_SIZE = 81 * 139                  # spatial action space
+A_DEFAULT = 81 * 80 * 2 + 81 * 7   # default action space
 PAWN, LANCE, KNIGHT, SILVER, GOLD, BISHOP, ROOK, KING = range(1, 9)
 WHITE, PROM = 0x10, 0x20
 R_PROGRESS, R_CHECKMATE, R_REPETITION, R_PERPETUAL, R_IMPASSE, R_MAXMOVES = range(6)
@@ -49,10 +49,12 @@ def _p(a: np.ndarray):
 class OracleVecEnv:
     """The reference's VecEnv(num_envs, max_ply, "katago", "spatial") restated on the CPU (vec_env.rs:556-855)."""
 
-    def __init__(self, num_envs: int, max_ply: int = 500):
+    def __init__(self, num_envs: int, max_ply: int = 500, observation_mode: str = "katago", action_mode: str = "spatial"):
         self.n, self.max_ply = num_envs, max_ply
-        self.h = C.c_void_p(lib().so_create(num_envs, max_ply))
-        self.terminal_obs = np.zeros((num_envs, 50, 9, 9), np.float32)      # persistent, like the reference's buffer
+        self.omode, self.amode = int(observation_mode == "katago"), int(action_mode == "spatial")
+        self.C, self.A = (50 if self.omode else 46), (A_SIZE if self.amode else A_DEFAULT)
+        self.h = C.c_void_p(lib().so_create(num_envs, max_ply, self.omode, self.amode))
+        self.terminal_obs = np.zeros((num_envs, self.C, 9, 9), np.float32)  # persistent, like the reference's buffer
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -60,8 +62,8 @@ class OracleVecEnv:
             self.h = None
 
     def reset(self):
-        obs = np.zeros((self.n, 50, 9, 9), np.float32)
-        mask = np.zeros((self.n, A_SIZE), np.uint8)
+        obs = np.zeros((self.n, self.C, 9, 9), np.float32)
+        mask = np.zeros((self.n, self.A), np.uint8)
         lib().so_reset(self.h, _p(obs), _p(mask))
         return obs, mask.astype(bool)
 
@@ -69,7 +71,7 @@ class OracleVecEnv:
         a = np.ascontiguousarray(actions, dtype=np.int64)
         assert a.shape == (self.n,)
         out = dict(
-            observations=np.zeros((self.n, 50, 9, 9), np.float32), legal_masks=np.zeros((self.n, A_SIZE), np.uint8),
+            observations=np.zeros((self.n, self.C, 9, 9), np.float32), legal_masks=np.zeros((self.n, self.A), np.uint8),
             rewards=np.zeros(self.n, np.float32), terminated=np.zeros(self.n, np.uint8), truncated=np.zeros(self.n, np.uint8),
             current_players=np.zeros(self.n, np.uint8), captured_piece=np.zeros(self.n, np.uint8),
             termination_reason=np.zeros(self.n, np.uint8), ply_count=np.zeros(self.n, np.uint16),
@@ -102,7 +104,7 @@ class OracleVecEnv:
         lib().so_set_state(self.h, i, _p(b), _p(hd), int(side))
 
     def observe(self, i: int):
-        obs, mask = np.zeros((50, 9, 9), np.float32), np.zeros(A_SIZE, np.uint8)
+        obs, mask = np.zeros((self.C, 9, 9), np.float32), np.zeros(self.A, np.uint8)
         lib().so_observe(self.h, i, _p(obs), _p(mask))
         return obs, mask.astype(bool)
 
@@ -130,13 +132,13 @@ class OracleVecEnv:
         return lib().so_check_termination(self.h, i, C.byref(w)), w.value
 
 
-def encode(frm, to, promote=False, drop=0, white=False):
-    return lib().so_encode(frm, to, int(promote), drop, int(white))
+def encode(frm, to, promote=False, drop=0, white=False, spatial=True):
+    return lib().so_encode(frm, to, int(promote), drop, int(white), int(spatial))
 
 
-def decode(idx, white=False):
+def decode(idx, white=False, spatial=True):
     out = (C.c_int * 4)()
-    if lib().so_decode(idx, int(white), out) != 0:
+    if lib().so_decode(idx, int(white), int(spatial), out) != 0:
         return None
     return tuple(out)
 

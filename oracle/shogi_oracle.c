@@ -30,8 +30,12 @@ enum { PAWN = 1, LANCE, KNIGHT, SILVER, GOLD, BISHOP, ROOK, KING };          /* 
 enum { R_PROGRESS = 0, R_CHECKMATE, R_REPETITION, R_PERPETUAL, R_IMPASSE, R_MAXMOVES };   /* step_result.rs:9-16 */
 
 #define A_TYPES 139
-#define A_SIZE (81 * A_TYPES)
-#define OBS_LEN (50 * 81)
+#define A_SPATIAL (81 * A_TYPES)
+#define A_BOARD (81 * 80 * 2)                 /* action_mapper.rs:17-19 */
+#define A_DEFAULT (A_BOARD + 81 * 7)
+#define A_MAX A_DEFAULT
+static int a_size(int amode) { return amode ? A_SPATIAL : A_DEFAULT; }
+static int obs_len(int omode) { return (omode ? 50 : 46) * 81; }
 
 typedef struct { uint8_t board[81]; uint8_t hands[2][7]; uint8_t side; } Pos;        /* position.rs:20-25 */
 typedef struct { uint8_t from, to, promote, drop; } Mv;                              /* drop: 0 = board move, 1..7 hand type */
@@ -46,6 +50,7 @@ typedef struct {
 
 typedef struct {
     int n; uint32_t max_ply; Game* g;
+    int omode, amode;                /* 1 = katago 50 planes / spatial 11 259 actions; 0 = the 46-plane / 13 527-action defaults */
     uint8_t* mask;                   /* the masks handed out last (step() validates against them, vec_env.rs:666-672) */
     uint64_t stats[4];               /* completed, drawn, truncated, total ply (vec_env.rs:395-408) */
 } Env;
@@ -375,7 +380,26 @@ static int material_balance(const Pos* p, int who) {                            
     return b;
 }
 
-static int encode_action(Mv m, int persp) {                                      /* spatial_action_mapper.rs:138-186 */
+static int encode_default(Mv m, int persp) {                                     /* action_mapper.rs:36-45, 63-77 */
+    const int t = persp ? 80 - m.to : m.to;
+    if (m.drop) return A_BOARD + t * 7 + (m.drop - 1);
+    const int f = persp ? 80 - m.from : m.from;
+    return f * 160 + (t > f ? t - 1 : t) * 2 + (m.promote ? 1 : 0);
+}
+
+static int decode_default(int idx, int persp, Mv* out) {                         /* action_mapper.rs:46-59, 79-110 */
+    if (idx < 0 || idx >= A_DEFAULT) return -1;
+    if (idx >= A_BOARD) {
+        const int t = (idx - A_BOARD) / 7;
+        *out = (Mv){0, (uint8_t)(persp ? 80 - t : t), 0, (uint8_t)((idx - A_BOARD) % 7 + 1)};
+        return 0;
+    }
+    const int f = idx / 160, rem = idx % 160, off = rem / 2, t = off >= f ? off + 1 : off;
+    *out = (Mv){(uint8_t)(persp ? 80 - f : f), (uint8_t)(persp ? 80 - t : t), (uint8_t)(rem & 1), 0};
+    return 0;
+}
+
+static int encode_spatial(Mv m, int persp) {                                     /* spatial_action_mapper.rs:138-186 */
     if (m.drop) return (persp ? 80 - m.to : m.to) * A_TYPES + 132 + (m.drop - 1);
     const int f = persp ? 80 - m.from : m.from, t = persp ? 80 - m.to : m.to;
     const int dr = t / 9 - f / 9, dc = t % 9 - f % 9;
@@ -394,8 +418,8 @@ static int encode_action(Mv m, int persp) {                                     
     return -1;
 }
 
-static int decode_action(int idx, int persp, Mv* out) {                          /* spatial_action_mapper.rs:188-279 */
-    if (idx < 0 || idx >= A_SIZE) return -1;
+static int decode_spatial(int idx, int persp, Mv* out) {                         /* spatial_action_mapper.rs:188-279 */
+    if (idx < 0 || idx >= A_SPATIAL) return -1;
     const int sq = idx / A_TYPES, slot = idx % A_TYPES;
     const int row = sq / 9, col = sq % 9;
     if (slot < 132) {
@@ -417,20 +441,23 @@ static int decode_action(int idx, int persp, Mv* out) {                         
     return 0;
 }
 
-static void write_mask(const Game* g, uint8_t* mask) {                                              /* vec_env.rs:229-247 */
+static int encode_action(Mv m, int persp, int amode) { return amode ? encode_spatial(m, persp) : encode_default(m, persp); }
+static int decode_action(int idx, int persp, Mv* out, int amode) { return amode ? decode_spatial(idx, persp, out) : decode_default(idx, persp, out); }
+
+static void write_mask(const Game* g, uint8_t* mask, int amode) {                                              /* vec_env.rs:229-247 */
     static _Thread_local Mv mv[1024];
-    memset(mask, 0, A_SIZE);
+    memset(mask, 0, (size_t)a_size(amode));
     const int n = legal_moves(g, mv);
-    for (int i = 0; i < n; ++i) mask[encode_action(mv[i], g->pos.side)] = 1;
+    for (int i = 0; i < n; ++i) mask[encode_action(mv[i], g->pos.side, amode)] = 1;
 }
 
 static void fill_plane(float* obs, int ch, float v) { for (int i = 0; i < 81; ++i) obs[ch * 81 + i] = v; }
 
-static void write_obs(const Game* g, int persp, float* obs) {        /* observation.rs:81-153 + katago_observation.rs:41-92 */
+static void write_obs(const Game* g, int persp, float* obs, int omode) {        /* observation.rs:81-153 + katago_observation.rs:41-92 */
     static const int unprom_ch[9] = {0, 0, 1, 2, 3, 4, 5, 6, 7}, prom_ch[9] = {0, 0, 1, 2, 3, 0, 4, 5, 0};
     static const float hand_max[7] = {18.f, 4.f, 4.f, 4.f, 4.f, 2.f, 2.f};
     const Pos* p = &g->pos;
-    memset(obs, 0, OBS_LEN * sizeof(float));
+    memset(obs, 0, (size_t)obs_len(omode) * sizeof(float));
     for (int i = 0; i < 81; ++i) {
         const int pc = p->board[i];
         if (!pc) continue;
@@ -447,6 +474,7 @@ static void write_obs(const Game* g, int persp, float* obs) {        /* observat
     if (mc < 0.f) mc = 0.f;
     if (mc > 1.f) mc = 1.f;
     fill_plane(obs, 43, mc);
+    if (!omode) return;                                   /* observation.rs: planes 44-45 stay zero */
     const int prior = repetition_count(g) - 1;
     if (prior >= 1 && prior <= 3) fill_plane(obs, 44 + prior - 1, 1.f);
     else if (prior >= 4) fill_plane(obs, 47, 1.f);
@@ -459,11 +487,11 @@ static float reward_of(int result, int winner, int last_mover) {                
 }
 
 /* ------------------------------------------------------------------------------------------------ exported API */
-void* so_create(int n, int max_ply) {
+void* so_create(int n, int max_ply, int omode, int amode) {
     Env* e = calloc(1, sizeof *e);
-    e->n = n; e->max_ply = (uint32_t)max_ply;
+    e->n = n; e->max_ply = (uint32_t)max_ply; e->omode = omode; e->amode = amode;
     e->g = calloc((size_t)n, sizeof(Game));
-    e->mask = calloc((size_t)n, A_SIZE);
+    e->mask = calloc((size_t)n, A_MAX);
     for (int i = 0; i < n; ++i) {
         e->g[i].max_ply = (uint32_t)max_ply;
         e->g[i].hist = calloc((size_t)max_ply + 2, sizeof(Pos));
@@ -474,19 +502,19 @@ void* so_create(int n, int max_ply) {
 }
 
 void so_destroy(void* h) {
-    Env* e = h;
+    Env* e = h; const size_t OL = (size_t)obs_len(e->omode); const long AS = a_size(e->amode); (void)OL; (void)AS;
     for (int i = 0; i < e->n; ++i) { free(e->g[i].hist); free(e->g[i].in_check_hist); }
     free(e->g); free(e->mask); free(e);
 }
 
 void so_reset(void* h, float* obs, uint8_t* mask) {                                                 /* vec_env.rs:617-645 */
-    Env* e = h;
+    Env* e = h; const size_t OL = (size_t)obs_len(e->omode); const long AS = a_size(e->amode); (void)OL; (void)AS;
     for (int i = 0; i < e->n; ++i) {
         game_reset(&e->g[i]);
-        write_obs(&e->g[i], e->g[i].pos.side, obs + (size_t)i * OBS_LEN);
-        write_mask(&e->g[i], e->mask + (size_t)i * A_SIZE);
+        write_obs(&e->g[i], e->g[i].pos.side, obs + (size_t)i * OL, e->omode);
+        write_mask(&e->g[i], e->mask + (size_t)i * AS, e->amode);
     }
-    memcpy(mask, e->mask, (size_t)e->n * A_SIZE);
+    memcpy(mask, e->mask, (size_t)e->n * AS);
 }
 
 /* vec_env.rs:651-700 (validation: nothing is mutated when any action is refused) and :340-460 (apply_moves).
@@ -494,15 +522,15 @@ void so_reset(void* h, float* obs, uint8_t* mask) {                             
 int so_step(void* h, const int64_t* actions, float* obs, uint8_t* mask, float* rewards, uint8_t* terminated,
             uint8_t* truncated, float* terminal_obs, uint8_t* current_players, uint8_t* captured, uint8_t* term_reason,
             uint16_t* ply, int32_t* material) {
-    Env* e = h;
+    Env* e = h; const size_t OL = (size_t)obs_len(e->omode); const long AS = a_size(e->amode); (void)OL; (void)AS;
     for (int i = 0; i < e->n; ++i) {
         Mv m;
-        if (actions[i] < 0 || decode_action((int)actions[i], e->g[i].pos.side, &m) != 0) return -(1 + i);
-        if (actions[i] >= A_SIZE || !e->mask[(size_t)i * A_SIZE + actions[i]]) return -(1 + i);
+        if (actions[i] < 0 || decode_action((int)actions[i], e->g[i].pos.side, &m, e->amode) != 0) return -(1 + i);
+        if (actions[i] >= AS || !e->mask[(size_t)i * AS + actions[i]]) return -(1 + i);
     }
     for (int i = 0; i < e->n; ++i) {
         Game* g = &e->g[i];
-        Mv m; decode_action((int)actions[i], g->pos.side, &m);
+        Mv m; decode_action((int)actions[i], g->pos.side, &m, e->amode);
         const int cap = make_move(g, m, 1);
         const int last_mover = g->pos.side ^ 1;
         check_termination(g);
@@ -517,14 +545,14 @@ int so_step(void* h, const int64_t* actions, float* obs, uint8_t* mask, float* r
             e->stats[0]++; e->stats[3] += g->ply;
             if (g->result == R_REPETITION || (g->result == R_IMPASSE && g->winner < 0)) e->stats[1]++;
             if (g->result == R_MAXMOVES) e->stats[2]++;
-            write_obs(g, g->pos.side, terminal_obs + (size_t)i * OBS_LEN);
+            write_obs(g, g->pos.side, terminal_obs + (size_t)i * OL, e->omode);
             game_reset(g);
         }
-        write_obs(g, g->pos.side, obs + (size_t)i * OBS_LEN);
-        write_mask(g, e->mask + (size_t)i * A_SIZE);
+        write_obs(g, g->pos.side, obs + (size_t)i * OL, e->omode);
+        write_mask(g, e->mask + (size_t)i * AS, e->amode);
         current_players[i] = g->pos.side;
     }
-    memcpy(mask, e->mask, (size_t)e->n * A_SIZE);
+    memcpy(mask, e->mask, (size_t)e->n * AS);
     return 0;
 }
 
@@ -538,17 +566,17 @@ void so_get_state(void* h, int i, uint8_t* board, uint8_t* hands, int* side, int
 
 /* place an arbitrary position in env i (the fixtures of rules.rs build theirs square by square); history is cleared */
 void so_set_state(void* h, int i, const uint8_t* board, const uint8_t* hands, int side) {
-    Env* e = h; Game* g = &e->g[i];
+    Env* e = h; Game* g = &e->g[i]; const size_t OL = (size_t)obs_len(e->omode); const long AS = a_size(e->amode); (void)OL; (void)AS;
     memcpy(g->pos.board, board, 81); memcpy(g->pos.hands, hands, 14); g->pos.side = (uint8_t)side;
     g->ply = 0; g->result = R_PROGRESS; g->winner = -1;
-    write_mask(g, e->mask + (size_t)i * A_SIZE);
+    write_mask(g, e->mask + (size_t)i * AS, e->amode);
 }
 
 void so_observe(void* h, int i, float* obs, uint8_t* mask) {
-    Env* e = h; Game* g = &e->g[i];
-    write_obs(g, g->pos.side, obs);
-    write_mask(g, e->mask + (size_t)i * A_SIZE);
-    memcpy(mask, e->mask + (size_t)i * A_SIZE, A_SIZE);
+    Env* e = h; Game* g = &e->g[i]; const size_t OL = (size_t)obs_len(e->omode); const long AS = a_size(e->amode); (void)OL; (void)AS;
+    write_obs(g, g->pos.side, obs, e->omode);
+    write_mask(g, e->mask + (size_t)i * AS, e->amode);
+    memcpy(mask, e->mask + (size_t)i * AS, (size_t)AS);
 }
 
 int so_legal_count(void* h, int i) { static _Thread_local Mv mv[1024]; return legal_moves(&((Env*)h)->g[i], mv); }
@@ -560,9 +588,9 @@ int so_zone_count(void* h, int i, int color) { return zone_count(&((Env*)h)->g[i
 int so_material(void* h, int i, int who) { return material_balance(&((Env*)h)->g[i].pos, who); }
 int so_result(void* h, int i, int* winner) { Game* g = &((Env*)h)->g[i]; *winner = g->winner; return g->result; }
 float so_reward(int result, int winner, int last_mover) { return reward_of(result, winner, last_mover); }
-int so_encode(int from, int to, int promote, int drop, int persp) { return encode_action((Mv){(uint8_t)from, (uint8_t)to, (uint8_t)promote, (uint8_t)drop}, persp); }
-int so_decode(int idx, int persp, int out[4]) {
-    Mv m; const int rc = decode_action(idx, persp, &m);
+int so_encode(int from, int to, int promote, int drop, int persp, int amode) { return encode_action((Mv){(uint8_t)from, (uint8_t)to, (uint8_t)promote, (uint8_t)drop}, persp, amode); }
+int so_decode(int idx, int persp, int amode, int out[4]) {
+    Mv m; const int rc = decode_action(idx, persp, &m, amode);
     if (rc == 0) { out[0] = m.from; out[1] = m.to; out[2] = m.promote; out[3] = m.drop; }
     return rc;
 }

@@ -19,8 +19,8 @@ FIELDS = ("observations", "legal_masks", "rewards", "terminated", "truncated", "
 META = ("captured_piece", "termination_reason", "ply_count", "material_balance")
 
 
-def _env(n, max_ply, **kw):
-    return VecEnv(num_envs=n, max_ply=max_ply, observation_mode="katago", action_mode="spatial", **kw)
+def _env(n, max_ply, observation_mode="katago", action_mode="spatial", **kw):
+    return VecEnv(num_envs=n, max_ply=max_ply, observation_mode=observation_mode, action_mode=action_mode, **kw)
 
 
 def _compare_step(dev, ref, tag):
@@ -35,8 +35,8 @@ def _compare_step(dev, ref, tag):
         assert a.dtype == b.dtype and np.array_equal(a, b), (tag, k, a[:8], b[:8])
 
 
-def _playout(n, max_ply, steps, seed, compare_states_every=25):
-    dev, ref = _env(n, max_ply), OracleVecEnv(n, max_ply)
+def _playout(n, max_ply, steps, seed, compare_states_every=25, modes=("katago", "spatial")):
+    dev, ref = _env(n, max_ply, *modes), OracleVecEnv(n, max_ply, *modes)
     r0, (obs, mask) = dev.reset(), ref.reset()
     assert np.array_equal(r0.observations, obs) and np.array_equal(r0.legal_masks, mask)
     rng = np.random.default_rng(seed)
@@ -83,6 +83,53 @@ def test_random_playouts_long_games():
     """max_ply 300: captures, drops, promotions, mates (random play mates in roughly a tenth of the games)."""
     reasons = _playout(96, 300, 700, seed=2)
     assert reasons[S.R_CHECKMATE] > 0
+
+
+def test_default_modes_and_the_mixed_ones():
+    """The reference's constructor defaults (46 planes, 13 527 actions: vec_env.rs:559-573) and the two mixed settings."""
+    for k, modes in enumerate((("default", "default"), ("katago", "default"), ("default", "spatial"))):
+        reasons = _playout(24, 60, 150, seed=10 + k, modes=modes)
+        assert reasons[S.R_MAXMOVES] > 0
+    env = VecEnv(num_envs=4, max_ply=100)                               # shogi-gym/tests/test_vec_env.py:124-146
+    assert (env.num_envs, env.action_space_size, env.observation_channels) == (4, 13527, 46)
+    r = env.reset()
+    assert r.observations.shape == (4, 46, 9, 9) and r.legal_masks.shape == (4, 13527) and r.legal_masks.sum(1).tolist() == [30] * 4
+
+
+def test_action_mappers_on_the_host():
+    from keisei_amd.shogi_gym import DefaultActionMapper, SpatialActionMapper
+    sp, df = SpatialActionMapper(), DefaultActionMapper()
+    assert sp.action_space_size == 11259 and df.action_space_size == 13527
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        white = bool(rng.integers(2))
+        idx = int(rng.integers(11259))
+        m = S.decode(idx, white)
+        if m is None:
+            with pytest.raises(ValueError):
+                sp.decode(idx, white)
+        else:
+            d = sp.decode(idx, white)
+            if m[3]:
+                assert d == {"type": "drop", "to_sq": m[1], "piece_type_idx": m[3] - 1}
+                assert sp.encode_drop_move(m[1], m[3] - 1, white) == idx
+            else:
+                assert d == {"type": "board", "from_sq": m[0], "to_sq": m[1], "promote": bool(m[2])}
+                assert sp.encode_board_move(m[0], m[1], bool(m[2]), white) == idx
+        idx = int(rng.integers(13527))
+        m = S.decode(idx, white, spatial=False)
+        d = df.decode(idx, white)
+        if m[3]:
+            assert d == {"type": "drop", "to_sq": m[1], "piece_type_idx": m[3] - 1} and df.encode_drop_move(m[1], m[3] - 1, white) == idx
+        else:
+            assert d == {"type": "board", "from_sq": m[0], "to_sq": m[1], "promote": bool(m[2])}
+            assert df.encode_board_move(m[0], m[1], bool(m[2]), white) == idx
+    with pytest.raises(ValueError):
+        sp.encode_board_move(3, 3, False, False)
+    with pytest.raises(ValueError):
+        sp.encode_board_move(0, 12, False, False)                      # neither a line nor a knight jump
+    with pytest.raises(ValueError):
+        df.decode(13527, False)
 
 
 def test_odd_env_counts_and_mask_alignment():
@@ -301,8 +348,10 @@ def test_refused_actions_raise_like_the_reference_and_move_nothing():
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2:] == y[2:]
     r2 = dev.step(good)                                                 # and the env still works
     assert r2.step_metadata.ply_count.tolist() == [1, 1, 1, 1]
-    with pytest.raises(NotImplementedError):
-        VecEnv(num_envs=2)
+    fresh = _env(2, 100)                                                # vec_env.rs:574-612: no masks before reset()
+    assert fresh.get_sfen(1).startswith("lnsgkgsnl/1r5b1/ppppppppp/9/9/9/PPPPPPPPP/1B5R1/LNSGKGSNL b - 1")
+    with pytest.raises(RuntimeError, match="env 0: action index 0 is not legal"):
+        fresh.step([0, 0])
     with pytest.raises(ValueError, match="Unknown observation_mode"):
         VecEnv(num_envs=2, observation_mode="x")
 

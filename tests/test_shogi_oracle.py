@@ -286,3 +286,34 @@ def test_random_playouts_keep_the_invariants():
         mate = r["termination_reason"] == S.R_CHECKMATE
         assert np.all(r["rewards"][mate] == 1.0)
     assert ends > 0 and e.stats()["episodes_completed"] == ends
+
+
+def test_default_modes_46_planes_and_13527_actions():
+    # shogi-gym/tests/test_vec_env.py:124-146 (shapes, 30 legal moves) and action_mapper.rs:17-110 (index layout)
+    e = OracleVecEnv(2, 100, "default", "default")
+    obs, mask = e.reset()
+    assert obs.shape == (2, 46, 9, 9) and mask.shape == (2, 13527) and mask.sum(axis=1).tolist() == [30, 30]
+    k = OracleVecEnv(2, 100)
+    kobs, kmask = k.reset()
+    assert np.array_equal(obs[:, :44], kobs[:, :44]) and np.all(obs[:, 44:] == 0)     # katago = default + 6 planes
+    # the same moves under both encodings
+    for i in np.flatnonzero(kmask[0]):
+        f, t, p, d = S.decode(int(i))
+        assert mask[0, S.encode(f, t, p, d, spatial=False)]
+    assert S.encode(0, 1, spatial=False) == 0 and S.encode(0, 80, True, spatial=False) == 79 * 2 + 1
+    assert S.encode(5, 3, spatial=False) == 5 * 160 + 3 * 2 and S.encode(5, 7, spatial=False) == 5 * 160 + 6 * 2
+    assert S.encode(0, 10, drop=3, spatial=False) == 12960 + 10 * 7 + 2
+    assert S.encode(0, 10, drop=3, white=True, spatial=False) == 12960 + 70 * 7 + 2
+    for idx in (0, 159, 160, 12959, 12960, 13526):
+        f, t, p, d = S.decode(idx, spatial=False)
+        assert S.encode(f, t, p, d, spatial=False) == idx
+        fw, tw, pw, dw = S.decode(idx, white=True, spatial=False)
+        assert S.encode(fw, tw, pw, dw, white=True, spatial=False) == idx
+    assert S.decode(13527, spatial=False) is None
+    # one truncated game: same bookkeeping in the default modes (test_vec_env.py:159-197, 257-273)
+    e = OracleVecEnv(1, 1, "default", "default")
+    _, mask = e.reset()
+    r = e.step([int(np.flatnonzero(mask[0])[0])])
+    assert r["truncated"][0] and r["legal_masks"][0].sum() == 30 and r["terminal_observations"].shape == (1, 46, 9, 9)
+    assert r["terminal_observations"][0].sum() != 0 and r["current_players"][0] == 0
+    assert e.stats()["episodes_completed"] == 1 and e.stats()["episodes_truncated"] == 1

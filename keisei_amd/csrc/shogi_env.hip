@@ -20,7 +20,7 @@ namespace {
 constexpr int kTypes = 139, kBoardMoves = 81 * 80 * 2;
 // action spaces: spatial 81 x 139 = 11 259 (spatial_action_mapper.rs), default 81 x 80 x 2 + 81 x 7 = 13 527 (action_mapper.rs:17-19);
 // observation planes: katago 50 (katago_observation.rs), default 46 (observation.rs: planes 44-45 reserved)
-constexpr int kMaxWords = (13527 + 31) / 32;
+constexpr int kMaxWords = (13527 + 31) / 32, kMaxCand = 1024;
 __host__ __device__ constexpr int action_space(int amode) { return amode ? 81 * kTypes : kBoardMoves + 81 * 7; }
 constexpr int kStateBytes = 128;      // board[81] hands[14] side in_check pad[3] | ply u32 @100 | key u64 @104 | reps u32 @112
 enum { PAWN = 1, LANCE, KNIGHT, SILVER, GOLD, BISHOP, ROOK, KING };
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ uint8_t s_hands[16];
     __shared__ uint16_t s_dirs[64];
     __shared__ uint32_t s_bits[kMaxWords + 2];
-    __shared__ uint32_t s_cand[1024];
+    __shared__ uint32_t s_cand[kMaxCand];      // pseudo-legal candidates: at most 593 legal moves exist in any position; appends are clamped
     __shared__ int s_ncand, s_np, s_nh;
     __shared__ uint8_t s_plist[48], s_hlist[8];
     __shared__ float s_plane[22];
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                             const int to_p = me ? 80 - to : to;
                             const int act = a.amode ? sq_p * kTypes + d_p * 8 + k - 1 : sq_p * 160 + (to_p > sq_p ? to_p - 1 : to_p) * 2;
                             const int pstep = a.amode ? 64 : 1;
-                            if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
-                            if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + pstep) << 18);
+                            if (!must) s_cand[min(atomicAdd(&s_ncand, 1), kMaxCand - 1)] = base | ((unsigned)act << 18);
+                            if (must || opt) s_cand[min(atomicAdd(&s_ncand, 1), kMaxCand - 1)] = base | (1u << 14) | ((unsigned)(act + pstep) << 18);
                             if (q) break;
                         }
                     } else {
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         const bool must = tr_p <= 1, opt = !must && tr_p <= 2;
                         const unsigned base = (unsigned)from | ((unsigned)to << 7);
                         const int act = a.amode ? sq_p * kTypes + 128 + sd * 2 : sq_p * 160 + (to_p > sq_p ? to_p - 1 : to_p) * 2;
-                        if (!must) s_cand[atomicAdd(&s_ncand, 1)] = base | ((unsigned)act << 18);
-                        if (must || opt) s_cand[atomicAdd(&s_ncand, 1)] = base | (1u << 14) | ((unsigned)(act + 1) << 18);
+                        if (!must) s_cand[min(atomicAdd(&s_ncand, 1), kMaxCand - 1)] = base | ((unsigned)act << 18);
+                        if (must || opt) s_cand[min(atomicAdd(&s_ncand, 1), kMaxCand - 1)] = base | (1u << 14) | ((unsigned)(act + 1) << 18);
                     }
                 } else {
                     const int u = task - nboard, h = s_hlist[u / 81], sq_p = u % 81;
@@ -441,13 +441,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         for (int r = 0; r < 9; ++r) nifu |= s_board[r * 9 + to % 9] == (PAWN | mine);
                         if (nifu) continue;
                     }
-                    s_cand[atomicAdd(&s_ncand, 1)] = ((unsigned)to << 7) | ((unsigned)(h + 1) << 15) |
+                    s_cand[min(atomicAdd(&s_ncand, 1), kMaxCand - 1)] = ((unsigned)to << 7) | ((unsigned)(h + 1) << 15) |
                                                      ((unsigned)(a.amode ? sq_p * kTypes + 132 + h : kBoardMoves + sq_p * 7 + h) << 18);
                 }
             }
             __syncthreads();
             const int my_king = king_of(me), opp_king = king_of(me ^ 1);
-            const int nc = s_ncand;
+            const int nc = min(s_ncand, kMaxCand);
             // King safety.  A move can only uncover the king when the moving piece stands on one of the king's eight
             // lines, and a drop never does; so unless the mover is in check already, only king moves and moves of aligned
             // pieces take the full test (the moved piece gone from `from`, present on `to`, look outward from the king).

@@ -336,3 +336,44 @@ def test_per_env_gae_layout(golden, monkeypatch):
             d["terminated"][:1], d["legal_masks"][:1], d["value_categories"][:1], d["score_targets"][:1], env_ids=torch.tensor([9]))
     with pytest.raises(IndexError, match="env_id 9 >= next_values size 4"):
         algo.update(buf, g["next_values"])
+
+
+def test_rollout_helpers_of_the_loop_on_the_cpu():
+    """keisei_amd.training.katago_loop (katago_loop.py:63-431): the reference's call forms on CPU tensors."""
+    import numpy as np
+
+    from keisei_amd.training.katago_loop import (PendingTransitions, _compute_value_cats, _negate_where, _resolve_opponent_devices,
+                                                  sign_correct_bootstrap, split_merge_step, to_learner_perspective)
+    from keisei_amd.training.model_registry import build_model
+
+    torch.manual_seed(0)
+    cfg = dict(num_blocks=1, channels=16, se_reduction=4, global_pool_channels=8, policy_channels=8, value_fc_size=16,
+               score_fc_size=8, obs_channels=50)
+    learner, opp = build_model("se_resnet", dict(cfg)).eval(), build_model("se_resnet", dict(cfg)).eval()
+    n = 6
+    obs = torch.randn(n, 50, 9, 9)
+    legal = torch.zeros(n, 11259, dtype=torch.bool); legal[:, 100:140] = True
+    players = np.array([0, 1, 0, 1, 1, 0], dtype=np.uint8)
+    sm = split_merge_step(obs, legal, players, learner, opponent_model=opp, learner_side=0)
+    assert sm.learner_indices.tolist() == [0, 2, 5] and sm.learner_mask.tolist() == [True, False, True, False, False, True]
+    assert bool(legal[torch.arange(n), sm.actions].all()) and sm.learner_log_probs.shape == (3,) and sm.learner_values.shape == (3,)
+    sm2 = split_merge_step(obs, legal, players, learner, opponent_models={7: opp, 9: opp}, env_opponent_ids=np.array([7, 9, 7, 9, 7, 9]),
+                           learner_side=np.array([0, 0, 1, 1, 0, 0]))
+    assert sm2.learner_mask.tolist() == [True, False, False, True, False, True]
+    assert _resolve_opponent_devices({0: opp}, torch.device("cpu")) == {0: None}
+    v = torch.tensor([1.0, -2.0, 3.0])
+    assert _negate_where(v, np.array([True, False, True])).tolist() == [-1.0, -2.0, -3.0] and v.tolist() == [1.0, -2.0, 3.0]
+    assert to_learner_perspective(v, np.array([0, 1, 1]), 0).tolist() == [1.0, 2.0, -3.0]
+    assert sign_correct_bootstrap(v, np.array([1, 1, 0]), np.array([1, 0, 0])).tolist() == [1.0, 2.0, 3.0]
+    cats = _compute_value_cats(torch.tensor([1.0, 0.0, -1.0, 1.0]), torch.tensor([True, True, True, False]), torch.device("cpu"))
+    assert cats.tolist() == [0, 1, 2, -1]
+    pend = PendingTransitions(3, (2,), 5, torch.device("cpu"))
+    m = torch.tensor([True, False, True])
+    z = torch.zeros(3)
+    pend.create(m, torch.ones(3, 2), torch.tensor([4, 4, 4]), z, z, torch.ones(3, 5, dtype=torch.bool), z, z)
+    with pytest.raises(RuntimeError, match="already-valid pending transition"):
+        pend.create(m, torch.ones(3, 2), torch.tensor([4, 4, 4]), z, z, torch.ones(3, 5, dtype=torch.bool), z, z)
+    pend.accumulate_reward(torch.tensor([1.0, 5.0, -1.0]))
+    out = pend.finalize(torch.tensor([True, True, False]), torch.tensor([True, False, False]), torch.tensor([True, False, False]))
+    assert out["env_ids"].tolist() == [0] and out["rewards"].tolist() == [1.0] and pend.valid.tolist() == [False, False, True]
+    assert pend.finalize(torch.tensor([False, True, False]), torch.zeros(3, dtype=torch.bool), torch.zeros(3, dtype=torch.bool)) is None

@@ -96,3 +96,74 @@ def test_self_play_epochs_with_the_device_env():
         assert buf.size == 0 and all(math.isfinite(v) for v in met.values()), met
     assert env.episodes_completed >= N                                   # max_ply 24 < 48 steps: every game ended at least once
     assert env.episodes_truncated > 0
+
+
+def test_split_merge_step_with_device_players_and_the_device_env():
+    """SURVEY §8 f2 (katago_loop.py:284-431): learner where it is to move, the opponents elsewhere, merged actions legal;
+    players / opponent ids as device tensors (from the device env) and as the numpy arrays the reference passes."""
+    import numpy as np
+
+    from keisei_amd.shogi_gym import VecEnv
+    from keisei_amd.training.katago_loop import (PendingTransitions, _compute_value_cats, sign_correct_bootstrap,
+                                                  split_merge_step, to_learner_perspective)
+
+    torch.manual_seed(0)
+    cfg = dict(num_blocks=2, channels=64, se_reduction=8, global_pool_channels=32, policy_channels=16, value_fc_size=64,
+               score_fc_size=32, obs_channels=50)
+    learner, opp_a, opp_b = (build_model("se_resnet", dict(cfg)).to(DEV).eval() for _ in range(3))
+    N = 48
+    env = VecEnv(num_envs=N, max_ply=40, observation_mode="katago", action_mode="spatial", output="torch", check_actions=False)
+    r = env.reset()
+    obs, legal = r.observations, r.legal_masks
+    players = torch.zeros(N, dtype=torch.uint8, device=DEV)
+    opp_ids = torch.arange(N, device=DEV) % 2
+    learner_side = (torch.arange(N, device=DEV) % 3 == 0).to(torch.uint8)       # per-env sides, as the league assigns them
+    pending = PendingTransitions(N, (50, 9, 9), A, torch.device(DEV))
+    seen_learner = seen_opp = 0
+    for t in range(30):
+        sm = split_merge_step(obs, legal, players, learner, opponent_models={0: opp_a, 1: opp_b}, env_opponent_ids=opp_ids,
+                              learner_side=learner_side)
+        assert torch.equal(sm.learner_mask, players == learner_side) and torch.equal(sm.opponent_mask, ~sm.learner_mask)
+        assert torch.equal(sm.learner_indices, sm.learner_mask.nonzero(as_tuple=True)[0])
+        assert bool(legal[torch.arange(N, device=DEV), sm.actions].all())
+        n_l = int(sm.learner_mask.sum())
+        assert sm.learner_log_probs.shape == (n_l,) and sm.learner_values.shape == (n_l,)
+        assert bool(torch.isfinite(sm.learner_log_probs).all()) and bool((sm.learner_log_probs <= 0).all())
+        if n_l:                                                          # log-probs are the masked softmax of the learner's logits
+            with torch.no_grad():
+                logits = learner(obs[sm.learner_indices]).policy_logits.reshape(n_l, -1).float()
+            ref = torch.log_softmax(logits.masked_fill(~legal[sm.learner_indices], float("-inf")), dim=-1)
+            got = ref.gather(1, sm.actions[sm.learner_indices].unsqueeze(1)).squeeze(1)
+            assert torch.allclose(sm.learner_log_probs, got, atol=2e-3, rtol=0)
+        seen_learner += n_l; seen_opp += N - n_l
+        pre_players = players
+        res = env.step(sm.actions)
+        players = res.current_players
+        rew = to_learner_perspective(res.rewards, pre_players, learner_side)
+        assert torch.equal(rew.abs(), res.rewards.abs())
+        flipped = pre_players != learner_side
+        assert torch.equal(rew[flipped], -res.rewards[flipped]) and torch.equal(rew[~flipped], res.rewards[~flipped])
+        boot = sign_correct_bootstrap(torch.ones(N, device=DEV), players, learner_side)
+        assert torch.equal(boot == -1, players != learner_side)
+        cats = _compute_value_cats(rew, res.terminated, torch.device(DEV))
+        assert bool((cats[~res.terminated] == -1).all())
+        pending.accumulate_reward(rew)
+        done = res.terminated | res.truncated
+        fin = pending.finalize(done | sm.learner_mask, done, res.terminated)
+        if fin is not None:
+            assert fin["obs"].shape[1:] == (50, 9, 9) and fin["env_ids"].dtype == torch.long
+        full_lp = torch.zeros(N, device=DEV); full_lp[sm.learner_indices] = sm.learner_log_probs
+        full_v = torch.zeros(N, device=DEV); full_v[sm.learner_indices] = sm.learner_values
+        pending.create(sm.learner_mask & ~done, obs, sm.actions, full_lp, full_v, legal, torch.zeros(N, device=DEV),
+                       torch.zeros(N, device=DEV))
+        obs, legal = res.observations, res.legal_masks
+    env.raise_if_refused()
+    assert seen_learner > 0 and seen_opp > 0
+    # the reference's call form: numpy players / ids, one opponent model, integer side
+    sm = split_merge_step(obs, legal, players.cpu().numpy(), learner, opponent_model=opp_a, learner_side=0)
+    assert torch.equal(sm.learner_mask, players == 0) and bool(legal[torch.arange(N, device=DEV), sm.actions].all())
+    with pytest.raises(ValueError, match="Must provide either opponent_model or opponent_models"):
+        split_merge_step(obs, legal, players, learner)
+    dead = legal.clone(); dead[5] = False
+    with pytest.raises(RuntimeError, match="zero legal actions"):
+        split_merge_step(obs, dead, torch.full((N,), 0, dtype=torch.uint8, device=DEV), learner, opponent_model=opp_a, learner_side=0)

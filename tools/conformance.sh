@@ -24,4 +24,12 @@ FILES=(
   tests/integration/test_ddp_training.py
 )
 cd "$REF" || exit 2
+if [ "${1:-}" = "--loop-helpers" ]; then
+  # second leg: the reference's tests of its rollout helpers (and its loop) with keisei_amd.training.katago_loop's
+  # split_merge_step / PendingTransitions / perspective corrections grafted into the reference's katago_loop module
+  shift
+  export KEISEI_CONFORMANCE_LOOP=1
+  exec python -m pytest -p no:cacheprovider --noconftest -p keisei_shim_plugin -q tests/test_split_merge.py \
+    tests/test_split_merge_transitions.py tests/test_split_merge_gae_opt.py tests/test_katago_loop.py "$@"
+fi
 exec python -m pytest -p no:cacheprovider --noconftest -p keisei_shim_plugin -q "${FILES[@]}" "$@"

@@ -90,5 +90,19 @@ def install() -> None:
 install()
 
 
+def _graft_loop_helpers() -> None:
+    """KEISEI_CONFORMANCE_LOOP=1: the rollout helpers of the reference's katago_loop.py (split_merge_step,
+    PendingTransitions, the perspective corrections ...) are replaced by this build's (keisei_amd.training.katago_loop)
+    INSIDE the reference's module, so that the reference's tests of those helpers -- and its loop -- run on them."""
+    ref_loop = importlib.import_module("keisei.training.katago_loop")
+    mine = importlib.import_module("keisei_amd.training.katago_loop")
+    for name in mine.__all__:
+        setattr(ref_loop, name, getattr(mine, name))
+
+
+if os.environ.get("KEISEI_CONFORMANCE_LOOP") == "1":
+    _graft_loop_helpers()
+
+
 def pytest_report_header(config):
     return [f"keisei conformance shim: hot-path modules -> keisei_amd ({len(HOT)} aliases), the rest from {REF}"]

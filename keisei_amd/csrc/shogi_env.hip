@@ -73,30 +73,30 @@ __device__ __forceinline__ int at(const View& v, int sq) { return sq == v.o1 ? v
 
 // is `sq` attacked by a piece of colour `by`?  Looks outward from the square: the first piece met along each of the
 // eight lines attacks it if it steps (distance 1) or slides back along that line; plus the two knight origins.
-__device__ bool attacked(const View& v, int sq, int by) {
+// One probe = one line (d < 8) or one knight origin (d = 8, 9), so that ten lanes can share a test.
+__device__ __forceinline__ bool attacked_from(const View& v, int sq, int by, int d) {
     const int r = sq / 9, c = sq % 9;
-#pragma unroll 1
-    for (int d = 0; d < 8; ++d) {
+    if (d < 8) {
         const int dr = dir_dr(d), dc = dir_dc(d);
         const unsigned need = 1u << ((d + 4) & 7);
         int rr = r + dr, cc = c + dc, k = 1;
         while ((unsigned)rr < 9u && (unsigned)cc < 9u) {
             const int p = at(v, rr * 9 + cc);
             if (p) {
-                if (((p >> 4) & 1) == by) {
-                    const unsigned m = v.dirs[p & 63];
-                    if ((k == 1 && (m & need)) || ((m >> 8) & need)) return true;
-                }
-                break;
+                if (((p >> 4) & 1) != by) return false;
+                const unsigned m = v.dirs[p & 63];
+                return (k == 1 && (m & need)) || ((m >> 8) & need);
             }
             rr += dr; cc += dc; ++k;
         }
+        return false;
     }
-    const int kr = by ? r - 2 : r + 2, kn = KNIGHT | (by ? WHITE_BIT : 0);
-    if ((unsigned)kr < 9u) {
-        if (c > 0 && at(v, kr * 9 + c - 1) == kn) return true;
-        if (c < 8 && at(v, kr * 9 + c + 1) == kn) return true;
-    }
+    const int kr = by ? r - 2 : r + 2, kc = c + (d == 8 ? -1 : 1);
+    return (unsigned)kr < 9u && (unsigned)kc < 9u && at(v, kr * 9 + kc) == (KNIGHT | (by ? WHITE_BIT : 0));
+}
+__device__ bool attacked(const View& v, int sq, int by) {
+#pragma unroll 1
+    for (int d = 0; d < 10; ++d) if (attacked_from(v, sq, by, d)) return true;
     return false;
 }
 
@@ -231,11 +231,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         h = wave_xor64(h);
         return side ? h ^ mix64(0x8000ull) : h;
     };
-    auto side_in_check = [&](int color) {                      // game.rs:98-105 (wave-uniform result)
+    auto side_in_check = [&](int color) {                      // game.rs:98-105 (wave-uniform result); ten lanes, one probe each
         const int k = king_of(color);
-        int r = 0;
-        if (lane == 0 && k >= 0) { const View v{brd, drs, -1, 0, -1, 0}; r = attacked(v, k, color ^ 1); }
-        return __shfl(r, 0);
+        bool hit = false;
+        if (k >= 0 && lane < 10) { const View v{brd, drs, -1, 0, -1, 0}; hit = attacked_from(v, k, color ^ 1, lane); }
+        return (int)(__ballot(hit) != 0);
     };
 
     int terminal = R_PROGRESS, winner = -1, last_mover = 0, cap = 0;
@@ -346,26 +346,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         else if (lane == 20) s_plane[20] = (a.obs_ch == 50 && in_check) ? 1.f : 0.f;
         else if (lane == 21) s_plane[21] = 0.f;
         __syncthreads();
+        // 28 piece planes: zeros, then one 1.0 per piece; the other planes are constants.  (Computing every element from
+        // the board cost about a third of the kernel's instructions.)
         f32x2* o2 = reinterpret_cast<f32x2*>(out);
-        for (int i = lane; i < kObs / 2; i += 64) {
-            f32x2 v;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int idx = 2 * i + e, ch = idx / 81, s = idx - ch * 81;
-                float f;
-                if (ch >= 28) f = s_plane[ch - 28];
-                else {
-                    const int p = s_board[side ? 80 - s : s];
-                    int pch = -1;
-                    if (p) {
-                        const int t = p & 15, own = ((p >> 4) & 1) == side;
-                        pch = (p & PROM_BIT) ? (own ? 8 : 22) + (t <= SILVER ? t - 1 : t - 2) : (own ? 0 : 14) + t - 1;
-                    }
-                    f = pch == ch ? 1.f : 0.f;
-                }
-                v[e] = f;
+        constexpr int kPiecePairs = 28 * 81 / 2;
+        for (int i = lane; i < kPiecePairs; i += 64) o2[i] = f32x2{0.f, 0.f};
+        for (int i = kPiecePairs + lane; i < kObs / 2; i += 64) {
+            const int idx = 2 * i;
+            o2[i] = f32x2{s_plane[idx / 81 - 28], s_plane[(idx + 1) / 81 - 28]};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zeros are in L2 before other lanes' ones follow them
+        for (int sq = lane; sq < 81; sq += 64) {
+            const int p = s_board[side ? 80 - sq : sq];
+            if (p) {
+                const int t = p & 15, own = ((p >> 4) & 1) == side;
+                const int pch = (p & PROM_BIT) ? (own ? 8 : 22) + (t <= SILVER ? t - 1 : t - 2) : (own ? 0 : 14) + t - 1;
+                out[pch * 81 + sq] = 1.f;
             }
-            o2[i] = v;
         }
         __syncthreads();
     };

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
     };
 
     KA_LDS_BARRIER();
+    // Every workgroup walks the same FC weight rows, and all of them arrive at a chain at about the same moment: without a
+    // per-workgroup rotation of the row order all 128+ workgroups ask the same L2 lines in the same clock (one channel serves
+    // them one after the other while the others idle).  The rows are independent, so the order does not touch the results.
+    const int rot1 = (int)((blockIdx.x * 8u) % (unsigned)a.G), rot2 = (int)((blockIdx.x * 16u) & (kC - 1));
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const TowerBlock tb = a.blocks[blk];
         // ---- global-pool bias: hid = relu(W1 pooled + b1), one wave per row, lanes along the 3C inputs; four rows' loads are
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
                 f32x4 wv[8][3];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int j = min(jb + 8 * u, a.G - 1);
+                    const int j = (min(jb + 8 * u, a.G - 1) + rot1) % a.G;          // (rows rotated per workgroup, see rot1)
                     gvec_ptr wr = (gvec_ptr)(tb.gw1 + (size_t)j * 3 * kC);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) wv[u][k] = wr[lane + 64 * k];
@@ -171,15 +175,15 @@ __global__ __launch_bounds__(512) void tower_eval_kernel(TowerArgs a) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) t += wv[u][k][0] * pv[k][0] + wv[u][k][1] * pv[k][1] + wv[u][k][2] * pv[k][2] + wv[u][k][3] * pv[k][3];
                     t = wave_sum(t);
-                    const int j = jb + 8 * u;
-                    if (lane == 0 && j < a.G) vec[kHid + j] = fmaxf(t + gf(tb.gb1)[j], 0.f);
+                    const int j = jb + 8 * u, jr = (j + rot1) % a.G;
+                    if (lane == 0 && j < a.G) vec[kHid + jr] = fmaxf(t + gf(tb.gb1)[jr], 0.f);
                 }
             }
         }
         KA_LDS_BARRIER();
         if (!(a.abl & 1)) {   // g[c] = W2[c] . hid + b2[c]: two threads per channel, each a contiguous half of the row (16-byte loads)
             typedef const __attribute__((address_space(1))) f32x4* gvec_ptr;
-            const int c = tid >> 1, half = tid & 1, n = a.G >> 1;
+            const int c = ((tid >> 1) + rot2) & (kC - 1), half = tid & 1, n = a.G >> 1;
             gvec_ptr wr = (gvec_ptr)(tb.gw2 + (size_t)c * a.G + half * n);
             float s = 0.f;
             for (int j = 0; j < n / 4; ++j) {

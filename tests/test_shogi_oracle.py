@@ -317,3 +317,44 @@ def test_default_modes_46_planes_and_13527_actions():
     assert r["truncated"][0] and r["legal_masks"][0].sum() == 30 and r["terminal_observations"].shape == (1, 46, 9, 9)
     assert r["terminal_observations"][0].sum() != 0 and r["current_players"][0] == 0
     assert e.stats()["episodes_completed"] == 1 and e.stats()["episodes_truncated"] == 1
+
+
+def test_host_action_mappers_agree_with_the_oracle_and_the_env_needs_a_gpu():
+    import torch
+
+    from keisei_amd import _lib
+    from keisei_amd.shogi_gym import DefaultActionMapper, SpatialActionMapper, VecEnv
+
+    sp, df = SpatialActionMapper(), DefaultActionMapper()
+    assert sp.action_space_size == 11259 and df.action_space_size == 13527
+    for white in (False, True):
+        for idx in range(0, 11259, 7):
+            m = S.decode(idx, white)
+            if m is None:
+                with pytest.raises(ValueError):
+                    sp.decode(idx, white)
+            elif m[3]:
+                assert sp.decode(idx, white) == {"type": "drop", "to_sq": m[1], "piece_type_idx": m[3] - 1}
+                assert sp.encode_drop_move(m[1], m[3] - 1, white) == idx
+            else:
+                assert sp.decode(idx, white) == {"type": "board", "from_sq": m[0], "to_sq": m[1], "promote": bool(m[2])}
+                assert sp.encode_board_move(m[0], m[1], bool(m[2]), white) == idx
+        for idx in range(0, 13527, 11):
+            m = S.decode(idx, white, spatial=False)
+            if m[3]:
+                assert df.decode(idx, white) == {"type": "drop", "to_sq": m[1], "piece_type_idx": m[3] - 1}
+                assert df.encode_drop_move(m[1], m[3] - 1, white) == idx
+            else:
+                assert df.decode(idx, white) == {"type": "board", "from_sq": m[0], "to_sq": m[1], "promote": bool(m[2])}
+                assert df.encode_board_move(m[0], m[1], bool(m[2]), white) == idx
+    with pytest.raises(ValueError):
+        sp.encode_board_move(3, 3, False, False)
+    with pytest.raises(ValueError):
+        sp.encode_board_move(0, 12, False, False)
+    with pytest.raises(ValueError):
+        df.decode(13527, False)
+    with pytest.raises(ValueError, match="Unknown action_mode"):
+        VecEnv(num_envs=2, action_mode="x")
+    if not torch.cuda.is_available():                       # the product path fails loudly: there is no CPU env behind this class
+        with pytest.raises(_lib.KeiseiHipError):
+            VecEnv(num_envs=2, observation_mode="katago", action_mode="spatial")

@@ -207,6 +207,14 @@ int ka_policy_loss(const float* logits, const void* legal, const long long* acti
  * legal as in ka_policy_loss (bool rows, or packed rows with legal_words = ka_mask_words(A)). */
 int ka_masked_softmax(const float* logits, const void* legal, float* probs, int* nlegal, int* flags, int B, int A,
                       int legal_words, void* stream);
+/* ka_policy_sample: the whole tail of select_actions in one launch (katago_ppo.py:567-612 masked_fill / softmax /
+ * Categorical.sample / log_prob / zero-legal guard, :536-541 scalar value, value_adapter.py:56-65 blend).  logits (B,A) fp32 or
+ * bf16 (logits_bf16 != 0); legal as in ka_masked_softmax; seed: any 64-bit value, one uniform per (seed, row) by a 64-bit mix;
+ * actions (B) int64, logp (B) = log softmax_masked(logits)[action], nlegal (B); values (B) optional: P(W)-P(L) of vlogits (B,3),
+ * blended with clamp(score,-1,1) by alpha when score != NULL.  flags[0] |= NaN in the logits, flags[1] |= a row with no legal action. */
+int ka_policy_sample(const void* logits, int logits_bf16, const void* legal, int legal_words, long long seed,
+                     const float* vlogits, const float* score, float alpha, long long* actions, float* logp, float* values,
+                     int* nlegal, int* flags, int B, int A, void* stream);
 /* Supervised policy cross-entropy (keisei/sl/trainer.py:150-152): rowloss[b] = logsumexp(logits[b]) - logits[b][t],
  * t = targets[idx ? idx[b] : b]; dlogits (optional) = w_policy * (softmax - onehot) [* *gscale].  flags[0] |= NaN logits,
  * flags[1] |= target outside [0,A).  ka_value_loss then supplies the W/D/L cross-entropy, the score MSE and the means

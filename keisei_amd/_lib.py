@@ -56,6 +56,7 @@ _SIGS = {
     "ka_rows_sq_sums": "ppp ii i p",
     "ka_policy_loss": "pppppp pppp pp fff iii p",
     "ka_masked_softmax": "ppppp iii p",
+    "ka_policy_sample": "pi pi q pp f ppp pp ii p",
     "ka_policy_ce": "ppp ppp p f ii p",
     "ka_value_loss": "ppppp pp pp pp p ffff i i p",
     "ka_scalar_value": "pp f p i p",

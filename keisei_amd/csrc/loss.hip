@@ -312,6 +312,103 @@ __global__ void scalar_value_kernel(const float* __restrict__ vl, const float* _
     out[b] = v;
 }
 
+// Rollout side, one launch per select_actions call (katago_ppo.py:567-612: masked_fill(-inf) -> softmax -> Categorical.sample()
+// -> log_prob, zero-legal guard, scalar value): one workgroup per environment stages the logit row in LDS, draws ONE action
+// by inverse-CDF over the legal actions (contiguous chunk per thread, block prefix sums, the first chunk whose running
+// total passes u * total is walked) and returns log p(action) as the masked-softmax path does; the value head's
+// P(W) - P(L) (+ blend) rides along.  u comes from a 64-bit mix of (seed, environment): the caller draws `seed` from the
+// host generator, so torch.manual_seed() still fixes the rollout.  flags[0] |= NaN logits, flags[1] |= a row without a
+// legal action (its action is 0, the caller raises as the reference does).
+struct SampleArgs {
+    const void* logits; int logits_bf16; const uint8_t* legal; int legal_words; unsigned long long seed;
+    const float* vlogits; const float* score; float alpha;
+    long long* actions; float* logp; float* values; int* nlegal; int* flags; int A;
+};
+
+__device__ __forceinline__ unsigned long long sample_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(kPolThreads) void policy_sample_kernel(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    uint8_t* msk = reinterpret_cast<uint8_t*>(smem + ((size_t)a.A * 4 + 15) / 16 * 16);
+    __shared__ float red[kPolThreads / 64];
+    __shared__ float wave_tot[kPolThreads / 64];
+    __shared__ int s_first, s_last;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, A = a.A;
+    const uint8_t* lm = a.legal + (size_t)b * A;
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(a.legal) + (size_t)b * a.legal_words;
+    float mx = -INFINITY, nlegal = 0.f;
+    int nan_seen = 0;
+    for (int j = tid; j < A; j += kPolThreads) {
+        const float v = a.logits_bf16 ? bf2f(static_cast<const uint16_t*>(a.logits)[(size_t)b * A + j])
+                                      : static_cast<const float*>(a.logits)[(size_t)b * A + j];
+        const uint8_t k = a.legal_words ? (uint8_t)((lw[j >> 5] >> (j & 31)) & 1u) : lm[j];
+        row[j] = v; msk[j] = k;
+        nan_seen |= (v != v);
+        if (k) { mx = fmaxf(mx, v); nlegal += 1.f; }
+    }
+    if (tid == 0) { s_first = kPolThreads; s_last = -1; }
+    mx = block_reduce(mx, red, true);
+    nlegal = block_reduce(nlegal, red, false);
+    const float nanf_ = block_reduce((float)nan_seen, red, false);
+    float s = 0.f;
+    for (int j = tid; j < A; j += kPolThreads)
+        if (msk[j]) s += expf(row[j] - mx);
+    s = block_reduce(s, red, false);                           // the normaliser of the masked-softmax path (same order)
+    // contiguous chunk per thread, inclusive prefix over the threads
+    const int chunk = (A + kPolThreads - 1) / kPolThreads, j0 = tid * chunk, j1 = min(j0 + chunk, A);
+    float local = 0.f;
+    for (int j = j0; j < j1; ++j) if (msk[j]) local += expf(row[j] - mx);
+    float incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    float base = 0.f, total = 0.f;
+    for (int w = 0; w < kPolThreads / 64; ++w) { if (w < wave) base += wave_tot[w]; total += wave_tot[w]; }
+    incl += base;
+    const unsigned long long h = sample_mix(a.seed ^ sample_mix((unsigned long long)b + 0x5851F42D4C957F2Dull));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);   // 24 bits: [0, 1)
+    const float target = u * total;
+    if (local > 0.f) {
+        if (incl > target) atomicMin(&s_first, tid);
+        atomicMax(&s_last, tid);
+    }
+    __syncthreads();
+    const int winner = s_first < kPolThreads ? s_first : s_last;          // (rounding can leave target >= total: last legal chunk)
+    if (tid == 0) {
+        if (nanf_ > 0.f) atomicOr(&a.flags[0], 1);
+        if (nlegal == 0.f) { atomicOr(&a.flags[1], 1); a.actions[b] = 0; a.logp[b] = 0.f; }
+        a.nlegal[b] = (int)nlegal;
+        if (a.values) {                                        // katago_ppo.py:536-541 / value_adapter.py:56-65
+            const float l0 = a.vlogits[b * 3], l1 = a.vlogits[b * 3 + 1], l2 = a.vlogits[b * 3 + 2];
+            const float m = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+            float v = (e0 - e2) / (e0 + e1 + e2);
+            if (a.score && a.alpha != 0.f) v = (1.f - a.alpha) * v + a.alpha * fminf(fmaxf(a.score[b], -1.f), 1.f);
+            a.values[b] = v;
+        }
+    }
+    if (tid == winner) {
+        float run = incl - local;
+        int pick = -1, last = -1;
+        for (int j = j0; j < j1; ++j) {
+            if (!msk[j]) continue;
+            last = j;
+            run += expf(row[j] - mx);
+            if (run > target) { pick = j; break; }
+        }
+        if (pick < 0) pick = last;
+        a.actions[b] = pick;
+        a.logp[b] = logf(expf(row[pick] - mx) * (1.f / s));
+    }
+}
+
 }  // namespace
 
 extern "C" int ka_policy_loss(const float* logits, const void* legal, const long long* actions, const float* old_lp,
@@ -338,6 +435,20 @@ extern "C" int ka_masked_softmax(const float* logits, const void* legal, float* 
     hipLaunchKernelGGL(masked_softmax_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), logits,
                        static_cast<const uint8_t*>(legal), probs, nlegal, flags, A, legal_words);
     return ka_check_launch("masked_softmax");
+}
+
+extern "C" int ka_policy_sample(const void* logits, int logits_bf16, const void* legal, int legal_words, long long seed,
+                                const float* vlogits, const float* score, float alpha, long long* actions, float* logp,
+                                float* values, int* nlegal, int* flags, int B, int A, void* stream) {
+    KA_REQUIRE(logits && legal && actions && logp && nlegal && flags && B > 0 && A > 0, "policy_sample: null tensor");
+    KA_REQUIRE(legal_words == 0 || legal_words == (A + 31) / 32, "policy_sample: packed mask rows must hold %d words", (A + 31) / 32);
+    KA_REQUIRE((values == nullptr) || vlogits, "policy_sample: values need the value logits");
+    const size_t lds = ((size_t)A * 4 + 15) / 16 * 16 + ((size_t)A + 15) / 16 * 16;
+    KA_REQUIRE(lds <= 64 * 1024, "policy_sample: action space %d too large for the LDS row", A);
+    SampleArgs a{logits, logits_bf16, static_cast<const uint8_t*>(legal), legal_words, (unsigned long long)seed, vlogits, score, alpha,
+                 actions, logp, values, nlegal, flags, A};
+    hipLaunchKernelGGL(policy_sample_kernel, dim3(B), dim3(kPolThreads), lds, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("policy_sample");
 }
 
 extern "C" int ka_policy_ce(const float* logits, const long long* targets, const long long* idx, float* dlogits,

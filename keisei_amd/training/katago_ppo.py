@@ -429,6 +429,13 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
                 end.record(stream)
                 self._timing_events["select_actions_forward_ms"].append((start, end))
             raw = out.policy_logits.reshape(obs.shape[0], -1)
+            if (raw.is_cuda and legal_masks.is_cuda and legal_masks.dtype == torch.bool
+                    and raw.dtype in (torch.float32, torch.bfloat16) and os.environ.get("KA_SELECT_TORCH_SAMPLER", "0") != "1"):
+                # the whole tail in ONE launch: masked softmax, one inverse-CDF draw per row, log-prob, the zero-legal guard and
+                # the scalar value (the masked-softmax + torch.multinomial chain below is ~25 launches)
+                sampled = self._sample_fused(raw, legal_masks, out, value_adapter)
+                if sampled is not None:
+                    return sampled
             if raw.is_cuda and legal_masks.is_cuda and legal_masks.dtype == torch.bool:
                 # one launch: masked softmax + legal-action counts (the tensor-op chain below is ~12 launches)
                 B_, A_ = raw.shape
@@ -460,6 +467,37 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
             return actions, log_probs, values
         finally:
             self._set_training(True)           # = self.forward_model.train()
+
+    def _sample_fused(self, raw: torch.Tensor, legal_masks: torch.Tensor, out, value_adapter):
+        """`ka_policy_sample` (loss.hip): returns (actions, log_probs, values), or None when the value adapter is not one the
+        kernel knows (then the caller takes the generic route)."""
+        from keisei_amd.training.value_adapter import MultiHeadValueAdapter
+
+        if value_adapter is None:
+            alpha = 0.0
+        elif type(value_adapter) is MultiHeadValueAdapter:
+            alpha = float(value_adapter.score_blend_alpha)
+        else:
+            return None
+        B_, A_ = raw.shape
+        dev = raw.device
+        logits = raw.contiguous()
+        masks_c = legal_masks.reshape(B_, A_).contiguous()
+        vl = out.value_logits.float().contiguous()
+        sc = out.score_lead.float().reshape(B_).contiguous() if alpha != 0.0 else None
+        actions = torch.empty(B_, dtype=torch.int64, device=dev)
+        log_probs = torch.empty(B_, device=dev)
+        values = torch.empty(B_, device=dev)
+        n_legal = torch.empty(B_, dtype=torch.int32, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())       # host generator: torch.manual_seed() fixes the rollout
+        _lib.call("ka_policy_sample", logits, int(logits.dtype == torch.bfloat16), masks_c, 0, seed, vl, sc, alpha, actions,
+                  log_probs, values, n_legal, flags, B_, A_, _lib.stream_ptr(dev))
+        if int(flags[1].item()):                               # katago_ppo.py:572-578 (the one synchronisation of the call)
+            empty = (n_legal == 0).nonzero(as_tuple=True)[0].tolist()
+            raise RuntimeError(f"Environments {empty} have zero legal actions — "
+                               f"all-False legal mask would produce NaN")
+        return actions, log_probs, values
 
     def _set_training(self, mode: bool) -> None:
         """forward_model.train(mode) without walking the module tree on every rollout step: nn.Module.train() recurses

@@ -265,3 +265,78 @@ def test_empty_step_raises_as_in_the_reference():
         with pytest.raises(RuntimeError, match="max"):
             fill(buf, [empty], where)
         assert buf.size == 1
+
+
+def _sample(logits, masks, seed, vl=None, score=None, alpha=0.0):
+    B, A_ = logits.shape
+    acts = torch.empty(B, dtype=torch.int64, device=DEV); lp = torch.empty(B, device=DEV)
+    vals = torch.empty(B, device=DEV) if vl is not None else None
+    nl = torch.empty(B, dtype=torch.int32, device=DEV); flags = torch.zeros(2, dtype=torch.int32, device=DEV)
+    _lib.call("ka_policy_sample", logits, int(logits.dtype == torch.bfloat16), masks, 0, seed, vl, score, alpha, acts, lp, vals,
+              nl, flags, B, A_, st())
+    return acts, lp, vals, nl, flags
+
+
+def test_fused_sampler_draws_from_the_masked_softmax():
+    """ka_policy_sample (the one-launch tail of select_actions, katago_ppo.py:567-612): legal actions only, log-probs of the
+    masked softmax, the categorical distribution itself (frequencies over 40 000 draws), determinism in the seed, values."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    B, A_ = 6, 53
+    logits = torch.randn(B, A_, device=DEV, generator=g) * 2
+    masks = torch.rand(B, A_, device=DEV, generator=g) < 0.6
+    masks[0] = False; masks[0, 17] = True                               # a single legal action
+    masks[1] = True                                                     # everything legal
+    masks[:, 5] |= ~masks.any(dim=1)
+    ref = torch.log_softmax(logits.masked_fill(~masks, float("-inf")), dim=-1)
+    counts = torch.zeros(B, A_, device=DEV)
+    draws = 40000
+    rows = torch.arange(B, device=DEV)
+    for seed in range(draws // 50):
+        big = logits.repeat(50, 1); bigm = masks.repeat(50, 1)          # the uniform depends on (seed, row): 300 distinct rows
+        acts, lp, _, nl, flags = _sample(big, bigm, seed)
+        assert bool(bigm[torch.arange(300, device=DEV), acts].all()) and flags.tolist() == [0, 0]
+        assert torch.allclose(lp, ref.repeat(50, 1)[torch.arange(300, device=DEV), acts], atol=1e-5, rtol=1e-5)
+        counts.index_put_((rows.repeat(50), acts), torch.ones(300, device=DEV), accumulate=True)
+    assert torch.equal(nl[:B], masks.sum(1).int())
+    p = ref.exp()
+    sigma = (p * (1 - p) / draws).sqrt()
+    assert bool(((counts / draws - p).abs() <= 4.5 * sigma + 1e-4).all()), ((counts / draws - p).abs() / (sigma + 1e-9)).max()
+    assert counts[0, 17] == draws
+    a1 = _sample(logits, masks, 12345)[0]; a2 = _sample(logits, masks, 12345)[0]
+    assert torch.equal(a1, a2)
+    assert any(not torch.equal(a1, _sample(logits, masks, s)[0]) for s in (1, 2, 3))
+    # bf16 logits are read as such: same draws as their fp32 widening
+    lb = logits.to(torch.bfloat16)
+    ab, lpb = _sample(lb, masks, 99)[:2]; af, lpf = _sample(lb.float(), masks, 99)[:2]
+    assert torch.equal(ab, af) and torch.equal(lpb, lpf)
+    # values: P(W) - P(L), blended with the clamped score
+    vl = torch.randn(B, 3, device=DEV, generator=g); sc = torch.randn(B, device=DEV, generator=g) * 2
+    pr = torch.softmax(vl, -1)
+    v0 = _sample(logits, masks, 1, vl)[2]
+    assert torch.allclose(v0, pr[:, 0] - pr[:, 2], atol=1e-6)
+    v1 = _sample(logits, masks, 1, vl, sc, 0.25)[2]
+    assert torch.allclose(v1, 0.75 * (pr[:, 0] - pr[:, 2]) + 0.25 * sc.clamp(-1, 1), atol=1e-6)
+    # a row without a legal action is flagged (select_actions raises on it)
+    dead = masks.clone(); dead[3] = False
+    assert _sample(logits, dead, 5)[4].tolist() == [0, 1]
+    # full-size rows through select_actions: legal, log-probs of the model's masked softmax, reproducible under manual_seed
+    torch.manual_seed(0)
+    model = build_model("se_resnet", dict(MP)).to(DEV)
+    algo = KataGoPPOAlgorithm(KataGoPPOParams(batch_size=64, use_amp=True), model)
+    adapter = MultiHeadValueAdapter(1.5, 0.02, 0.3)
+    obs = torch.randn(16, 50, 9, 9, device=DEV)
+    legal = torch.rand(16, A, device=DEV) < 0.01; legal[:, 0] = True
+    torch.manual_seed(7); r1 = algo.select_actions(obs, legal, adapter)
+    torch.manual_seed(7); r2 = algo.select_actions(obs, legal, adapter)
+    assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+    assert bool(legal[torch.arange(16, device=DEV), r1[0]].all())
+    model.eval()
+    with torch.no_grad():
+        o = model(obs)
+    model.train()
+    want = torch.log_softmax(o.policy_logits.reshape(16, -1).float().masked_fill(~legal, float("-inf")), -1)
+    assert torch.allclose(r1[1], want[torch.arange(16, device=DEV), r1[0]], atol=2e-3)
+    assert torch.allclose(r1[2], adapter.scalar_value_blended(o.value_logits.float(), o.score_lead.float()), atol=2e-3)
+    legal[9] = False
+    with pytest.raises(RuntimeError, match=r"Environments \[9\] have zero legal actions"):
+        algo.select_actions(obs, legal, adapter)

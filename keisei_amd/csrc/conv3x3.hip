@@ -744,6 +744,256 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- producer / consumer form (bf16, Cin = Cout = 256)
+// What keeps conv3x3_kernel and the streaming form at ~365 us is that staging (HBM latency + input transform + LDS
+// writes) and the MFMA phases of a workgroup are serial; two workgroups per CU overlap them only by chance.  Here the
+// overlap is explicit: a persistent 768-thread workgroup per CU, waves 0-7 multiply (the streaming form's loop, weights
+// through the register ring, continuous across units), waves 8-11 stage the NEXT unit -- one (board, 128-channel chunk)
+// -- straight into the other of two zero-haloed LDS images while the current one is multiplied.  One LDS-only barrier
+// per unit.  The input transforms (BatchNorm + ReLU + bias, or the two-tensor data-gradient input and its write-back)
+// live in the staging waves, whose registers are otherwise idle -- the two-tensor form spilled when the MFMA waves had
+// to carry it.  Same ConvArgs, weight packs and epilogue as conv3x3_kernel: bit-identical results.
+constexpr int kPcImg = kImgSquares1 * kStImgStride;                       // one 128-channel image: 181 squares x 288 B
+constexpr int kPcZero = 2 * kPcImg;                                       // the all-zero squares the padded rows read
+constexpr int kPcLds = kPcZero + kZeroSquares * kStImgStride;
+constexpr int kPcYStride = 256 * 2 + 16;                                  // the masked epilogue's y rows in LDS (16 B of padding: 2-way conflicts at most)
+constexpr int kPcLdsMasked = kPcLds + KA_BOARD * kPcYStride;
+
+template <bool TWO, bool MASKED>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue
+__global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int nwg = gridDim.x;
+    if ((int)blockIdx.x >= a.B) return;
+    for (int i = tid; i < kPcLds / 16; i += 768) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+    const int nboards = (a.B - (int)blockIdx.x + nwg - 1) / nwg, nunits = 2 * nboards;
+    if (!MASKED) a.ep_y = nullptr;                           // (compile-time: the other epilogue is not compiled in)
+    __syncthreads();
+
+    if (wave >= 8) {
+        // ---------------- staging waves: piece i = pt + 256 k of a unit = row i / 16, 16-byte piece i % 16 = pt % 16
+        const int pt = tid - 512, pc = pt & 15;
+        const bool has_aff = a.in_scale != nullptr;
+        auto stage = [&](int u) {
+            const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1, ch0 = kc * 128 + pc * 8;
+            char* img = smem + (u & 1) * kPcImg;
+            bf16x8 pv[6], pw[TWO ? 6 : 1];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = pt + 256 * k;
+                pv[k] = bf16x8{};
+                if (TWO) pw[TWO ? k : 0] = bf16x8{};
+                if (i < KA_BOARD * 16) {
+                    const size_t off = (((size_t)bb * KA_BOARD + (i >> 4)) * 256 + ch0) * 2;
+                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
+                    if (TWO) pw[TWO ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
+                }
+            }
+            float sc[8], sh[8], k3[8], pb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
+                k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
+                pb[e] = (!TWO && a.in_bias) ? a.in_bias[(size_t)bb * 256 + ch0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = pt + 256 * k;
+                if (i >= KA_BOARD * 16) continue;
+                bf16x8 v = pv[k];
+                if (TWO) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                    if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + (((size_t)bb * KA_BOARD + (i >> 4)) * 256 + ch0) * 2) = v;
+                } else if (has_aff || a.relu || a.in_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float f = (float)v[e];
+                        if (has_aff) f = fmaf(f, sc[e], sh[e]);
+                        if (a.relu) f = fmaxf(f, 0.f);
+                        if (a.in_bias) f += pb[e];
+                        v[e] = (__bf16)f;
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(img + lds_square(0, i >> 4) * kStImgStride + pc * 16) = v;
+            }
+        };
+        // masked form: the y rows the epilogue of board b compares against are brought into LDS during the board's second
+        // unit, and the MFMA waves run that epilogue right AFTER the barrier that ends it (no HBM latency, few registers)
+        auto load_y = [&](int bb) {
+            bf16x8 yv[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const int i = pt + 256 * k;                   // 81 rows x 32 pieces
+                yv[k] = bf16x8{};
+                if (i < KA_BOARD * 32)
+                    yv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) + ((size_t)bb * KA_BOARD * 32 + i) * 16));
+            }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const int i = pt + 256 * k;
+                if (i < KA_BOARD * 32) *reinterpret_cast<bf16x8*>(smem + kPcLds + (i >> 5) * kPcYStride + (i & 31) * 16) = yv[k];
+            }
+        };
+        stage(0);
+        KA_LDS_BARRIER();
+        for (int u = 0; u < nunits; ++u) {
+            if (u + 1 < nunits && !(a.tune_stagger & 2)) stage(u + 1);
+            if (MASKED && (u & 1)) load_y((int)blockIdx.x + (u >> 1) * nwg);
+            KA_LDS_BARRIER();
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves: 6 row tiles x 2 channel tiles each, the weight ring runs on across the units
+    if (a.tune_prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (a.tune_prio >= 2) __builtin_amdgcn_s_setprio(3);
+    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
+    // weight fragments of (chunk kc, step = tap * 4 + k-step); steps 36..38 are the first three of the NEXT unit's chunk
+    // (the ring runs on across units; after the last unit they re-read its own, unused)
+    auto wfrag = [&](int kc, int step, bf16x8 (&f)[2]) {
+        const int over = step >= 36 ? 1 : 0;
+        step -= 36 * over; kc ^= over;
+        const int tap = step >> 2, ks = kc * 4 + (step & 3);
+        const char* p = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
+        f[0] = *reinterpret_cast<const bf16x8*>(p);
+        f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+    };
+    auto toff_of = [&](int step) {
+        step = min(step, 35);
+        const int tap = step >> 2, ks = step & 3;
+        return ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kStImgStride + ks * 64;
+    };
+    bf16x8 w0[2], w1[2], w2[2], w3[2];
+    wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);
+    f32x4 acc[kMTW][2];
+    KA_LDS_BARRIER();                                        // unit 0 is staged
+    for (int u = 0; u < nunits; ++u) {
+        const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1;
+        if (!kc) {
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        int rowoff[kMTW];
+#pragma unroll
+        for (int mt = 0; mt < kMTW; ++mt) {
+            const int p = mt * 16 + r;
+            rowoff[mt] = (p < KA_BOARD ? (u & 1) * kPcImg + lds_square(0, p) * kStImgStride : kPcZero + (kPW + 1) * kStImgStride) + q * 16;
+        }
+        auto mm = [&](const bf16x8 (&wf)[2], const bf16x8 (&ac)[kMTW], bf16x8 (&an)[kMTW], int next_step) {
+            const int toff = toff_of(next_step);
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                an[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        };
+        bf16x8 fa[kMTW], fb[kMTW];
+        {
+            const int toff = toff_of(0);
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s0 = tap * 4;
+            // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
+            const bool ahead = !(MASKED && kc && tap == 8);
+            wfrag(kc, s0 + 3, w3); __builtin_amdgcn_sched_barrier(0); mm(w0, fa, fb, s0 + 1); __builtin_amdgcn_sched_barrier(0);
+            if (ahead) wfrag(kc, s0 + 4, w0);
+            __builtin_amdgcn_sched_barrier(0); mm(w1, fb, fa, s0 + 2); __builtin_amdgcn_sched_barrier(0);
+            if (ahead) wfrag(kc, s0 + 5, w1);
+            __builtin_amdgcn_sched_barrier(0); mm(w2, fa, fb, s0 + 3); __builtin_amdgcn_sched_barrier(0);
+            if (ahead) wfrag(kc, s0 + 6, w2);
+            __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
+        KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete
+        if (MASKED && kc) {
+            // da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums (conv_epilogue's masked branch, term for term), y from LDS
+            const int cb0 = chan_of(wave * 2, 4 * q, 16);
+            int cbl = cb0;                                   // (opaque copy: the coefficient loads below are loop-invariant, and hoisted
+            asm volatile("" : "+v"(cbl));                    //  above the MFMA loop their 32 registers spill it)
+            if (a.bsum) {                                    // per-board sums of the raw accumulators (conv_epilogue, same order)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float s0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < kMTW; ++mt) {
+                        const bool in = mt * 16 + r < KA_BOARD;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s0[i] += in ? acc[mt][j][i] : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
+                    if (r == 0) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb0 + 4 * j) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+                }
+            }
+            float esc[8], esh[8], emu[8], eis[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                esc[e] = a.ep_scale[cbl + e]; esh[e] = a.ep_shift[cbl + e]; emu[e] = a.ep_mean[cbl + e]; eis[e] = a.ep_invstd[cbl + e];
+                t1[e] = 0.f; t2[e] = 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt) {
+                const int p = mt * 16 + r;
+                const bool in = p < KA_BOARD;
+                bf16x8 yv = bf16x8{};
+                if (in) yv = *reinterpret_cast<const bf16x8*>(smem + kPcLds + p * kPcYStride + cb0 * 2);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = (float)yv[e];
+                    const __bf16 db = (__bf16)acc[mt][e >> 2][e & 3];
+                    const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                    t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
+                    o[e] = (__bf16)d;
+                }
+                if (in) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb0) * 2) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
+            if (r == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb0 + e) = f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
+                    *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb0 + e) = f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
+                }
+            }
+            wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);
+        }
+    }
+}
+
+static int launch_conv_pc(ConvArgs a, hipStream_t st) {
+    static std::atomic<unsigned long long> done0{0}, done1{0};
+    a.tune_stagger = 0; a.tune_prio = 0;                       // diagnostics: KA_CONV_P_ABL 1 no epilogue, 2 no staging after the first unit
+    if (const char* e = getenv("KA_CONV_P_ABL")) a.tune_stagger = atoi(e);
+    if (const char* e = getenv("KA_CONV_P_PRIO")) a.tune_prio = atoi(e);
+    int grid = 256;
+    if (const char* e = getenv("KA_CONV_P_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
+    if (grid > a.B) grid = a.B;
+    static std::atomic<unsigned long long> done2{0};
+    if (a.in2 && a.ep_y) {
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, true>), done2, "conv3x3 (pc, masked)")) return rc;
+        hipLaunchKernelGGL((conv3x3_pc_kernel<true, true>), dim3(grid), dim3(768), kPcLdsMasked, st, a);
+    } else if (a.in2) {
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, false>), done1, "conv3x3 (pc, two-tensor)")) return rc;
+        hipLaunchKernelGGL((conv3x3_pc_kernel<true, false>), dim3(grid), dim3(768), kPcLds, st, a);
+    } else {
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false>), done0, "conv3x3 (pc)")) return rc;
+        hipLaunchKernelGGL((conv3x3_pc_kernel<false, false>), dim3(grid), dim3(768), kPcLds, st, a);
+    }
+    return ka_check_launch("conv3x3 (pc)");
+}
+
 static int launch_conv_stream(ConvArgs a, hipStream_t st) {
     a.tune_stagger = 0;
     if (const char* e = getenv("KA_CONV_T_ABL")) a.tune_stagger = atoi(e);      // diagnostics only
@@ -767,6 +1017,13 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         // the streaming form: tower shapes at training batch sizes (opt-in while it is being measured: KA_CONV_T=1)
         const char* e = getenv("KA_CONV_T");
         if (e && atoi(e) != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 && !a.in2) return launch_conv_stream(a, st);
+        // the producer / consumer form.  KA_CONV_P: 0 off; 1 (default) the forward forms -- 8 % / 4 % faster alone, 1 % in
+        // the step; 2: + the two-tensor data-gradient form with the plain epilogue (no faster alone, slower in the step: it
+        // owns every register file, so the weight-gradient stream no longer runs beside it); 3: + the masked epilogue (spills)
+        const char* ep = getenv("KA_CONV_P");
+        const int pv = ep ? atoi(ep) : 1;
+        if (pv != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 &&
+            (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) return launch_conv_pc(a, st);
     }
     // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
     int wm = 1;

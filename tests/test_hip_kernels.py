@@ -775,3 +775,42 @@ def test_streaming_conv_is_bit_identical_to_the_default_kernel(monkeypatch, tran
     monkeypatch.setenv("KA_CONV_T", "1")
     out1, bsum1, sq1 = run_conv(xin, wp, B, C, C, dt, *args)
     assert torch.equal(out0, out1) and torch.equal(bsum0, bsum1) and torch.equal(sq0, sq1)
+
+
+@pytest.mark.parametrize("B", [515, 1024])
+def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(monkeypatch, B):
+    """conv3x3_pc_kernel (staging waves + MFMA waves, the default for the forward forms at training batch sizes): the same
+    summation order, weight packs and epilogues as conv3x3_kernel -- all four launch kinds agree bit for bit, including a
+    board count that does not divide the 256 persistent workgroups."""
+    C = 256
+    g = torch.Generator(device=DEV).manual_seed(B)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, x2, yprev = (rnd(B, 81, C).to(torch.bfloat16) for _ in range(3))
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, _lib.stream_ptr())
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    gb = rnd(B, C) * 0.1
+    k3 = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+
+    def run(kind):
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        out, dyo = nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16)
+        bsum, sq, e1, e2 = nan(B, C), nan(B, C), nan(B, C), nan(B, C)
+        st = _lib.stream_ptr()
+        if kind == 0: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st)
+        if kind == 1: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, gb, 1, bsum, sq, B, C, C, 1, st)
+        if kind == 2: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st)
+        if kind == 3: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st)
+        torch.cuda.synchronize()
+        return out, dyo, bsum, sq, e1, e2
+
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    for kind in range(4):
+        monkeypatch.setenv("KA_CONV_P", "0")
+        ref = run(kind)
+        monkeypatch.setenv("KA_CONV_P", "3")                  # every form through the producer / consumer kernel
+        got = run(kind)
+        assert all(same(a.float(), b.float()) for a, b in zip(ref, got)), kind
+        assert not ref[0].float().isnan().any()

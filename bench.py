@@ -490,16 +490,21 @@ def main() -> None:
             if pmc is not None and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
                 prof = json.loads(pmc.read_text())
                 if prof.get("kernel_source_sha16") == kernel_source_id():
+                    # the tower's launches: conv3x3_kernel<bf16_t, 4, 1> (data gradients) and conv3x3_pc_kernel (forward) --
+                    # launch-weighted mean, like the timed launches
                     recs = [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
-                    rec = max(recs, key=lambda v: v["launches"]) if recs else None      # the tower instantiation
-                    traffic = rec["hbm_bytes_per_launch"] if rec else None
+                    recs = [max(recs, key=lambda v: v["launches"])] if recs else []
+                    recs += [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_pc_kernel")]
+                    n = sum(v["launches"] for v in recs)
+                    traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in recs) / n) if n else None
                     traffic_note = f"{pmc.name} (same kernel sources)"
                 else:
                     traffic_note = (f"{pmc.name} was collected on kernel sources {prof.get('kernel_source_sha16')}, this build is "
                                     f"{kernel_source_id()}: not reported")
             ev_ms_step = 1e3 * res["events_elapsed"] / res["events_steps"]
-            roof = {"bound": "mfma", "kernel": "conv3x3_kernel (implicit-GEMM 3x3 conv; forward + data-gradient launches, the "
-                                               "latter with fused BatchNorm-backward passes and concurrent with wgrad on a 2nd stream)",
+            roof = {"bound": "mfma", "kernel": "conv3x3_pc_kernel / conv3x3_kernel (implicit-GEMM 3x3 conv; forward launches on the "
+                                               "producer-consumer form, data-gradient launches on conv3x3_kernel with fused "
+                                               "BatchNorm-backward passes and concurrent with wgrad on a 2nd stream)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_note, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
                     "flop_per_launch": conv_flop,

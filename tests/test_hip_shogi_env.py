@@ -387,3 +387,17 @@ def test_full_size_invariants_on_the_device():
             mate = r.step_metadata.termination_reason == S.R_CHECKMATE
             assert bool((r.rewards[mate] == 1).all())
     assert dev.episodes_completed == ends and ends > n
+
+
+def test_device_env_reproduces_the_committed_playout():
+    """The same frozen playout (tests/golden/g10_shogi_playout.npz) through the HIP kernels: digest for digest."""
+    from tests.test_shogi_oracle import _replay_golden
+
+    def step(env, acts):
+        r = env.step(acts)
+        d = {k: getattr(r, k) for k in FIELDS}
+        d.update({k: getattr(r.step_metadata, k) for k in META})
+        return d
+
+    env, stats = _replay_golden(lambda n, mp: _env(n, mp), step)
+    assert [env.episodes_completed, env.episodes_drawn, env.episodes_truncated] == stats[:3]

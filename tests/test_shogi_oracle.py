@@ -358,3 +358,29 @@ def test_host_action_mappers_agree_with_the_oracle_and_the_env_needs_a_gpu():
     if not torch.cuda.is_available():                       # the product path fails loudly: there is no CPU env behind this class
         with pytest.raises(_lib.KeiseiHipError):
             VecEnv(num_envs=2, observation_mode="katago", action_mode="spatial")
+
+
+def _replay_golden(make_env, step_fn):
+    import hashlib
+    from pathlib import Path
+
+    g = np.load(Path(__file__).parent / "golden" / "g10_shogi_playout.npz")
+    keys = ("observations", "legal_masks", "rewards", "terminated", "truncated", "terminal_observations", "current_players",
+            "captured_piece", "termination_reason", "ply_count", "material_balance")
+    env = make_env(int(g["n"]), int(g["max_ply"]))
+    obs, mask = env.reset() if not hasattr(env, "num_envs") else (lambda r: (r.observations, r.legal_masks))(env.reset())
+    assert hashlib.sha256(obs.tobytes() + mask.tobytes()).digest() == g["reset_digest"].tobytes()
+    for t, acts in enumerate(g["actions"]):
+        out = step_fn(env, acts)
+        h = hashlib.sha256()
+        for k in keys:
+            h.update(np.ascontiguousarray(out[k]).tobytes())
+        assert h.digest() == g["digests"][t].tobytes(), f"step {t}"
+    return env, g["stats"].tolist()
+
+
+def test_oracle_reproduces_the_committed_playout():
+    """tests/golden/g10_shogi_playout.npz (oracle/make_shogi_golden.py): the oracle's behaviour, frozen."""
+    env, stats = _replay_golden(lambda n, mp: OracleVecEnv(n, mp), lambda e, a: e.step(a))
+    st = env.stats()
+    assert [st["episodes_completed"], st["episodes_drawn"], st["episodes_truncated"], st["total_episode_ply"]] == stats

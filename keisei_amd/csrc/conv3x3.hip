@@ -917,54 +917,67 @@ __global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
         KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete
         if (MASKED && kc) {
             // da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums (conv_epilogue's masked branch, term for term), y from LDS
-            const int cb0 = chan_of(wave * 2, 4 * q, 16);
-            int cbl = cb0;                                   // (opaque copy: the coefficient loads below are loop-invariant, and hoisted
-            asm volatile("" : "+v"(cbl));                    //  above the MFMA loop their 32 registers spill it)
+            // (opaque copies of the lane coordinates: everything below is invariant across the boards, and hoisted above the
+            //  MFMA loop its addresses and coefficients spill it)
+            int rl = r, ql = q;
+            asm volatile("" : "+v"(rl), "+v"(ql));
+            const int cb0 = chan_of(wave * 2, 4 * ql, 16);
+            const int cbl = cb0;
             if (a.bsum) {                                    // per-board sums of the raw accumulators (conv_epilogue, same order)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float s0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int mt = 0; mt < kMTW; ++mt) {
-                        const bool in = mt * 16 + r < KA_BOARD;
+                        const bool in = mt * 16 + rl < KA_BOARD;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) s0[i] += in ? acc[mt][j][i] : 0.f;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
-                    if (r == 0) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb0 + 4 * j) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+                    if (rl == 0) *reinterpret_cast<f32x4*>(a.bsum + (size_t)bb * a.Cout + cb0 + 4 * j) = f32x4{s0[0], s0[1], s0[2], s0[3]};
                 }
             }
-            float esc[8], esh[8], emu[8], eis[8], t1[8], t2[8];
+            // two passes of four channels (one MFMA tile each): half the coefficient / sum registers at a time; the first
+            // pass's bf16 results wait in 12 registers so that the rows still leave as 16-byte pieces
+            bf16x4 o0[kMTW];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                esc[e] = a.ep_scale[cbl + e]; esh[e] = a.ep_shift[cbl + e]; emu[e] = a.ep_mean[cbl + e]; eis[e] = a.ep_invstd[cbl + e];
-                t1[e] = 0.f; t2[e] = 0.f;
-            }
+            for (int j = 0; j < 2; ++j) {
+                float esc[4], esh[4], emu[4], eis[4], t1[4], t2[4];
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
-                const int p = mt * 16 + r;
-                const bool in = p < KA_BOARD;
-                bf16x8 yv = bf16x8{};
-                if (in) yv = *reinterpret_cast<const bf16x8*>(smem + kPcLds + p * kPcYStride + cb0 * 2);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float y = (float)yv[e];
-                    const __bf16 db = (__bf16)acc[mt][e >> 2][e & 3];
-                    const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
-                    t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
-                    o[e] = (__bf16)d;
+                for (int e = 0; e < 4; ++e) {
+                    esc[e] = a.ep_scale[cbl + 4 * j + e]; esh[e] = a.ep_shift[cbl + 4 * j + e];
+                    emu[e] = a.ep_mean[cbl + 4 * j + e]; eis[e] = a.ep_invstd[cbl + 4 * j + e];
+                    t1[e] = 0.f; t2[e] = 0.f;
                 }
-                if (in) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb0) * 2) = o;
-            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
-            if (r == 0) {
+                for (int mt = 0; mt < kMTW; ++mt) {
+                    const int p = mt * 16 + rl;
+                    const bool in = p < KA_BOARD;
+                    bf16x4 yv = bf16x4{};
+                    if (in) yv = *reinterpret_cast<const bf16x4*>(smem + kPcLds + p * kPcYStride + (cb0 + 4 * j) * 2);
+                    bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 8; e += 4) {
-                    *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb0 + e) = f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
-                    *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb0 + e) = f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (float)yv[e];
+                        const __bf16 db = (__bf16)acc[mt][j][e];
+                        const float d = (in && y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                        t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
+                        o[e] = (__bf16)d;
+                    }
+                    if (j == 0) o0[mt] = o;
+                    else if (in) {
+                        bf16x8 o8;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o8[e] = o0[mt][e]; o8[4 + e] = o[e]; }
+                        *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + ((size_t)(bb * KA_BOARD + p) * a.Cout + cb0) * 2) = o8;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
+                if (rl == 0) {
+                    *reinterpret_cast<f32x4*>(a.ep_s1 + (size_t)bb * a.Cout + cb0 + 4 * j) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+                    *reinterpret_cast<f32x4*>(a.ep_s2 + (size_t)bb * a.Cout + cb0 + 4 * j) = f32x4{t2[0], t2[1], t2[2], t2[3]};
                 }
             }
             wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);

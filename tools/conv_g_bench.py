@@ -7,6 +7,7 @@ import torch
 from keisei_amd import _lib
 dev = 'cuda'
 VAR = os.environ.get('CG_VAR', 'KA_CONV_G')
+ON = os.environ.get('CG_ON', '1')            # the switch's "on" value (KA_CONV_P=3 routes every launch kind)
 C = 256
 dt = torch.bfloat16
 def timeit(fn, n=20):
@@ -38,14 +39,14 @@ for B in sizes:
     for kind in (int(k) for k in os.environ.get('CG_KINDS', '0,1').split(',')):
         res = {}
         for flag in ("0", "1"):
-            os.environ[VAR] = flag
+            os.environ[VAR] = ON if flag == "1" else "0"
             outs = [torch.full((B, 81, C), float("nan"), device=dev).to(dt), torch.full((B, C), float("nan"), device=dev), torch.full((B, C), float("nan"), device=dev),
                     torch.full((B, 81, C), float("nan"), device=dev).to(dt), torch.full((B, C), float("nan"), device=dev), torch.full((B, C), float("nan"), device=dev)]
             run(kind, outs); torch.cuda.synchronize()
             res[flag] = [outs, 1e9]
         for rnd in range(3):                      # alternating rounds in one process, best of three
             for flag in ("0", "1"):
-                os.environ[VAR] = flag
+                os.environ[VAR] = ON if flag == "1" else "0"
                 res[flag][1] = min(res[flag][1], timeit(lambda: run(kind, res[flag][0])))
         o0, t0 = res["0"]; o1, t1 = res["1"]
         def rel(a, b):

@@ -24,7 +24,7 @@ R_PROGRESS, R_CHECKMATE, R_REPETITION, R_PERPETUAL, R_IMPASSE, R_MAXMOVES = rang
 def build(force: bool = False) -> Path:
     if force or not LIB.exists() or LIB.stat().st_mtime < SRC.stat().st_mtime:
         LIB.parent.mkdir(exist_ok=True)
-        subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-shared", "-fPIC", "-o", str(LIB), str(SRC)], check=True)
+        subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-fopenmp", "-shared", "-fPIC", "-o", str(LIB), str(SRC)], check=True)
     return LIB
 
 

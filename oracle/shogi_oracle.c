@@ -528,6 +528,8 @@ int so_step(void* h, const int64_t* actions, float* obs, uint8_t* mask, float* r
         if (actions[i] < 0 || decode_action((int)actions[i], e->g[i].pos.side, &m, e->amode) != 0) return -(1 + i);
         if (actions[i] >= AS || !e->mask[(size_t)i * AS + actions[i]]) return -(1 + i);
     }
+    /* games are independent (the reference steps them with rayon, vec_env.rs:541-545); OMP_NUM_THREADS sets the cores used */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < e->n; ++i) {
         Game* g = &e->g[i];
         Mv m; decode_action((int)actions[i], g->pos.side, &m, e->amode);
@@ -542,9 +544,18 @@ int so_step(void* h, const int64_t* actions, float* obs, uint8_t* mask, float* r
         material[i] = material_balance(&g->pos, last_mover);
         captured[i] = cap ? (uint8_t)(TYPE(cap) - 1) : 255;
         if (term || trunc) {
-            e->stats[0]++; e->stats[3] += g->ply;
-            if (g->result == R_REPETITION || (g->result == R_IMPASSE && g->winner < 0)) e->stats[1]++;
-            if (g->result == R_MAXMOVES) e->stats[2]++;
+#pragma omp atomic
+            e->stats[0]++;
+#pragma omp atomic
+            e->stats[3] += g->ply;
+            if (g->result == R_REPETITION || (g->result == R_IMPASSE && g->winner < 0)) {
+#pragma omp atomic
+                e->stats[1]++;
+            }
+            if (g->result == R_MAXMOVES) {
+#pragma omp atomic
+                e->stats[2]++;
+            }
             write_obs(g, g->pos.side, terminal_obs + (size_t)i * OL, e->omode);
             game_reset(g);
         }

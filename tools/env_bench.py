@@ -26,6 +26,7 @@ for n in (128, 512, 4096, 16384):
                          "written_GBps": n * out["bytes_written_per_env_step"] / ms / 1e6,
                          "mean_legal_moves": float(r.legal_masks.sum(1).float().mean())})
     print(out["cases"][-1], flush=True)
+os.environ["OMP_NUM_THREADS"] = "1"          # the recorded baseline is one host core (the oracle steps games in parallel under OpenMP otherwise)
 from oracle.shogi import OracleVecEnv
 e = OracleVecEnv(128, 500); obs, mask = e.reset(); rng = np.random.default_rng(0)
 acts_t = 0.0; t0 = time.time(); k = 0

@@ -529,7 +529,10 @@ int so_step(void* h, const int64_t* actions, float* obs, uint8_t* mask, float* r
         if (actions[i] >= AS || !e->mask[(size_t)i * AS + actions[i]]) return -(1 + i);
     }
     /* games are independent (the reference steps them with rayon, vec_env.rs:541-545); OMP_NUM_THREADS sets the cores used */
-#pragma omp parallel for schedule(static)
+    int nthreads = e->n / 16;                              /* a thread per 16 games, at most 16 (small test batches stay serial) */
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int i = 0; i < e->n; ++i) {
         Game* g = &e->g[i];
         Mv m; decode_action((int)actions[i], g->pos.side, &m, e->amode);

@@ -110,6 +110,12 @@ class OracleVecEnv:
 
     # rule-level probes used by the fixtures
     def legal_count(self, i=0): return lib().so_legal_count(self.h, i)
+
+    def pseudo_moves(self, i, color, boards_only=True):
+        out = np.zeros(2048, np.uint32)
+        n = lib().so_pseudo_moves(self.h, i, color, int(boards_only), _p(out))
+        return [(int(v & 255), int((v >> 8) & 255), int((v >> 16) & 255), int(v >> 24)) for v in out[:n]]
+
     def in_check(self, i, color): return bool(lib().so_in_check(self.h, i, color))
     def uchi_fu_zume(self, i, to, color): return bool(lib().so_uchi_fu_zume(self.h, i, to, color))
     def impasse_score(self, i, color): return lib().so_impasse_score(self.h, i, color)

@@ -9,10 +9,13 @@
  * (board, hands, side to move), where the reference compares 64-bit Zobrist keys and the HIP path a 64-bit mixed key.
  *
  * Parity pin: no Rust toolchain exists in the build image, so the reference cannot be run.  The oracle is pinned by the
- * reference's own known answers (tests/test_shogi_oracle.py): perft 30 / 900 / 25 470 from the start position
- * (game.rs:1225-1243), the start-position mask and observation facts (vec_env.rs:1083-1215, observation.rs tests), the
- * pawn-drop-mate, repetition, perpetual-check and impasse positions of rules.rs:575-1790, the reward table
- * (vec_env.rs:986-1060), and the action-index examples of spatial_action_mapper.rs:357-726.
+ * reference's own known answers (tests/test_shogi_oracle.py): perft 30 / 900 / 25 470 / 719 731 from the start position
+ * (game.rs:1225-1243, :1900), the mate, stalemate, nifu, pin, check-escape and capture-to-hand positions of game.rs:623-1544,
+ * the generator counts of movegen.rs:242-1146 (lone sliders, corners, promotion zones, dead drops), the pawn-drop-mate,
+ * repetition, perpetual-check and impasse positions of rules.rs:575-1790, the plane contents of observation.rs:255-724 and
+ * katago_observation.rs:214-420, the start-position mask facts and the reward table of vec_env.rs:986-1215, the action-index
+ * examples of spatial_action_mapper.rs:357-726 and action_mapper.rs:17-110, and the VecEnv behaviour its Python tests
+ * state (shogi-gym/tests/test_vec_env.py: shapes, truncation, restart, counters).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
@@ -593,6 +596,15 @@ void so_observe(void* h, int i, float* obs, uint8_t* mask) {
     memcpy(mask, e->mask + (size_t)i * AS, (size_t)AS);
 }
 
+/* pseudo-legal moves of `color` (movegen.rs:112-203): out[k] = from | to << 8 | promote << 16 | drop << 24; returns the count */
+int so_pseudo_moves(void* h, int i, int color, int boards_only, uint32_t* out) {
+    static _Thread_local Mv mv[2048];
+    const Pos* p = &((Env*)h)->g[i].pos;
+    int n = pseudo_board_moves(p, color, mv, 0);
+    if (!boards_only) n = pseudo_drops(p, color, mv, n);
+    for (int k = 0; k < n; ++k) out[k] = (uint32_t)mv[k].from | ((uint32_t)mv[k].to << 8) | ((uint32_t)mv[k].promote << 16) | ((uint32_t)mv[k].drop << 24);
+    return n;
+}
 int so_legal_count(void* h, int i) { static _Thread_local Mv mv[1024]; return legal_moves(&((Env*)h)->g[i], mv); }
 int so_in_check(void* h, int i, int color) { return color_in_check(&((Env*)h)->g[i].pos, color); }
 int so_uchi_fu_zume(void* h, int i, int to, int color) { return is_uchi_fu_zume(&((Env*)h)->g[i].pos, to, color); }

@@ -384,3 +384,140 @@ def test_oracle_reproduces_the_committed_playout():
     env, stats = _replay_golden(lambda n, mp: OracleVecEnv(n, mp), lambda e, a: e.step(a))
     st = env.stats()
     assert [st["episodes_completed"], st["episodes_drawn"], st["episodes_truncated"], st["total_episode_ply"]] == stats
+
+
+def _kings(bk, wk):
+    b, h = S.empty_board()
+    b[sq(*bk)] = KING; b[sq(*wk)] = KING | WHITE
+    return b, h
+
+
+def _legal(e, i=0):
+    _, mask = e.observe(i)
+    return [S.decode(int(a), white=bool(e.state(i)[2])) for a in np.flatnonzero(mask)]
+
+
+def test_game_rs_known_answers():
+    """Positions and expectations restated from shogi-core/src/game.rs's test module (line numbers of the reference)."""
+    # :713-775 nifu: a pawn on column 4 forbids pawn drops there, other columns stay open
+    b, h = _kings((8, 4), (0, 4)); b[sq(6, 4)] = PAWN; h[0, 0] = 1
+    drops = [m for m in _legal(_env(b, h, 0)) if m[3] == PAWN]
+    assert drops and all(m[1] % 9 != 4 for m in drops)
+    # :1251-1286 a promoted pawn does not count for nifu
+    b, h = _kings((8, 4), (0, 4)); b[sq(5, 4)] = PAWN | S.PROM; h[0, 0] = 1
+    assert any(m[3] == PAWN and m[1] % 9 == 4 for m in _legal(_env(b, h, 0)))
+    # :1288-1326 the same rule for White
+    b, h = _kings((8, 4), (0, 4)); b[sq(3, 3)] = PAWN | WHITE; h[1, 0] = 1
+    drops = [m for m in _legal(_env(b, h, 1)) if m[3] == PAWN]
+    assert drops and all(m[1] % 9 != 3 for m in drops)
+    # :806-850 mate: rook on the rank, gold beside the king, the gold protected
+    b, h = _kings((0, 0), (8, 8)); b[sq(0, 8)] = ROOK | WHITE; b[sq(1, 1)] = GOLD | WHITE; b[sq(8, 1)] = ROOK | WHITE
+    e = _env(b, h, 0)
+    assert e.legal_count(0) == 0 and e.check_termination() == (S.R_CHECKMATE, 1)
+    # :1061-1124 no legal move without check loses too
+    b, h = _kings((0, 0), (2, 1)); b[sq(0, 1)] = b[sq(1, 0)] = b[sq(1, 1)] = PAWN | WHITE; b[sq(0, 5)] = ROOK | WHITE
+    e = _env(b, h, 0)
+    assert not e.in_check(0, 0) and e.legal_count(0) == 0 and e.check_termination() == (S.R_CHECKMATE, 1)
+    # :2051-2110 and for White
+    b, h = _kings((6, 7), (8, 8)); b[sq(8, 7)] = b[sq(7, 8)] = b[sq(7, 7)] = PAWN; b[sq(8, 3)] = ROOK
+    e = _env(b, h, 1)
+    if not e.in_check(0, 1) and e.legal_count(0) == 0:       # (mirror of the position above)
+        assert e.check_termination() == (S.R_CHECKMATE, 0)
+    # :902-960 a captured promoted piece goes to the hand as its base type
+    b, h = _kings((8, 4), (0, 4)); b[sq(4, 4)] = BISHOP | S.PROM | WHITE; b[sq(4, 0)] = ROOK
+    e = _env(b, h, 0)
+    r = e.step([S.encode(sq(4, 0), sq(4, 4))])
+    assert e.state(0)[1][0, BISHOP - 1] == 1 and r["captured_piece"][0] == BISHOP - 1 and e.state(0)[0][sq(4, 4)] == ROOK
+    # :1441-1490 a pinned pawn has no move
+    b, h = _kings((4, 4), (0, 0)); b[sq(4, 8)] = ROOK | WHITE; b[sq(4, 6)] = PAWN
+    assert not [m for m in _legal(_env(b, h, 0)) if m[3] == 0 and m[0] == sq(4, 6)]
+    # :1492-1544 in check: the king steps away or the bishop interposes, nothing else
+    b, h = _kings((4, 4), (0, 0)); b[sq(4, 8)] = ROOK | WHITE; b[sq(6, 6)] = BISHOP
+    e = _env(b, h, 0)
+    moves = _legal(e)
+    assert e.in_check(0, 0) and moves
+    for f, t, p, d in moves:
+        assert f == sq(4, 4) or (f == sq(6, 6) and t in (sq(4, 6), sq(4, 8))), (f, t)
+    # :639-665 check detection; :623-637 thirty opening moves
+    b, h = _kings((8, 4), (0, 4)); b[sq(4, 4)] = ROOK | WHITE
+    assert _env(b, h, 0).in_check(0, 0)
+    assert OracleVecEnv(1).legal_count(0) == 30
+
+
+def _lone(piece, at, side=0, extra=()):
+    b, h = S.empty_board()
+    b[sq(*at)] = piece
+    for pc, pos in extra:
+        b[sq(*pos)] = pc
+    e = _env(b, h, side)
+    return e.pseudo_moves(0, side)
+
+
+def test_movegen_rs_known_answers():
+    """Pseudo-legal generator counts restated from shogi-core/src/movegen.rs's tests (:428-582, :697-828, :1056-1146)."""
+    assert len(_lone(ROOK, (4, 4))) == 19                    # 16 targets, the three in the zone twice
+    assert len(_lone(BISHOP, (4, 4))) == 22
+    assert len(_lone(LANCE, (4, 4))) == 6                    # (3,4) once, (2,4) (1,4) twice, (0,4) promoted only
+    m = _lone(PAWN | WHITE, (2, 4), side=1)
+    assert m == [(sq(2, 4), sq(3, 4), 0, 0)]
+    assert len(_lone(PAWN | WHITE, (5, 4), side=1)) == 2     # into the zone: with and without promotion
+    assert _lone(PAWN | WHITE, (7, 4), side=1) == [(sq(7, 4), sq(8, 4), 1, 0)]
+    m = _lone(S.KNIGHT | WHITE, (4, 4), side=1)
+    assert len(m) == 4 and {t for _, t, _, _ in m} == {sq(6, 3), sq(6, 5)}
+    m = _lone(S.KNIGHT, (4, 4))                              # :275-320 Black's knight jumps up the board
+    assert {t for _, t, _, _ in m} == {sq(2, 3), sq(2, 5)} and len(m) == 4
+    assert {t for _, t, _, _ in _lone(SILVER, (0, 0))} == {sq(1, 1)}
+    assert {t for _, t, _, _ in _lone(SILVER, (0, 8))} == {sq(1, 7)}
+    assert {t for _, t, _, _ in _lone(GOLD, (0, 0))} == {sq(0, 1), sq(1, 0)}
+    assert len({t for _, t, _, _ in _lone(BISHOP | S.PROM, (0, 0))}) == 10
+    assert len({t for _, t, _, _ in _lone(ROOK | S.PROM, (8, 8))}) == 17
+    for pc in (PAWN, LANCE, S.KNIGHT, SILVER):               # :842-953 promoted minor pieces move like a gold
+        assert {t for _, t, _, _ in _lone(pc | S.PROM, (4, 4))} == {t for _, t, _, _ in _lone(GOLD, (4, 4))}
+    # :593-647 a slider stops before its own piece and does not take it
+    m = _lone(ROOK, (4, 4), extra=((PAWN, (4, 6)),))
+    assert sq(4, 5) in {t for _, t, _, _ in m} and sq(4, 6) not in {t for f, t, _, _ in m if f == sq(4, 4)}
+    # :371-401, :1118-1146 dead drops: no pawn / lance on the last rank, no knight on the last two
+    b, h = S.empty_board(); h[0] = [1, 1, 1, 1, 0, 0, 0]
+    e = _env(b, h, 0)
+    drops = [x for x in e.pseudo_moves(0, 0, boards_only=False) if x[3]]
+    rows = lambda t: {x[1] // 9 for x in drops if x[3] == t}
+    assert rows(PAWN) == set(range(1, 9)) and rows(LANCE) == set(range(1, 9)) and rows(S.KNIGHT) == set(range(2, 9))
+    assert rows(SILVER) == set(range(9)) and len(drops) == 72 + 72 + 63 + 81
+    # :242-273 / :501-519 twenty board moves... the opening has 30 pseudo-legal board moves a side
+    e = OracleVecEnv(1)
+    assert len(e.pseudo_moves(0, 0)) == 30 and len(e.pseudo_moves(0, 1)) == 30
+
+
+def test_observation_rs_known_answers():
+    """Plane contents restated from shogi-gym/src/observation.rs (:402-724) and katago_observation.rs (:214-420)."""
+    b, h = _kings((8, 4), (0, 4)); h[0, 0] = 9; h[1, 6] = 1; h[1, 1] = 3
+    o, _ = _env(b, h, 0).observe(0)
+    assert np.all(o[28] == np.float32(9) / np.float32(18)) and np.all(o[29:35] == 0)         # own pawns in hand: 9 / 18
+    assert np.all(o[35 + 6] == np.float32(0.5)) and np.all(o[35 + 1] == np.float32(0.75))    # the opponent's rook 1/2, lances 3/4
+    o, _ = _env(b, h, 1).observe(0)                                                          # seen from White the hands swap
+    assert np.all(o[35] == np.float32(0.5)) and np.all(o[28 + 6] == np.float32(0.5)) and np.all(o[42] == 0)
+    b, h = _kings((8, 4), (0, 4)); b[sq(4, 4)] = BISHOP | S.PROM; b[sq(2, 2)] = ROOK | S.PROM | WHITE; b[sq(5, 1)] = PAWN | S.PROM
+    o, _ = _env(b, h, 0).observe(0)
+    assert o[12][4, 4] == 1 and o[5][4, 4] == 0                   # own horse: plane 8 + 4
+    assert o[27][2, 2] == 1 and o[20][2, 2] == 0                  # the opponent's dragon: plane 22 + 5
+    assert o[8][5, 1] == 1 and o[0][5, 1] == 0                    # own tokin: plane 8 + 0
+    assert o[:28].sum() == 5 and np.all(o[:28].sum(axis=0) <= 1)  # one plane per occupied square
+    o, _ = _env(b, h, 1).observe(0)                               # White's view: colours swap, the board turns
+    assert o[22 + 4][4, 4] == 1 and o[13][6, 6] == 1 and o[22][3, 7] == 1
+    e = _env(*_kings((8, 4), (0, 4)), 0, max_ply=0)               # :726 max_ply 0: the ply plane is 0, not NaN
+    o, _ = e.observe(0)
+    assert np.all(o[43] == 0) and not np.isnan(o).any()
+    # repetition planes 44..47 after 1, 2, 3, 4 returns to a position, exactly one of them set
+    cycle = ((sq(8, 4), sq(7, 4)), (sq(0, 4), sq(1, 4)), (sq(7, 4), sq(8, 4)), (sq(1, 4), sq(0, 4)))
+    e = _env(*_kings((8, 4), (0, 4)), 0)
+    for rep in range(1, 6):
+        for f, t in cycle:
+            e.play(0, f, t)
+        o, _ = e.observe(0)
+        want = 44 + min(rep, 4) - 1
+        assert [bool(np.all(o[c] == 1)) for c in range(44, 48)] == [c == want for c in range(44, 48)], rep
+    # check plane: set for the side to move whose king is attacked, from either perspective
+    b, h = _kings((8, 4), (0, 4)); b[sq(4, 4)] = ROOK | WHITE
+    assert np.all(_env(b, h, 0).observe(0)[0][48] == 1)
+    b[sq(4, 4)] = ROOK
+    assert np.all(_env(b, h, 1).observe(0)[0][48] == 1) and np.all(_env(b, h, 0).observe(0)[0][48] == 0)

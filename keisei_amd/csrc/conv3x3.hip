@@ -806,13 +806,14 @@ __global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
                     for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
                     if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + (((size_t)bb * KA_BOARD + (i >> 4)) * 256 + ch0) * 2) = v;
                 } else if (has_aff || a.relu || a.in_bias) {
+                    // two channels per instruction (v_pk_fma_f32 / v_pk_add_f32): this arithmetic shares the SIMDs with the MFMA waves
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float f = (float)v[e];
-                        if (has_aff) f = fmaf(f, sc[e], sh[e]);
-                        if (a.relu) f = fmaxf(f, 0.f);
-                        if (a.in_bias) f += pb[e];
-                        v[e] = (__bf16)f;
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 f = {(float)v[e], (float)v[e + 1]};
+                        if (has_aff) f = __builtin_elementwise_fma(f, f32x2{sc[e], sc[e + 1]}, f32x2{sh[e], sh[e + 1]});
+                        if (a.relu) f = __builtin_elementwise_max(f, f32x2{0.f, 0.f});
+                        if (a.in_bias) f += f32x2{pb[e], pb[e + 1]};
+                        v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
                     }
                 }
                 *reinterpret_cast<bf16x8*>(img + lds_square(0, i >> 4) * kStImgStride + pc * 16) = v;

@@ -759,28 +759,30 @@ constexpr int kPcLds = kPcZero + kZeroSquares * kStImgStride;
 constexpr int kPcYStride = 256 * 2 + 16;                                  // the masked epilogue's y rows in LDS (16 B of padding: 2-way conflicts at most)
 constexpr int kPcLdsMasked = kPcLds + KA_BOARD * kPcYStride;
 
-template <bool TWO, bool MASKED>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue
-__global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
+template <bool TWO, bool MASKED, int NPW = 4>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue; NPW staging waves
+__global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) {
+    constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
+    constexpr int KP = (KA_BOARD * 16 + NP - 1) / NP, KY = (KA_BOARD * 32 + NP - 1) / NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int nwg = gridDim.x;
     if ((int)blockIdx.x >= a.B) return;
-    for (int i = tid; i < kPcLds / 16; i += 768) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < kPcLds / 16; i += NT_) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
     const int nboards = (a.B - (int)blockIdx.x + nwg - 1) / nwg, nunits = 2 * nboards;
     if (!MASKED) a.ep_y = nullptr;                           // (compile-time: the other epilogue is not compiled in)
     __syncthreads();
 
     if (wave >= 8) {
-        // ---------------- staging waves: piece i = pt + 256 k of a unit = row i / 16, 16-byte piece i % 16 = pt % 16
+        // ---------------- staging waves: piece i = pt + NP k of a unit = row i / 16, 16-byte piece i % 16 = pt % 16
         const int pt = tid - 512, pc = pt & 15;
         const bool has_aff = a.in_scale != nullptr;
         auto stage = [&](int u) {
             const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1, ch0 = kc * 128 + pc * 8;
             char* img = smem + (u & 1) * kPcImg;
-            bf16x8 pv[6], pw[TWO ? 6 : 1];
+            bf16x8 pv[KP], pw[TWO ? KP : 1];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int i = pt + 256 * k;
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k;
                 pv[k] = bf16x8{};
                 if (TWO) pw[TWO ? k : 0] = bf16x8{};
                 if (i < KA_BOARD * 16) {
@@ -797,8 +799,8 @@ __global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
                 pb[e] = (!TWO && a.in_bias) ? a.in_bias[(size_t)bb * 256 + ch0 + e] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int i = pt + 256 * k;
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k;
                 if (i >= KA_BOARD * 16) continue;
                 bf16x8 v = pv[k];
                 if (TWO) {
@@ -822,17 +824,17 @@ __global__ __launch_bounds__(768) void conv3x3_pc_kernel(ConvArgs a) {
         // masked form: the y rows the epilogue of board b compares against are brought into LDS during the board's second
         // unit, and the MFMA waves run that epilogue right AFTER the barrier that ends it (no HBM latency, few registers)
         auto load_y = [&](int bb) {
-            bf16x8 yv[11];
+            bf16x8 yv[KY];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const int i = pt + 256 * k;                   // 81 rows x 32 pieces
+            for (int k = 0; k < KY; ++k) {
+                const int i = pt + NP * k;                   // 81 rows x 32 pieces
                 yv[k] = bf16x8{};
                 if (i < KA_BOARD * 32)
                     yv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) + ((size_t)bb * KA_BOARD * 32 + i) * 16));
             }
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const int i = pt + 256 * k;
+            for (int k = 0; k < KY; ++k) {
+                const int i = pt + NP * k;
                 if (i < KA_BOARD * 32) *reinterpret_cast<bf16x8*>(smem + kPcLds + (i >> 5) * kPcYStride + (i & 31) * 16) = yv[k];
             }
         };
@@ -1001,6 +1003,10 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     } else if (a.in2) {
         if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, false>), done1, "conv3x3 (pc, two-tensor)")) return rc;
         hipLaunchKernelGGL((conv3x3_pc_kernel<true, false>), dim3(grid), dim3(768), kPcLds, st, a);
+    } else if (getenv("KA_CONV_P_NPW") && atoi(getenv("KA_CONV_P_NPW")) == 2) {        // experiment: two staging waves
+        static std::atomic<unsigned long long> done3{0};
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false, 2>), done3, "conv3x3 (pc, 2 staging waves)")) return rc;
+        hipLaunchKernelGGL((conv3x3_pc_kernel<false, false, 2>), dim3(grid), dim3(640), kPcLds, st, a);
     } else {
         if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false>), done0, "conv3x3 (pc)")) return rc;
         hipLaunchKernelGGL((conv3x3_pc_kernel<false, false>), dim3(grid), dim3(768), kPcLds, st, a);

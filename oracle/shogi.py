@@ -111,6 +111,11 @@ class OracleVecEnv:
     # rule-level probes used by the fixtures
     def legal_count(self, i=0): return lib().so_legal_count(self.h, i)
 
+    def attack_map(self, i=0):
+        out = np.zeros((2, 81), np.uint8)
+        lib().so_attack_map(self.h, i, _p(out))
+        return out
+
     def pseudo_moves(self, i, color, boards_only=True):
         out = np.zeros(2048, np.uint32)
         n = lib().so_pseudo_moves(self.h, i, color, int(boards_only), _p(out))

@@ -605,6 +605,8 @@ int so_pseudo_moves(void* h, int i, int color, int boards_only, uint32_t* out) {
     for (int k = 0; k < n; ++k) out[k] = (uint32_t)mv[k].from | ((uint32_t)mv[k].to << 8) | ((uint32_t)mv[k].promote << 16) | ((uint32_t)mv[k].drop << 24);
     return n;
 }
+/* the 2 x 81 attack counts of the position (attack.rs:145-200) */
+void so_attack_map(void* h, int i, uint8_t* out) { uint8_t map[2][81]; attack_map(&((Env*)h)->g[i].pos, map); memcpy(out, map, 162); }
 int so_legal_count(void* h, int i) { static _Thread_local Mv mv[1024]; return legal_moves(&((Env*)h)->g[i], mv); }
 int so_in_check(void* h, int i, int color) { return color_in_check(&((Env*)h)->g[i].pos, color); }
 int so_uchi_fu_zume(void* h, int i, int to, int color) { return is_uchi_fu_zume(&((Env*)h)->g[i].pos, to, color); }

@@ -521,3 +521,52 @@ def test_observation_rs_known_answers():
     assert np.all(_env(b, h, 0).observe(0)[0][48] == 1)
     b[sq(4, 4)] = ROOK
     assert np.all(_env(b, h, 1).observe(0)[0][48] == 1) and np.all(_env(b, h, 0).observe(0)[0][48] == 0)
+
+
+def _amap(pieces, side=0):
+    b, h = S.empty_board()
+    for pc, pos in pieces:
+        b[sq(*pos)] = pc
+    return _env(b, h, side).attack_map(0).reshape(2, 9, 9)
+
+
+def test_attack_rs_known_answers():
+    """Attack counts restated from shogi-core/src/attack.rs's tests (:452-704)."""
+    m = OracleVecEnv(1).attack_map(0).reshape(2, 9, 9)
+    assert np.all(m[0][5] >= 1) and np.all(m[1][3] >= 1)                 # the pawn rows attack the rows in front of them
+    m = _amap([(KING, (4, 4))])
+    assert m[0].sum() == 8 and m[0][3:6, 3:6].sum() == 8 and m[0][4, 4] == 0
+    m = _amap([(ROOK, (4, 4))])
+    assert np.all(np.delete(m[0][4], 4) == 1) and np.all(np.delete(m[0][:, 4], 4) == 1) and m[0].sum() == 16
+    m = _amap([(ROOK, (4, 4)), (PAWN | WHITE, (4, 6))])                  # the blocker's square is attacked, nothing behind it
+    assert m[0][4, 5] == 1 and m[0][4, 6] == 1 and m[0][4, 7] == 0 and m[0][4, 8] == 0
+    m = _amap([(S.KNIGHT, (4, 4))])
+    assert m[0][2, 3] == 1 and m[0][2, 5] == 1 and m[0].sum() == 2
+    m = _amap([(BISHOP | S.PROM, (4, 4))])
+    assert m[0][3, 4] == m[0][5, 4] == m[0][4, 3] == m[0][4, 5] == 1 and m[0][3, 3] == 1 and m[0][0, 0] == 1
+    m = _amap([(LANCE, (4, 4))])
+    assert np.all(m[0][:4, 4] == 1) and np.all(m[0][5:, 4] == 0) and m[0].sum() == 4
+    m = _amap([(ROOK, (4, 0)), (ROOK, (0, 4))])
+    assert m[0][4, 4] == 2                                               # two attackers are counted twice
+    m = _amap([(S.KNIGHT | WHITE, (4, 4)), (LANCE | WHITE, (2, 0))])
+    assert m[1][6, 3] == 1 and m[1][6, 5] == 1 and np.all(m[1][3:, 0] == 1) and m[1][1, 0] == 0   # White's pieces point down the board
+
+
+def test_vec_env_rs_behaviour_restated():
+    """vec_env.rs:1400-1565, 1735-1783: players alternate, games are isolated from each other, the material balance is the
+    last mover's view (positive right after it captures)."""
+    e = OracleVecEnv(3, 500)
+    obs, mask = e.reset()
+    assert np.array_equal(obs[0], obs[1]) and np.array_equal(obs[1], obs[2])
+    acts = [int(np.flatnonzero(m)[0]) for m in mask]
+    acts[1] = int(np.flatnonzero(mask[1])[-1])
+    r = e.step(acts)
+    assert r["current_players"].tolist() == [1, 1, 1] and r["material_balance"].tolist() == [0, 0, 0]
+    assert not np.array_equal(r["observations"][0], r["observations"][1]) and np.array_equal(r["observations"][0], r["observations"][2])
+    b, h = _kings((8, 4), (0, 4)); b[sq(5, 4)] = PAWN; b[sq(4, 4)] = PAWN | WHITE; b[sq(3, 0)] = GOLD | WHITE
+    e = _env(b, h, 0)
+    r = e.step([S.encode(sq(5, 4), sq(4, 4))])                       # Black's pawn takes the pawn in front of it
+    assert r["captured_piece"][0] == 0 and r["material_balance"][0] == (1 + 1) - 6      # board pawn + hand pawn against a gold
+    assert e.state(0)[1][0, 0] == 1 and r["current_players"][0] == 1
+    r = e.step([S.encode(sq(3, 0), sq(4, 0), white=True)])           # White's reply: now the balance is White's view
+    assert r["material_balance"][0] == 6 - 2 and r["captured_piece"][0] == 255

@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 dur = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "conv3x3_kernel" not in k: continue
+    if "conv3x3_kernel" not in k and "conv3x3_pc_kernel" not in k: continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVE_CYCLES":
         n[k] += 1
@@ -24,6 +24,7 @@ for k, c in acc.items():
     busy_cu = c.get("SQ_BUSY_CU_CYCLES", 0) / L
     out[k[:60]] = {"launches": L, "per_launch": {m: round(v / L, 1) for m, v in c.items()},
                    "mfma_busy_share_of_cu_busy_cycles": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(c.get("SQ_BUSY_CU_CYCLES", 1), 1), 4),
+                   "matrix_pipe_busy_fraction (MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(c.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024, 1), 4),
                    "wave_cycle_shares": {m: round(c.get(m, 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 4) for m in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")}}
 json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python3 tools/conv_one.py (B = 4096, C = 256, bf16, plain forward conv, 5 launches)",
            "note": "raw counter sums over all XCDs / SEs as rocprofv3 reports them; shares are ratios of like counters", "kernels": out}, open(sys.argv[2], "w"), indent=1)

@@ -1003,7 +1003,9 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     } else if (a.in2) {
         if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, false>), done1, "conv3x3 (pc, two-tensor)")) return rc;
         hipLaunchKernelGGL((conv3x3_pc_kernel<true, false>), dim3(grid), dim3(768), kPcLds, st, a);
-    } else if (getenv("KA_CONV_P_NPW") && atoi(getenv("KA_CONV_P_NPW")) == 2) {        // experiment: two staging waves
+    } else if (const char* e = getenv("KA_CONV_P_NPW"); e ? atoi(e) == 2 : (a.in_scale || a.relu || a.in_bias)) {
+        // two staging waves where the input carries a transform (its arithmetic shares the SIMDs with the MFMA waves: measured
+        // 0.369-0.374 against 0.380-0.386 ms with four), four for the plain input (0.339 against 0.349); KA_CONV_P_NPW forces one
         static std::atomic<unsigned long long> done3{0};
         if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false, 2>), done3, "conv3x3 (pc, 2 staging waves)")) return rc;
         hipLaunchKernelGGL((conv3x3_pc_kernel<false, false, 2>), dim3(grid), dim3(640), kPcLds, st, a);

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """PPO samples/sec of the Keisei SE-ResNet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: started plainly like that, the process spawns its own N ranks (`python -m torch.distributed.run --nproc-per-node N`
+on 127.0.0.1 with a free port, as the reference's run.sh:309-310 does with torchrun) before anything touches the GPU,
+forwards rank 0's JSON line and exits with the ranks' status; started BY torch.distributed.run (WORLD_SIZE set) it is a rank.
 
 One "step" = one KataGo-PPO minibatch through the product path
 (keisei_amd.training.katago_ppo.KataGoPPOAlgorithm._fused_step): fused row-gather + SE-ResNet
@@ -193,6 +197,26 @@ def cpu_baseline(shape, seconds_budget=25.0):
                       f"minibatch {Bc}, median of {len(times)} step(s) (~{sum(times):.0f} s of CPU work) after a probe step"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of a parent that has not touched
+    the GPU (torch.distributed.run on 127.0.0.1 with a free port; the reference's launcher does the same with torchrun,
+    run.sh:161-162,309-310), let rank 0's JSON line through on stdout, return the launcher's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] spawning {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def run_transformer(args, device):
     """BASELINE configs[4]: transformer (d_model 256, nhead 8, 6 layers -- SURVEY 8d fixes the sizing, no reference config
     names one), minibatch 4096, one GPU: forward (bf16 autocast, train mode with the encoder's dropout 0.1) + clipped-
@@ -373,11 +397,13 @@ def main() -> None:
                          "N > 1 bench does, run ONE step with its collectives, print the collective counts and exit")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))          # the parent never initialises the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: pass the same N to torch.distributed.run and to bench.py")
     backend = os.environ.get("KA_BENCH_BACKEND", "nccl")     # "gloo": rehearse the N > 1 wiring with several ranks on ONE GPU
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
@@ -386,7 +412,7 @@ def main() -> None:
         os.environ.setdefault("KA_FORCE_COLLECTIVES", "1")     # world size 1: issue every collective of the N > 1 step anyway
     if world > 1 or args.dist_dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))      # (only reached without a launcher: --dist-dry-run at world 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
@@ -466,6 +492,13 @@ def main() -> None:
             fp32["conv_frac_of_157TF"] = round(conv_flop / (avg * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)
         del r32
 
+    n_ranks_seen = 1
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, torch.cuda.current_device()))
+        n_ranks_seen = len({r for r, _ in seen})
+        dist.barrier()
+        dist.destroy_process_group()          # the other ranks are done; rank 0 goes on to the CPU baseline alone
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -528,7 +561,7 @@ def main() -> None:
             "metric": "PPO samples/sec, se_resnet 40x256 on 50x9x9" if args.workload == "40x256" else f"PPO samples/sec, se_resnet {args.workload}",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic", "n_ranks_seen": n_ranks_seen, "backend": backend if world > 1 else None,
             "config": {"workload": f"se_resnet {nb}x{C} KataGo-PPO minibatch step (gather+fwd+loss+bwd+clip+Adam), "
                                    f"minibatch {B}/GPU from a {total}-sample device-resident epoch dataset, obs 50x9x9",
                        "per_gpu_batch": B, "global_batch": B * world,
@@ -543,6 +576,8 @@ def main() -> None:
                              "frac": round(value / world * flops / 1e12 / peak, 4)},
             "train_metrics": {k: round(v, 5) for k, v in metrics.items()},
             "kernel_source_sha16": kernel_source_id(),
+            # every run-time switch of the library / engine set in this process's environment (none in a default run)
+            "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("KA_", "KEISEI_AMD")) and k != "KA_CHECK_ARGS"},
         }
         out.update(extra)
         if fp32 is not None:
@@ -551,13 +586,9 @@ def main() -> None:
             out["whole_update"] = whole
         if sl is not None:
             out["sl_epoch"] = sl
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline((nb, C, Rr, G, P, V, S))
-        else:
-            out["cpu_baseline"] = None
+        # (N > 1: taken after the timed region and after the process group is gone -- the other ranks have exited)
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline((nb, C, Rr, G, P, V, S))
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

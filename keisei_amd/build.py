@@ -14,7 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
-OUT = Path(__file__).resolve().parent / "libkeisei_amd.so"
+DIAG = bool(os.environ.get("KA_DIAG"))      # diagnostic build: ablation switches compiled in (common.h ka_diag_env), separate .so
+OUT = Path(__file__).resolve().parent / ("libkeisei_amd_diag.so" if DIAG else "libkeisei_amd.so")
 SOURCES = ["capi.hip", "conv3x3.hip", "wgrad.hip", "board.hip", "gemm.hip", "loss.hip", "optim.hip", "gae.hip", "rollout.hip", "transformer.hip", "conv_g.hip", "tower.hip", "shogi_env.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -37,7 +38,7 @@ def _stale(obj: Path, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    bdir = CSRC / "_build"
+    bdir = CSRC / ("_build_diag" if DIAG else "_build")
     bdir.mkdir(exist_ok=True)
     hipcc = _hipcc()
     headers = list(CSRC.glob("*.h"))
@@ -49,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, *PER_FILE.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *(["-DKA_DIAG"] if DIAG else []), *PER_FILE.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -43,6 +43,20 @@ inline int ka_big_lds_once(const void* func, std::atomic<unsigned long long>& do
     return KA_OK;
 }
 
+// Ablation switches (KA_CONV_P_ABL, KA_CONV_T_ABL, KA_TOWER_ABL: they skip phases of a kernel and give WRONG results)
+// exist only in diagnostic builds -- `KA_DIAG=1 python -m keisei_amd.build` compiles libkeisei_amd_diag.so with -DKA_DIAG;
+// the product library never reads them.  (Switches that choose between two CORRECT implementations stay run-time; bench.py
+// records every KA_* variable set in its environment.)
+#include <stdlib.h>
+inline const char* ka_diag_env(const char* name) {
+#ifdef KA_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950.

@@ -991,7 +991,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
 static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     static std::atomic<unsigned long long> done0{0}, done1{0};
     a.tune_stagger = 0; a.tune_prio = 0;                       // diagnostics: KA_CONV_P_ABL 1 no epilogue, 2 no staging after the first unit
-    if (const char* e = getenv("KA_CONV_P_ABL")) a.tune_stagger = atoi(e);
+    if (const char* e = ka_diag_env("KA_CONV_P_ABL")) a.tune_stagger = atoi(e);
     if (const char* e = getenv("KA_CONV_P_PRIO")) a.tune_prio = atoi(e);
     int grid = 256;
     if (const char* e = getenv("KA_CONV_P_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
@@ -1018,7 +1018,7 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
 
 static int launch_conv_stream(ConvArgs a, hipStream_t st) {
     a.tune_stagger = 0;
-    if (const char* e = getenv("KA_CONV_T_ABL")) a.tune_stagger = atoi(e);      // diagnostics only
+    if (const char* e = ka_diag_env("KA_CONV_T_ABL")) a.tune_stagger = atoi(e);      // diagnostics only
     static std::atomic<unsigned long long> done{0};
     int grid = 256;
     if (const char* e = getenv("KA_CONV_T_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }

@@ -405,7 +405,10 @@ __global__ __launch_bounds__(kPolThreads) void policy_sample_kernel(SampleArgs a
         }
         if (pick < 0) pick = last;
         a.actions[b] = pick;
-        a.logp[b] = logf(expf(row[pick] - mx) * (1.f / s));
+        // Categorical(probs).log_prob (katago_ppo.py:603-605) = log(clamp(p, eps, 1 - eps)), eps = FLT_EPSILON: an action
+        // more than ~88 nats below the maximum gives log(eps), not -inf
+        const float p = expf(row[pick] - mx) * (1.f / s);
+        a.logp[b] = logf(fminf(fmaxf(p, 1.1920929e-7f), 1.f - 1.1920929e-7f));
     }
 }
 

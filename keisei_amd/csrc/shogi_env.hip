@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int env = blockIdx.x, lane = threadIdx.x;
     if (env >= a.n) return;
     const int kA = action_space(a.amode), kWords = (kA + 31) >> 5, kObs = a.obs_ch * 81;
-    if (a.mode == 1 && *a.err != 0) return;                   // an action was refused: nothing moves (vec_env.rs:651-690)
+    // an action of this step was refused: nothing moves in ANY game (vec_env.rs:651-690).  The outputs of this step are then
+    // written again from the unchanged positions (zero rewards, no flags), so that the buffers the caller flips to hold the
+    // positions to move and their masks -- the next step validates against them -- also when the caller reads the flag late.
+    const bool hold = a.mode == 1 && *a.err != 0;
     uint8_t* st = a.state + (size_t)env * kStateBytes;
     unsigned long long* keys = a.keys + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
     uint8_t* checks = a.checks + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
@@ -243,6 +246,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         set_start(); side = 0; ply = 0; reps = 1; in_check = 0; key = position_key();
     } else if (a.mode == 2) {
         load_board(); side = st[95]; ply = 0; reps = 1; in_check = side_in_check(side); key = position_key();
+    } else if (hold) {
+        load_board();
+        side = st[95]; in_check = st[96];
+        ply = *reinterpret_cast<const uint32_t*>(st + 100);
+        key = *reinterpret_cast<const unsigned long long*>(st + 104);
+        reps = (int)*reinterpret_cast<const uint32_t*>(st + 112);
+        last_mover = side ^ 1;
     } else {
         load_board();
         side = st[95]; in_check = st[96];
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             for (int w = lane; w < kWords; w += 64) any |= s_bits[w];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
-            if (pass == 0 && a.mode == 1 && any == 0) { terminal = R_CHECKMATE; winner = side ^ 1; }   // game.rs:374-386
+            if (pass == 0 && a.mode == 1 && !hold && any == 0) { terminal = R_CHECKMATE; winner = side ^ 1; }   // game.rs:374-386
         }
         if (terminal == R_PROGRESS) break;
         // the game ended with this move (vec_env.rs:395-423)

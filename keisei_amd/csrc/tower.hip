@@ -338,7 +338,7 @@ extern "C" int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out
     KA_REQUIRE(ka_tower_eval_supported(C, G, R, dtype), "tower_eval: unsupported configuration C=%d G=%d R=%d dtype=%d", C, G, R, dtype);
     TowerArgs a{static_cast<const uint16_t*>(x_in), pool_in, static_cast<uint16_t*>(x_out), pool_out,
                 static_cast<const TowerBlock*>(blocks), nblocks, B, G, R, 0};
-    if (const char* e = getenv("KA_TOWER_ABL")) a.abl = atoi(e);
+    if (const char* e = ka_diag_env("KA_TOWER_ABL")) a.abl = atoi(e);
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&tower_eval_kernel), done, "tower_eval")) return rc;
     hipLaunchKernelGGL(tower_eval_kernel, dim3(B), dim3(512), kTowerLds, static_cast<hipStream_t>(stream), a);

@@ -61,7 +61,7 @@ class SEResNetEngine:
         self._evalc = None            # (key, device table, {id(bn): (scale, shift)}): all eval BatchNorm coefficients, one launch
         self._evalc_sets = {}
         self._fc_tr_sets = {}                       # transposed global_fc weights of the backward chain
-        self._tensor_lists = None                   # [buffers, parameters, calls until re-read] of the eval-graph key
+        self._tensor_lists = None                   # (buffers, parameters, structure version) of the eval-graph key
         self._tower_tabs = {}                       # pointer tables of the one-launch eval tower (kept: graphs read them)
         self._evalc_live = None
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
@@ -447,12 +447,12 @@ class SEResNetEngine:
         if obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.float().contiguous()
         self._get_packs(T, dev)
-        # (the flat tensor lists are cached and re-read every 32 calls: walking the module tree costs more host time than
-        # the whole graph replay; the storage addresses themselves are checked on every call)
-        tl = self._tensor_lists
-        if tl is None or tl[2] <= 0:
-            tl = self._tensor_lists = [list(m.buffers()), list(m.parameters()), 32]
-        tl[2] -= 1
+        # (the flat tensor lists are cached while no module registered a submodule / parameter / buffer -- walking the module
+        # tree costs more host time than the whole graph replay; the storage addresses themselves are checked on every call)
+        from keisei_amd.training._structure import structure_version
+        tl, ver = self._tensor_lists, structure_version()
+        if tl is None or tl[2] != ver:
+            tl = self._tensor_lists = (list(m.buffers()), list(m.parameters()), ver)
         key = (tuple(obs.shape), T, str(dev), self._pack_tkey,
                tuple(b.data_ptr() for b in tl[0]), tuple(q.data_ptr() for q in tl[1]))
         with self._graph_lock:

@@ -8,8 +8,13 @@ asks for katago + spatial (katago_loop.py:580-585).  `DefaultActionMapper` / `Sp
 action_mapper.rs / spatial_action_mapper.rs on the host.
 
 `output="numpy"` (default) returns host arrays like the reference does; `output="torch"` returns the device tensors
-themselves (observations and masks alternate between two buffers, so a result stays intact until the step after the
-next one) -- the form `select_actions` and the device rollout store consume without a host round trip.
+themselves -- every per-step field of a result (observations, masks, rewards, flags, players, metadata) alternates
+between two buffers, so a StepResult stays intact until the step after the next one; keep `.clone()`s of what must live
+longer.  `terminal_observations` is the reference's ONE persistent buffer (vec_env.rs:246): the row of a game that ended
+stays until that game ends again.  This is the form `select_actions` and the device rollout store consume without a host round trip.
+A refused step (an illegal action anywhere) moves nothing: the kernel then writes the unchanged positions' observations
+and masks (zero rewards, no flags) into the buffers the caller flips to, so a caller that runs with `check_actions=False`
+and reads the flag late (`raise_if_refused()`) has still stepped against the right masks.
 There is no CPU fallback: without the HIP library or a GPU the constructor raises.
 """
 from __future__ import annotations
@@ -171,15 +176,18 @@ class VecEnv:
         self._mask = [z(n, self._A, dtype=torch.bool) for _ in range(2)]
         self._bits = [z(n, (self._A + 31) // 32, dtype=torch.int32) for _ in range(2)]
         self._cur = 0
-        self._rewards = z(n, dtype=torch.float32)
-        self._terminated = z(n, dtype=torch.bool)
-        self._truncated = z(n, dtype=torch.bool)
+        two = lambda *shape, dtype: [z(*shape, dtype=dtype) for _ in range(2)]
+        self._rewards = two(n, dtype=torch.float32)
+        self._terminated = two(n, dtype=torch.bool)
+        self._truncated = two(n, dtype=torch.bool)
+        # ONE persistent buffer, as the reference's terminal_obs_buffer (vec_env.rs:246,598): a game's row is rewritten only
+        # when that game ends again, rows of running games keep what they held
         self._terminal_obs = z(n, self._C, 9, 9, dtype=torch.float32)
-        self._players = z(n, dtype=torch.uint8)
-        self._captured = torch.full((n,), 255, dtype=torch.uint8, device=dev)
-        self._reason = z(n, dtype=torch.uint8)
-        self._ply = z(n, dtype=torch.int16)                   # u16 payload (max_ply <= 65535); viewed as uint16 on the host
-        self._material = z(n, dtype=torch.int32)
+        self._players = two(n, dtype=torch.uint8)
+        self._captured = [torch.full((n,), 255, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._reason = two(n, dtype=torch.uint8)
+        self._ply = two(n, dtype=torch.int16)                 # u16 payload (max_ply <= 65535); viewed as uint16 on the host
+        self._material = two(n, dtype=torch.int32)
         self._stats = z(4, dtype=torch.int64)
         self._err = z(1, dtype=torch.int32)
         self._actions = z(n, dtype=torch.int64)
@@ -188,14 +196,16 @@ class VecEnv:
         self.reset()
         for t in (self._obs[0], self._mask[0], self._bits[0]):
             t.zero_()
+        self._armed = False
 
     # ------------------------------------------------------------------ core
     def reset(self) -> ResetResult:
         """vec_env.rs:617-645: every game back to the start position; observations and masks of the first move."""
+        self._armed = True
         with torch.cuda.device(self.device):
             self._cur = 0
             _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._omode,
-                      self._amode, self._obs[0], self._mask[0], self._bits[0], self._players, 0, _lib.stream_ptr())
+                      self._amode, self._obs[0], self._mask[0], self._bits[0], self._players[0], 0, _lib.stream_ptr())
         return ResetResult(self._out(self._obs[0]), self._out(self._mask[0]),
                            self._bits[0] if self._output == "torch" else None)
 
@@ -215,24 +225,31 @@ class VecEnv:
                 raise ValueError(f"expected {n} actions, got {a.shape[0]}")
             self._actions.copy_(torch.from_numpy(a), non_blocking=False)
             act = self._actions
+        if not getattr(self, "_armed", True):                 # no masks were handed out yet: every action is refused
+            a0 = int(act[0].item())
+            if a0 < 0:
+                raise ValueError(f"env 0: negative action index {a0}")
+            raise RuntimeError(f"env 0: action index {a0} is not legal")
         prev, nxt = self._cur, self._cur ^ 1
         with torch.cuda.device(self.device):
             _lib.call("ka_shogi_env_step", self._state, self._keys, self._checks, act, n, self._max_ply, self._omode, self._amode,
                       self._mask[prev], self._bits[prev], self._err, self._obs[nxt], self._mask[nxt], self._bits[nxt],
-                      self._rewards, self._terminated, self._truncated, self._terminal_obs, self._players,
-                      self._captured, self._reason, self._ply, self._material, self._stats, _lib.stream_ptr())
+                      self._rewards[nxt], self._terminated[nxt], self._truncated[nxt], self._terminal_obs, self._players[nxt],
+                      self._captured[nxt], self._reason[nxt], self._ply[nxt], self._material[nxt], self._stats, _lib.stream_ptr())
+        self._cur = nxt                                       # (a refused step has re-written the unchanged positions there)
         if self._check:
             self.raise_if_refused(act)
-        self._cur = nxt
         o = self._out
-        ply = self._ply if self._output == "torch" else self._ply.cpu().numpy().view(np.uint16)
-        meta = StepMetadata(o(self._captured), o(self._reason), ply, o(self._material))
-        return StepResult(o(self._obs[nxt]), o(self._mask[nxt]), o(self._rewards), o(self._terminated), o(self._truncated),
-                          o(self._terminal_obs), o(self._players), meta, self._bits[nxt] if self._output == "torch" else None)
+        ply = self._ply[nxt] if self._output == "torch" else self._ply[nxt].cpu().numpy().view(np.uint16)
+        meta = StepMetadata(o(self._captured[nxt]), o(self._reason[nxt]), ply, o(self._material[nxt]))
+        return StepResult(o(self._obs[nxt]), o(self._mask[nxt]), o(self._rewards[nxt]), o(self._terminated[nxt]),
+                          o(self._truncated[nxt]), o(self._terminal_obs), o(self._players[nxt]), meta,
+                          self._bits[nxt] if self._output == "torch" else None)
 
     def raise_if_refused(self, actions: Optional[torch.Tensor] = None) -> None:
         """The reference refuses a step before anything moves (vec_env.rs:660-690); so does the kernel, and this reads
-        its flag (one 4-byte copy).  With check_actions=False call it whenever convenient; a refused step is a no-op."""
+        its flag (one 4-byte copy).  With check_actions=False call it whenever convenient: a refused step moved no game,
+        and its result holds the unchanged positions again (zero rewards, no flags)."""
         e = int(self._err.item())
         if e == 0:
             return
@@ -320,10 +337,12 @@ class VecEnv:
         self._refresh(raw)
 
     def _refresh(self, raw: np.ndarray) -> None:
+        self._armed = True
         self._state.copy_(torch.from_numpy(raw))
         with torch.cuda.device(self.device):
             _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._omode,
-                      self._amode, self._obs[self._cur], self._mask[self._cur], self._bits[self._cur], self._players, 1, _lib.stream_ptr())
+                      self._amode, self._obs[self._cur], self._mask[self._cur], self._bits[self._cur], self._players[self._cur], 1,
+                      _lib.stream_ptr())
 
     def current(self) -> ResetResult:
         """Observation and masks of the positions to move (what the last reset / step / set_state wrote)."""

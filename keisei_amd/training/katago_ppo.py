@@ -493,22 +493,38 @@ class KataGoPPOAlgorithm(FusedAdamMixin):
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())       # host generator: torch.manual_seed() fixes the rollout
         _lib.call("ka_policy_sample", logits, int(logits.dtype == torch.bfloat16), masks_c, 0, seed, vl, sc, alpha, actions,
                   log_probs, values, n_legal, flags, B_, A_, _lib.stream_ptr(dev))
-        if int(flags[1].item()):                               # katago_ppo.py:572-578 (the one synchronisation of the call)
+        nan_seen, zero_legal = flags.tolist()                  # the one synchronisation of the call; both guards ride on it
+        if zero_legal:                                         # katago_ppo.py:589-596
             empty = (n_legal == 0).nonzero(as_tuple=True)[0].tolist()
             raise RuntimeError(f"Environments {empty} have zero legal actions — "
                                f"all-False legal mask would produce NaN")
+        if nan_seen:
+            # the reference's softmax + Categorical(probs).sample() refuses NaN probabilities (torch.multinomial raises);
+            # a diverged model must not keep stepping the environments and filling the buffer
+            raise RuntimeError("NaN in raw policy logits in select_actions — probability tensor contains nan "
+                               "(the model has diverged)")
         return actions, log_probs, values
 
     def _set_training(self, mode: bool) -> None:
         """forward_model.train(mode) without walking the module tree on every rollout step: nn.Module.train() recurses
         through ~450 modules with nn.Module.__setattr__ at each (about a millisecond per select_actions call at 40
-        blocks, twice per call); the flat module list is cached and re-read every 32 calls."""
+        blocks, twice per call).  The flat module list is cached for as long as no module anywhere registered a
+        submodule / parameter / buffer (`_structure.structure_version`: convert_sync_batchnorm, a replaced head, a rebuilt
+        model all bump it); a tree in which any module overrides train() -- or carries hooks on it -- takes the plain
+        `fm.train(mode)` (DistributedDataParallel's override only forwards to nn.Module.train and is exempt)."""
+        from torch.nn.parallel import DistributedDataParallel
+        from keisei_amd.training._structure import structure_version
+
         fm = self.forward_model
+        ver = structure_version()
         ent = getattr(self, "_mode_cache", None)
-        if ent is None or ent[0] is not fm or ent[2] <= 0:
-            ent = [fm, list(fm.modules()), 32]
-            self._mode_cache = ent
-        ent[2] -= 1
+        if ent is None or ent[0] is not fm or ent[2] != ver:
+            mods = list(fm.modules())
+            plain = all(type(m).train is torch.nn.Module.train or type(m) is DistributedDataParallel for m in mods)
+            ent = self._mode_cache = (fm, mods if plain else None, ver)
+        if ent[1] is None:
+            fm.train(mode)
+            return
         for mod in ent[1]:
             mod.__dict__["training"] = mode
 

@@ -37,3 +37,22 @@ def test_bench_line_contract():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] > 0
     assert d["cpu_baseline"] is None                    # skipped on request; the default run fills it (rank 0, N = 1)
     assert all(v == v for v in d["train_metrics"].values())   # finite training metrics: the timed steps really trained
+
+
+def test_bench_gpus_2_starts_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's recorded `bench.py --gpus 1 ...`):
+    the process spawns its two ranks itself (the reference's run.sh:309-310 does it with torchrun), here both on the one
+    GPU of the box over gloo (KA_BENCH_BACKEND=gloo; RCCL needs one device per rank); ONE line, n_gpus 2, value = sum of ranks."""
+    env_backend = os.environ.get("KA_BENCH_BACKEND")
+    os.environ["KA_BENCH_BACKEND"] = "gloo"
+    try:
+        d = run_bench("--gpus", "2", "--workload", "2x32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    finally:
+        if env_backend is None:
+            os.environ.pop("KA_BENCH_BACKEND", None)
+        else:
+            os.environ["KA_BENCH_BACKEND"] = env_backend
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["parallelism"] == "dp2+syncbn" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]   # both ranks' samples
+    assert all(v == v for v in d["train_metrics"].values())

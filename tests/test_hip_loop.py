@@ -136,9 +136,15 @@ def test_split_merge_step_with_device_players_and_the_device_env():
             got = ref.gather(1, sm.actions[sm.learner_indices].unsqueeze(1)).squeeze(1)
             assert torch.allclose(sm.learner_log_probs, got, atol=2e-3, rtol=0)
         seen_learner += n_l; seen_opp += N - n_l
-        pre_players = players
+        pre_players, pre_copy = players, players.clone()
         res = env.step(sm.actions)
         players = res.current_players
+        # a result outlives the next step (every per-step field alternates between two buffers): the players handed out
+        # before this step are still the side that just moved -- in a running game the other side is now to move, a
+        # finished game was set up again with black to move (the reference keeps `current_players.copy()`, katago_loop.py)
+        assert torch.equal(pre_players, pre_copy) and players.data_ptr() != pre_players.data_ptr()
+        over = res.terminated | res.truncated
+        assert torch.equal(players[~over], 1 - pre_players[~over]) and bool((players[over] == 0).all())
         rew = to_learner_perspective(res.rewards, pre_players, learner_side)
         assert torch.equal(rew.abs(), res.rewards.abs())
         flipped = pre_players != learner_side

@@ -352,8 +352,45 @@ def test_refused_actions_raise_like_the_reference_and_move_nothing():
     assert fresh.get_sfen(1).startswith("lnsgkgsnl/1r5b1/ppppppppp/9/9/9/PPPPPPPPP/1B5R1/LNSGKGSNL b - 1")
     with pytest.raises(RuntimeError, match="env 0: action index 0 is not legal"):
         fresh.step([0, 0])
+    with pytest.raises(RuntimeError, match="env 0: action index 0 is not legal"):
+        fresh.step([0, 0])                                              # ... and a refused step hands none out either
     with pytest.raises(ValueError, match="Unknown observation_mode"):
         VecEnv(num_envs=2, observation_mode="x")
+
+
+def test_a_refused_step_without_host_checks_leaves_every_buffer_consistent():
+    """check_actions=False (the device loop reads the flag late): a step with an illegal action anywhere moves NO game
+    (vec_env.rs:651-690), and the result it returns is the unchanged positions again -- observations, masks, players, ply --
+    with zero rewards and no flags, so the caller's next actions are validated against the right masks.  Every per-step
+    field alternates between two buffers: the result of step t is still intact after step t+1."""
+    n = 6
+    dev = _env(n, 60, output="torch", check_actions=False)
+    ref = OracleVecEnv(n, 60)
+    r0, (obs, mask) = dev.reset(), ref.reset()
+    rng = np.random.default_rng(5)
+    pick = lambda m: np.array([rng.choice(np.flatnonzero(row)) for row in m], dtype=np.int64)
+    acts = pick(mask)
+    r1 = dev.step(torch.from_numpy(acts).cuda()); o1 = ref.step(acts)
+    keep = {k: getattr(r1, k).clone() for k in ("observations", "legal_masks", "rewards", "terminated", "truncated", "current_players")}
+    keep_ply = r1.step_metadata.ply_count.clone()
+    bad = pick(o1["legal_masks"])
+    bad[3] = int(np.flatnonzero(~o1["legal_masks"][3])[0])
+    before = dev._state.clone()
+    r2 = dev.step(torch.from_numpy(bad).cuda())                         # refused: not raised here (no host check)
+    assert torch.equal(dev._state, before)                              # nothing moved, in any game
+    for k, v in keep.items():                                           # step 1's result is still intact ...
+        assert torch.equal(getattr(r1, k), v), k
+    assert torch.equal(r2.observations, r1.observations) and torch.equal(r2.legal_masks, r1.legal_masks)   # ... and step 2 re-states it
+    assert torch.equal(r2.legal_mask_bits, r1.legal_mask_bits) and torch.equal(r2.current_players, r1.current_players)
+    assert torch.equal(r2.step_metadata.ply_count, keep_ply)
+    assert not bool(r2.terminated.any()) and not bool(r2.truncated.any()) and not bool((r2.rewards != 0).any())
+    with pytest.raises(RuntimeError, match=r"env 3: action index \d+ is not legal"):
+        dev.raise_if_refused()
+    good = pick(o1["legal_masks"])                                       # the env goes on from the unchanged positions
+    r3 = dev.step(torch.from_numpy(good).cuda()); o3 = ref.step(good)
+    dev.raise_if_refused()
+    assert np.array_equal(r3.observations.cpu().numpy(), o3["observations"]) and np.array_equal(r3.legal_masks.cpu().numpy(), o3["legal_masks"])
+    assert np.array_equal(r3.rewards.cpu().numpy(), o3["rewards"]) and np.array_equal(r3.current_players.cpu().numpy(), o3["current_players"])
 
 
 def test_full_size_invariants_on_the_device():

@@ -51,7 +51,7 @@ def kernel_source_id() -> str:
     profiles/ to the build of that kernel."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("common.h", "conv3x3.hip", "conv_g.h", "conv_g.hip"):
+    for name in ("common.h", "conv3x3.hip"):
         f = ROOT / "keisei_amd" / "csrc" / name
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]

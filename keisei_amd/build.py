@@ -16,7 +16,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 DIAG = bool(os.environ.get("KA_DIAG"))      # diagnostic build: ablation switches compiled in (common.h ka_diag_env), separate .so
 OUT = Path(__file__).resolve().parent / ("libkeisei_amd_diag.so" if DIAG else "libkeisei_amd.so")
-SOURCES = ["capi.hip", "conv3x3.hip", "wgrad.hip", "board.hip", "gemm.hip", "loss.hip", "optim.hip", "gae.hip", "rollout.hip", "transformer.hip", "conv_g.hip", "tower.hip", "shogi_env.hip"]
+SOURCES = ["capi.hip", "conv3x3.hip", "wgrad.hip", "board.hip", "gemm.hip", "loss.hip", "optim.hip", "gae.hip", "rollout.hip", "transformer.hip", "tower.hip", "shogi_env.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unknown-pragmas", "-Wno-sometimes-uninitialized"]

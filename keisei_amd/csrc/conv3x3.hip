@@ -31,7 +31,6 @@
 // keisei/training/models/se_resnet.py:50,52,110 and its autograd backward.
 #include <stdlib.h>
 #include "common.h"
-#include "conv_g.h"
 
 namespace {
 
@@ -1098,11 +1097,6 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (conv_g_applies(B, Cin, Cout, dtype, false)) {      // the GEMM-class kernel (conv_g.hip): tower shapes at training batch sizes
-        ConvGArgs g{in, wpack, out, in_scale, in_shift, in_bias, relu, nullptr, nullptr, nullptr, bsum, sqpart,
-                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B};
-        return conv_g_run(g, st);
-    }
     if (dtype == KA_DTYPE_BF16) return conv_dispatch<bf16_t>(a, st);
     if (dtype == KA_DTYPE_F32) return conv_dispatch<float>(a, st);
     ka_set_error("conv3x3: unknown dtype %d", dtype);
@@ -1120,11 +1114,6 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
     KA_REQUIRE(in && in2 && k && wpack && out, "conv3x3_dgrad_fused: null tensor");
     KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused: bf16 only");
     KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused: epilogue tensors");
-    if (conv_g_applies(B, Cin, Cout, dtype, true)) {
-        ConvGArgs g{in, wpack, out, k, k + Cin, nullptr, 0, in2, k + 2 * Cin, dy_out, bsum, nullptr,
-                    ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, B};
-        return conv_g_run(g, static_cast<hipStream_t>(stream));
-    }
     ConvArgs a{in, wpack, out, k, k + Cin, nullptr, bsum, nullptr, B, Cin, Cout, 0, 0,
                in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps.load()};
     return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));

@@ -732,32 +732,6 @@ def test_grouped_fc_weight_gradients():
             assert torch.allclose(db.cpu(), dy.sum(0), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,transform", [(770, False), (770, True), (1025, True)])
-def test_conv_g_opt_in_kernel_matches_torch_and_conv3x3(monkeypatch, B, transform):
-    """The GEMM-class forward kernel (conv_g.hip, KA_CONV_G=1; off by default) on batches with 2-board and 1-board
-    remainder tiles: output against torch fp32 on bf16-rounded inputs, statistics against the default kernel's."""
-    dt, C = torch.bfloat16, 256
-    g = torch.Generator().manual_seed(B)
-    x = torch.randn(B, C, 9, 9, generator=g)
-    w = torch.randn(C, C, 3, 3, generator=g) / 48
-    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
-    gb = 0.5 * torch.randn(B, C, generator=g)
-    args = (sc.to(DEV), sh.to(DEV), gb.to(DEV), 1) if transform else ()
-    xin, wp = to_nhwc(x, dt), pack(w, dt, 0, C, C)
-    monkeypatch.setenv("KA_CONV_G", "0")
-    out0, bsum0, sq0 = run_conv(xin, wp, B, C, C, dt, *args)
-    monkeypatch.setenv("KA_CONV_G", "1")
-    out1, bsum1, sq1 = run_conv(xin, wp, B, C, C, dt, *args)
-    h = rnd(x, dt)
-    if transform:
-        h = rnd(torch.relu(h * sc[None, :, None, None] + sh[None, :, None, None]) + gb[:, :, None, None], dt)
-    ref = F.conv2d(h.to(DEV), rnd(w, dt).to(DEV), padding=1).cpu()
-    close(from_nhwc(out1), ref, dt, k=2 if transform else 1)
-    assert not torch.isnan(bsum1).any() and not torch.isnan(sq1).any()
-    close(bsum1.cpu(), bsum0.cpu(), torch.float32, k=5)
-    close(sq1.cpu(), sq0.cpu(), torch.float32, k=5)
-
-
 @pytest.mark.parametrize("transform", [False, True])
 def test_streaming_conv_is_bit_identical_to_the_default_kernel(monkeypatch, transform):
     """The opt-in persistent form of the forward convolution (KA_CONV_T=1; the eval tower's MFMA loop with the next board

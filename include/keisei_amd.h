@@ -265,6 +265,29 @@ int ka_rollout_append(const float* obs, const void* legal, const long long* acti
 int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream);
 int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A, void* stream);
 
+/* ---- Pending learner transitions of the split-merge rollout (PendingTransitions.create / accumulate_reward / finalize,
+ * katago_loop.py:139-250).  Slots = one row per game: obs fp32 (n, obs_elems), legal masks PACKED (n,
+ * ka_mask_words(A)) uint32, actions int64, log_probs / values / rewards / score fp32, valid bytes.
+ * ka_pending_open (create(), katago_loop.py:172-200): the games with env_mask != 0 take this step's rows; masks come as bool
+ *   rows (s_legal, (n, A)) and are packed on the way, or as packed rows (s_bits) and are copied.  flags[0] = 1 and nothing is
+ *   written when a selected slot still holds a transition (the reference's RuntimeError).
+ * ka_pending_accumulate (accumulate_reward(), :203-211): rewards[valid] += add[valid].
+ * ka_pending_settle (finalize(), :213-250): rows of the games with fin_mask & valid, in game order, into the o_* columns
+ *   (n rows allocated; flags[1] = rows written); dones / terminated are this step's flags for all n games, floats
+ *   (flags_are_f32 != 0) or bytes; add_rewards (may be NULL) is accumulated first, as accumulate_reward() would; o_cats =
+ *   the value-head labels of _compute_value_cats (:75-92) for the settled rows; settled slots are released (valid_out, a
+ *   second buffer: the launch still counts over `valid`) and their rewards zeroed. */
+int ka_pending_open(float* obs, void* bits, long long* actions, float* log_probs, float* values, float* rewards, float* score,
+                    void* valid, const void* env_mask, const float* s_obs, const void* s_legal, const void* s_bits,
+                    const long long* s_actions, const float* s_log_probs, const float* s_values, const float* s_rewards,
+                    const float* s_score, int* flags, int n, int obs_elems, int A, void* stream);
+int ka_pending_accumulate(float* rewards, const void* valid, const float* add_rewards, int n, void* stream);
+int ka_pending_settle(float* obs, void* bits, long long* actions, float* log_probs, float* values, float* rewards, float* score,
+                      const void* valid, void* valid_out, const void* fin_mask, const void* dones, const void* terminated,
+                      int flags_are_f32, const float* add_rewards, float* o_obs, void* o_bits, long long* o_actions,
+                      float* o_log_probs, float* o_values, float* o_rewards, float* o_dones, float* o_terminated, float* o_score,
+                      long long* o_env_ids, long long* o_cats, int* flags, int n, int obs_elems, int A, void* stream);
+
 /* ---- the eval-mode residual tower in one launch (rollout inference, SURVEY 8 f2: katago_ppo.py:543-617 calling
  * se_resnet.py:67-75 for every block under no_grad / eval()).  One workgroup carries one board through all blocks; the
  * activations live in LDS.  x_in / x_out (B, 81, C) bf16, pool_in / pool_out (B, 4C) fp32 [mean|max|std|-]; blocks = device

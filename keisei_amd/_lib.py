@@ -74,6 +74,9 @@ _SIGS = {
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",
     "ka_pack_mask_bits": "pp ii p",
+    "ka_pending_open": "pppppppp ppppppppp p iii p",
+    "ka_pending_accumulate": "ppp i p",
+    "ka_pending_settle": "ppppppppp ppp i p ppppppppppp p iii p",
     "ka_tower_eval_supported": "iiii",
     "ka_tower_eval": "ppppp iiiii i p",
     "ka_shogi_env_state_bytes": "",

@@ -89,6 +89,118 @@ __global__ __launch_bounds__(256) void pack_mask_kernel(const uint8_t* __restric
     }
 }
 
+// ---------------------------------------------------------------- pending learner transitions
+// The split-merge rollout keeps, per game, the learner's last move until its outcome is known (the opponent may move in
+// between): reference keisei/training/katago_loop.py:139-250 holds eight (num_envs, ...) tensors and moves rows with
+// boolean-mask indexing (a dozen launches and a synchronising nonzero() per call).  Here the slots are columns in HBM --
+// observation rows, legal masks as PACKED rows (352 words instead of 11 259 bytes), scalars -- and each protocol step is one
+// launch: open (scatter by game mask, masks packed or copied on the way, "slot already taken" as a device flag), settle
+// (reward accumulation, selection, stable compaction in game order, value categories, slot release).
+struct PendingArgs {
+    // slots
+    float* obs; uint32_t* bits; long long* actions; float* log_probs; float* values; float* rewards; float* score; uint8_t* valid;
+    uint8_t* valid_out;   // settle: the slots' state after the launch (other workgroups still count over `valid` meanwhile)
+    // open: this step's tensors (all num_envs rows) and the games to open
+    const uint8_t* env_mask; const float* s_obs; const uint8_t* s_legal; const uint32_t* s_bits; const long long* s_actions;
+    const float* s_log_probs; const float* s_values; const float* s_rewards; const float* s_score;
+    // settle: selection, this step's flags, optional rewards to add first; compacted outputs (num_envs rows allocated)
+    const uint8_t* fin_mask; const void* dones; const void* terminated; const float* add_rewards;
+    float* o_obs; uint32_t* o_bits; long long* o_actions; float* o_log_probs; float* o_values; float* o_rewards; float* o_dones;
+    float* o_terminated; float* o_score; long long* o_env_ids; long long* o_cats;
+    int* flags;          // open: [0] a selected slot was still valid;  settle: [1] number of rows written
+    int n, obs_elems, A, words, flag_f32;      // flag_f32: dones / terminated are float rows (the loop's tensors), else bytes
+};
+
+__device__ __forceinline__ bool pending_flag(const void* p, int i, int f32) {
+    return f32 ? static_cast<const float*>(p)[i] != 0.f : static_cast<const uint8_t*>(p)[i] != 0;
+}
+
+// conflict probe: one workgroup; flags[0] = 1 when a game to open still holds a pending transition (reference: RuntimeError
+// before anything is written, katago_loop.py:187-191 -- the open kernel reads the flag and then writes nothing)
+__global__ __launch_bounds__(256) void pending_probe_kernel(PendingArgs a) {
+    bool hit = false;
+    for (int i = threadIdx.x; i < a.n; i += 256) hit |= a.env_mask[i] && a.valid[i];
+    const int any = __syncthreads_or(hit);
+    if (threadIdx.x == 0) a.flags[0] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void pending_open_kernel(PendingArgs a) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (!a.env_mask[g] || a.flags[0]) return;
+    const f32x2* s2 = reinterpret_cast<const f32x2*>(a.s_obs + (size_t)g * a.obs_elems);
+    f32x2* d2 = reinterpret_cast<f32x2*>(a.obs + (size_t)g * a.obs_elems);
+    if ((a.obs_elems & 1) == 0) { for (int i = tid; i < a.obs_elems / 2; i += 256) d2[i] = s2[i]; }
+    else { for (int i = tid; i < a.obs_elems; i += 256) a.obs[(size_t)g * a.obs_elems + i] = a.s_obs[(size_t)g * a.obs_elems + i]; }
+    uint32_t* bits = a.bits + (size_t)g * a.words;
+    if (a.s_bits) {
+        for (int w = tid; w < a.words; w += 256) bits[w] = a.s_bits[(size_t)g * a.words + w];
+    } else {
+        const uint8_t* lm = a.s_legal + (size_t)g * a.A;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int base = wave * 64; base < a.words * 32; base += 256) {
+            const int j = base + lane;
+            const unsigned long long vote = __ballot(j < a.A && lm[j] != 0);
+            if (lane < 2 && (base >> 5) + lane < a.words) bits[(base >> 5) + lane] = (uint32_t)(vote >> (32 * lane));
+        }
+    }
+    if (tid == 0) {
+        a.actions[g] = a.s_actions[g]; a.log_probs[g] = a.s_log_probs[g]; a.values[g] = a.s_values[g];
+        a.rewards[g] = a.s_rewards[g]; a.score[g] = a.s_score[g]; a.valid[g] = 1;
+    }
+}
+
+// rewards[valid] += add[valid] (katago_loop.py:203-211) -- also available fused into the settle launch
+__global__ void pending_accumulate_kernel(PendingArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n && a.valid[i]) a.rewards[i] += a.add_rewards[i];
+}
+
+// settle: one workgroup per game.  Row of game g in the output = number of selected games before it (every workgroup counts
+// the prefix itself: num_envs bytes, L2-resident), so the rows come out in game order like the reference's nonzero().
+__global__ __launch_bounds__(256) void pending_settle_kernel(PendingArgs a) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_cnt[4];
+    int before = 0, total = 0;
+    for (int i = tid; i < a.n; i += 256) {
+        const int sel = a.fin_mask[i] && a.valid[i];
+        total += sel; before += sel && i < g;
+    }
+    // (two sums packed in one reduction: counts stay below 2^15 for any plausible num_envs; checked by the launcher)
+    int packed = before | (total << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) packed += __shfl_xor(packed, o);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = packed;
+    __syncthreads();
+    packed = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const int row = packed & 0xffff, ntot = packed >> 16;
+    if (g == 0 && tid == 0) a.flags[1] = ntot;
+    const bool mine = a.valid[g] != 0;
+    float rw = mine ? a.rewards[g] : 0.f;
+    if (mine && a.add_rewards) rw += a.add_rewards[g];
+    if (!(a.fin_mask[g] && mine)) {
+        if (tid == 0) {
+            a.valid_out[g] = mine;
+            if (mine && a.add_rewards) a.rewards[g] = rw;              // stays pending: keeps the accumulated reward
+        }
+        return;
+    }
+    const f32x2* s2 = reinterpret_cast<const f32x2*>(a.obs + (size_t)g * a.obs_elems);
+    f32x2* d2 = reinterpret_cast<f32x2*>(a.o_obs + (size_t)row * a.obs_elems);
+    if ((a.obs_elems & 1) == 0) { for (int i = tid; i < a.obs_elems / 2; i += 256) d2[i] = s2[i]; }
+    else { for (int i = tid; i < a.obs_elems; i += 256) a.o_obs[(size_t)row * a.obs_elems + i] = a.obs[(size_t)g * a.obs_elems + i]; }
+    for (int w = tid; w < a.words; w += 256) a.o_bits[(size_t)row * a.words + w] = a.bits[(size_t)g * a.words + w];
+    if (tid == 0) {
+        const bool dn = pending_flag(a.dones, g, a.flag_f32), tm = pending_flag(a.terminated, g, a.flag_f32);
+        a.o_actions[row] = a.actions[g]; a.o_log_probs[row] = a.log_probs[g]; a.o_values[row] = a.values[g];
+        a.o_rewards[row] = rw; a.o_score[row] = a.score[g];
+        a.o_dones[row] = dn ? 1.f : 0.f; a.o_terminated[row] = tm ? 1.f : 0.f;
+        a.o_env_ids[row] = g;
+        // value-head label of the settled transition (katago_loop.py:75-92): only genuinely terminal positions get one
+        a.o_cats[row] = !tm ? -1 : (rw > 0.f ? 0 : (rw == 0.f ? 1 : 2));
+        a.valid_out[g] = 0; a.rewards[g] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int ka_mask_words(int A) { return (A + 31) / 32; }
@@ -127,4 +239,61 @@ extern "C" int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A,
     hipLaunchKernelGGL(pack_mask_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint8_t*>(legal), static_cast<uint32_t*>(bits), A, (A + 31) / 32);
     return ka_check_launch("pack_mask_bits");
+}
+
+// ---- pending learner transitions (keisei_amd/training/katago_loop.py PendingTransitions; reference katago_loop.py:139-250)
+extern "C" int ka_pending_open(float* obs, void* bits, long long* actions, float* log_probs, float* values, float* rewards,
+                               float* score, void* valid, const void* env_mask, const float* s_obs, const void* s_legal,
+                               const void* s_bits, const long long* s_actions, const float* s_log_probs, const float* s_values,
+                               const float* s_rewards, const float* s_score, int* flags, int n, int obs_elems, int A,
+                               void* stream) {
+    KA_REQUIRE(obs && bits && actions && log_probs && values && rewards && score && valid, "pending_open: null slot column");
+    KA_REQUIRE(env_mask && s_obs && (s_legal || s_bits) && s_actions && s_log_probs && s_values && s_rewards && s_score && flags,
+               "pending_open: null source");
+    KA_REQUIRE(n > 0 && obs_elems > 0 && A > 0, "pending_open: bad sizes");
+    PendingArgs a{};
+    a.obs = obs; a.bits = static_cast<uint32_t*>(bits); a.actions = actions; a.log_probs = log_probs; a.values = values;
+    a.rewards = rewards; a.score = score; a.valid = static_cast<uint8_t*>(valid);
+    a.env_mask = static_cast<const uint8_t*>(env_mask); a.s_obs = s_obs; a.s_legal = static_cast<const uint8_t*>(s_legal);
+    a.s_bits = static_cast<const uint32_t*>(s_bits); a.s_actions = s_actions; a.s_log_probs = s_log_probs; a.s_values = s_values;
+    a.s_rewards = s_rewards; a.s_score = s_score; a.flags = flags;
+    a.n = n; a.obs_elems = obs_elems; a.A = A; a.words = (A + 31) / 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pending_probe_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(pending_open_kernel, dim3(n), dim3(256), 0, st, a);
+    return ka_check_launch("pending_open");
+}
+
+extern "C" int ka_pending_accumulate(float* rewards, const void* valid, const float* add_rewards, int n, void* stream) {
+    KA_REQUIRE(rewards && valid && add_rewards && n > 0, "pending_accumulate: bad arguments");
+    PendingArgs a{};
+    a.rewards = rewards; a.valid = const_cast<uint8_t*>(static_cast<const uint8_t*>(valid)); a.add_rewards = add_rewards; a.n = n;
+    hipLaunchKernelGGL(pending_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("pending_accumulate");
+}
+
+extern "C" int ka_pending_settle(float* obs, void* bits, long long* actions, float* log_probs, float* values, float* rewards,
+                                 float* score, const void* valid, void* valid_out, const void* fin_mask, const void* dones, const void* terminated,
+                                 int flags_are_f32, const float* add_rewards, float* o_obs, void* o_bits, long long* o_actions,
+                                 float* o_log_probs, float* o_values, float* o_rewards, float* o_dones, float* o_terminated,
+                                 float* o_score, long long* o_env_ids, long long* o_cats, int* flags, int n, int obs_elems, int A,
+                                 void* stream) {
+    KA_REQUIRE(obs && bits && actions && log_probs && values && rewards && score && valid && valid_out && valid != valid_out,
+               "pending_settle: null slot column (valid and valid_out must be two buffers)");
+    KA_REQUIRE(fin_mask && dones && terminated && flags, "pending_settle: null selection");
+    KA_REQUIRE(o_obs && o_bits && o_actions && o_log_probs && o_values && o_rewards && o_dones && o_terminated && o_score &&
+               o_env_ids && o_cats, "pending_settle: null output column");
+    KA_REQUIRE(n > 0 && n < 32768 && obs_elems > 0 && A > 0, "pending_settle: bad sizes (n=%d: at most 32767 games)", n);
+    PendingArgs a{};
+    a.obs = obs; a.bits = static_cast<uint32_t*>(bits); a.actions = actions; a.log_probs = log_probs; a.values = values;
+    a.rewards = rewards; a.score = score; a.valid = const_cast<uint8_t*>(static_cast<const uint8_t*>(valid));
+    a.valid_out = static_cast<uint8_t*>(valid_out);
+    a.fin_mask = static_cast<const uint8_t*>(fin_mask); a.dones = dones; a.terminated = terminated; a.flag_f32 = flags_are_f32;
+    a.add_rewards = add_rewards;
+    a.o_obs = o_obs; a.o_bits = static_cast<uint32_t*>(o_bits); a.o_actions = o_actions; a.o_log_probs = o_log_probs;
+    a.o_values = o_values; a.o_rewards = o_rewards; a.o_dones = o_dones; a.o_terminated = o_terminated; a.o_score = o_score;
+    a.o_env_ids = o_env_ids; a.o_cats = o_cats; a.flags = flags;
+    a.n = n; a.obs_elems = obs_elems; a.A = A; a.words = (A + 31) / 32;
+    hipLaunchKernelGGL(pending_settle_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return ka_check_launch("pending_settle");
 }

@@ -343,6 +343,232 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
     }
 }
 
+// ---------------------------------------------------------------- flat-K form, software-pipelined (bf16, 128 x 64 x 9 slab)
+// The same slab, tiles, operand reads and summation as wgrad_kernel<bf16_t, 128>, restructured around what its counters
+// showed (profiles/r03_mfma_sq_counters.json: matrix pipe 53 % busy, 41 % of the wave cycles issue stalls): every k-step
+// began with ~45 dependent address instructions followed by twelve LDS reads whose latency nothing covered, and both
+// waves of a SIMD restart in phase after the per-board barrier.  Here
+//   * a k-step belongs to the board its FIRST row lies in and may run on into the next board, whose tile was published one
+//     barrier earlier (the staging runs two boards ahead of the multiplication instead of one; still a ring of three
+//     tiles: board j's slot is rewritten with board j+3 only after the barrier that ends iteration j).  Every k-step
+//     therefore reads published tiles only -- also the first one of the next iteration --
+//   * so the operand fragments of step s+1 (four dY fragments, the first X fragment) and its row addresses are fetched
+//     under the MFMAs of step s, across board boundaries and barriers alike: no step starts with an LDS round trip;
+//   * row addresses come from one wave-uniform offset (first row of the step within its board) and two per-lane
+//     constants: a compare, a select, p/9 as (57 p) >> 9 and two multiply-adds per row instead of the divisions /
+//     conditional pointer chains of the first form (45 -> ~20 vector instructions per step);
+//   * the per-channel coefficients of the fused input transform are re-read per board (L2) instead of living in 24
+//     registers across the MFMA loop, which pays for the second fragment set.
+// Bit-identical slabs (same products, same order within a lane's accumulator: steps in flat-row order).
+struct RowPtr { uint32_t y1, y2, x1, x2; };
+
+template <bool FUSED>
+__global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
+    typedef Elem<bf16_t> E;
+    typedef bf16x8 vec16;
+    constexpr int TN = 128, NTHR = 512, P16 = 8;
+    constexpr int SY = WG<bf16_t, TN>::SY, SX = WG<bf16_t, TN>::SX, KROWS = WG<bf16_t, TN>::KROWS, PW = WG<bf16_t, TN>::PW;
+    constexpr int XSQ = 11 * PW, YB = KROWS * SY, TILE = YB + XSQ * SX;
+    constexpr int PY = TN * 2 / 16, PX = kTC * 2 / 16;
+    constexpr int NY = (KA_BOARD * PY + NTHR - 1) / NTHR, NX = (KA_BOARD * PX + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int nh = wave & 1, cq = wave >> 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // XCD-aware (tile, split) map: see wgrad_kernel
+    const int tile = slot % a.ntiles;
+    const int split = xcd + 8 * (slot / a.ntiles);
+    if (split >= a.nsplit) return;
+    const int tn = tile % a.ntn, tc = tile / a.ntn;
+    const int n0 = tn * TN, c0 = tc * kTC;
+    const int bbeg = split * a.boards_per_split;
+    const int bend = min(a.B, bbeg + a.boards_per_split);
+    const int nb = max(0, bend - bbeg);
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 3 * TILE / 16; i += NTHR) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+
+    // ---- staging (all eight waves; one register set, two boards ahead of its LDS write)
+    const int yj = tid % PY, xj = tid % PX;
+    const bool ycol_ok = n0 + yj * P16 < a.Cout, xcol_ok = c0 + xj * P16 < a.Cin;
+    const bool has_aff = FUSED && a.in_scale != nullptr;
+    vec16 ry[NY], rx[NX];
+    auto load_board = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = (tid + i * NTHR) / PY;
+            ry[i] = (row < KA_BOARD && ycol_ok)
+                        ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.dy) + ((size_t)(b * KA_BOARD + row) * a.Cout + n0 + yj * P16) * 2)
+                        : vec16{};
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = (tid + i * NTHR) / PX;
+            rx[i] = (row < KA_BOARD && xcol_ok)
+                        ? *reinterpret_cast<const vec16*>(static_cast<const char*>(a.x) + ((size_t)(b * KA_BOARD + row) * a.Cin + c0 + xj * P16) * 2)
+                        : vec16{};
+        }
+    };
+    auto store_board = [&](int b, uint32_t tbase) {
+        f32x4 cf[FUSED ? 6 : 1];                 // scale | shift | per-board bias of this thread's 8 channels (re-read per board)
+        if (FUSED && xcol_ok) {
+            const int cc = c0 + xj * P16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cf[FUSED ? h : 0] = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + cc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+                cf[FUSED ? 2 + h : 0] = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + cc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+                cf[FUSED ? 4 + h : 0] = a.in_bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b * a.Cin + cc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = (tid + i * NTHR) / PY;
+            if (row < KA_BOARD) *reinterpret_cast<vec16*>(smem + tbase + row * SY + yj * 16) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = (tid + i * NTHR) / PX;
+            if (row < KA_BOARD) {
+                vec16 v = rx[i];
+                if (FUSED && xcol_ok && (has_aff || a.relu || a.in_bias)) {
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) {
+                        float f = (float)v[e];
+                        if (has_aff) f = fmaf(f, cf[FUSED ? (e >> 2) : 0][e & 3], cf[FUSED ? 2 + (e >> 2) : 0][e & 3]);
+                        if (a.relu) f = fmaxf(f, 0.f);
+                        if (a.in_bias) f += cf[FUSED ? 4 + (e >> 2) : 0][e & 3];
+                        v[e] = (__bf16)f;
+                    }
+                }
+                const int sq = (row / 9 + 1) * PW + (row % 9) + 1;
+                *reinterpret_cast<vec16*>(smem + tbase + YB + sq * SX + xj * 16) = v;
+            }
+        }
+    };
+
+    // ---- MFMA side
+    const int ntn_valid = min(4, max(0, (a.Cout - n0 - nh * 64 + 15) / 16));
+    const bool active = (c0 + cq * 16 < a.Cin) && ntn_valid > 0;       // wave-uniform
+    // k-slot (q, j) <-> row 4q + j (j < 4) / 16 + 4q + (j - 4) of the step, for both operands (see wgrad_kernel)
+    const int l1 = 4 * q + (r >> 2);
+    const uint32_t colA = (uint32_t)((nh * 64 + 4 * (r & 3)) * 2);
+    const uint32_t colX = (uint32_t)(YB + 18 * SX + (cq * 16 + 4 * (r & 3)) * 2);      // (+18 squares: image index of square 0)
+    // rows p (< 81: in the tile at sbA) / p - 81 (in the tile at sbB) of a step whose first row is Fj within its board; `edge`:
+    // the board after sbA's lies outside the range -- its rows read the zero row 81 of sbA's dY tile (the product vanishes)
+    auto ptrs = [&](int Fj, uint32_t sbA, uint32_t sbB, bool edge) {
+        RowPtr o;
+        int p1 = l1 + Fj, p2 = p1 + 16;
+        const bool t1 = p1 >= KA_BOARD, t2 = p2 >= KA_BOARD;
+        p1 = t1 ? p1 - KA_BOARD : p1; p2 = t2 ? p2 - KA_BOARD : p2;
+        uint32_t b1 = t1 ? sbB : sbA, b2 = t2 ? sbB : sbA;
+        int y1r = p1, y2r = p2;
+        if (edge) { y1r = t1 ? KA_BOARD : p1; y2r = t2 ? KA_BOARD : p2; b1 = sbA; b2 = sbA; }
+        const int d1 = (p1 * 57) >> 9, d2 = (p2 * 57) >> 9;               // p / 9 for 0 <= p < 81
+        o.y1 = b1 + colA + (uint32_t)(y1r * SY); o.y2 = b2 + colA + (uint32_t)(y2r * SY);
+        o.x1 = b1 + colX + (uint32_t)((p1 + 8 * d1) * SX); o.x2 = b2 + colX + (uint32_t)((p2 + 8 * d2) * SX);
+        return o;
+    };
+    auto rd = [&](uint32_t off) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + off)); };
+    auto load_a = [&](const RowPtr& pt, int t) {
+        bf16x4 lo = rd(pt.y1 + t * 32), hi = rd(pt.y2 + t * 32);
+        return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_b = [&](const RowPtr& pt, int tap) {
+        const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * SX;
+        bf16x4 lo = rd(pt.x1 + toff), hi = rd(pt.x2 + toff);
+        return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // One k-step = 36 MFMAs.  On entry A[0..3] hold its four dY fragments and Bs[0], Bs[1] the X fragments of taps 0 and 1 --
+    // all fetched under the MFMAs of the step before.  X fragments run two taps ahead through five register slots; the
+    // last two taps go n-tile by n-tile, so that each dY fragment register is free a few MFMAs before the step ends and is
+    // refilled IN PLACE with the following step's fragment (no second fragment set: the slab leaves no room for one).
+    auto kstep = [&](const RowPtr& pc, const RowPtr& pn, bf16x8 (&A)[4], bf16x8 (&Bs)[5]) {
+#define KA_MM(tap_, t_, slot_) acc[tap_][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t_], Bs[slot_], acc[tap_][t_], 0, 0, 0)
+#define KA_TAP(tap_, slot_) KA_MM(tap_, 0, slot_); KA_MM(tap_, 1, slot_); KA_MM(tap_, 2, slot_); KA_MM(tap_, 3, slot_)
+        Bs[2] = load_b(pc, 2); KA_TAP(0, 0);
+        Bs[3] = load_b(pc, 3); KA_TAP(1, 1);
+        Bs[4] = load_b(pc, 4); KA_TAP(2, 2);
+        Bs[0] = load_b(pc, 5); KA_TAP(3, 3);
+        Bs[1] = load_b(pc, 6); KA_TAP(4, 4);
+        Bs[2] = load_b(pc, 7); KA_TAP(5, 0);
+        Bs[3] = load_b(pc, 8); KA_TAP(6, 1);
+        Bs[0] = load_b(pn, 0); KA_MM(7, 0, 2); KA_MM(7, 1, 2); KA_MM(8, 0, 3);
+        Bs[1] = load_b(pn, 1); A[0] = load_a(pn, 0); KA_MM(8, 1, 3);
+        A[1] = load_a(pn, 1); KA_MM(7, 2, 2); KA_MM(8, 2, 3);
+        A[2] = load_a(pn, 2); KA_MM(7, 3, 2); KA_MM(8, 3, 3);
+        A[3] = load_a(pn, 3);
+#undef KA_TAP
+#undef KA_MM
+        // issue order pinned: {LDS reads, MFMAs} groups exactly as written
+#define KA_WG_GRP(d_, m_) __builtin_amdgcn_sched_group_barrier(0x100, d_, 0); __builtin_amdgcn_sched_group_barrier(0x008, m_, 0)
+        KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4);
+        KA_WG_GRP(2, 3); KA_WG_GRP(4, 1); KA_WG_GRP(2, 2); KA_WG_GRP(2, 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#undef KA_WG_GRP
+    };
+
+    // ---- prologue: tiles 0 and 1 published, board 2 in registers
+    __syncthreads();                                    // zero fill complete
+    if (nb > 0) { load_board(bbeg); store_board(bbeg, 0); }
+    if (nb > 1) { load_board(bbeg + 1); store_board(bbeg + 1, TILE); }
+    if (nb > 2) load_board(bbeg + 2);
+    __syncthreads();
+
+    uint32_t sA = 0, sB = TILE, sC = 2 * TILE;          // slots of boards j, j + 1, j + 2
+    int Fj = 0, j = 0;                                  // first row of the next step within board j
+    RowPtr pc = ptrs(0, sA, sB, nb <= 1);
+    bf16x8 A[4], Bs[5];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) A[t] = load_a(pc, t);
+    Bs[0] = load_b(pc, 0); Bs[1] = load_b(pc, 1); Bs[2] = Bs[3] = Bs[4] = bf16x8{};
+    if (nb > 2) {                                       // iteration 0's staging: tile 2, board 3 into the registers
+        store_board(bbeg + 2, sC);
+        if (nb > 3) load_board(bbeg + 3);
+    }
+    // (inactive waves -- tiles beyond Cout / Cin of a small layer -- multiply zero-filled LDS columns: no run-time guard
+    //  around the MFMA stream, which would send the accumulators through scratch)
+    (void)ntn_valid; (void)active;
+    const int S = (KA_BOARD * nb + 31) / 32;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const int Fn = Fj + 32;
+        const bool adv = Fn >= KA_BOARD;                // the following step opens board j + 1
+        const RowPtr pn = ptrs(adv ? Fn - KA_BOARD : Fn, adv ? sB : sA, adv ? sC : sB, (adv ? j + 2 : j + 1) >= nb);
+        kstep(pc, pn, A, Bs);
+        pc = pn;
+        Fj = adv ? Fn - KA_BOARD : Fn;
+        if (adv) {
+            const uint32_t s0 = sA; sA = sB; sB = sC; sC = s0;
+            KA_LDS_BARRIER();                           // tile j + 2 is published; tile j may be rewritten
+            ++j;
+            if (j + 2 < nb) {
+                store_board(bbeg + j + 2, sC);
+                if (j + 3 < nb) load_board(bbeg + j + 3);
+            }
+        }
+    }
+
+    // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
+    if (c0 + cq * 16 < a.Cin) {
+        const int c = c0 + cq * 16 + r;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + (nh * 4 + t) * 16 + q * 4 + i;
+                    if (n < a.Cout && c < a.Cin)
+                        a.slab[(((size_t)split * 9 + tap) * a.Cout + n) * a.Cin + c] = acc[tap][t][i];
+                }
+    }
+}
+
 // dW[n][c][tap] (Cout, Cin_real, 3, 3) = sum_s slab[s][tap][n][c]; optional accumulate into dW.
 // One thread sums 4 consecutive c of one (tap, n) over the splits: the slab reads -- nsplit times the bytes of the
 // result -- are whole coalesced 16-byte pieces in slab order; only the 4-byte result stores are strided (by 9).
@@ -421,6 +647,20 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     int rc;
     const bool fused = in_scale || in_bias || relu;
 #define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
+    // bf16, 128-wide: the software-pipelined flat-K form (KA_WGRAD_V=1 selects the first form for A/B runs)
+    const char* ev = getenv("KA_WGRAD_V");
+    if (dtype == KA_DTYPE_BF16 && tn == 128 && !(ev && atoi(ev) == 1)) {
+        const size_t lds = 3 * (size_t)(WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + 11 * WG<bf16_t, 128>::PW * WG<bf16_t, 128>::SX);
+        static std::atomic<unsigned long long> d0{0}, d1{0};
+        if (fused) {
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<true>), d1, "wgrad (flat)")) return r2;
+            hipLaunchKernelGGL(wgrad_flat_kernel<true>, grid, dim3(512), lds, st, a);
+        } else {
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<false>), d0, "wgrad (flat)")) return r2;
+            hipLaunchKernelGGL(wgrad_flat_kernel<false>, grid, dim3(512), lds, st, a);
+        }
+        rc = ka_check_launch("wgrad (flat)");
+    } else
     if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
     else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);
 #undef KA_WG

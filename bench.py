@@ -214,7 +214,13 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
     print(f"[bench] spawning {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries exactly rank 0's JSON line: whatever else the ranks' libraries print there (gloo's "[Gloo] Rank 0 is
+    # connected to ..." banners) is passed on to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        dest = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        dest.write(line); dest.flush()
+    return proc.wait()
 
 
 def run_transformer(args, device):

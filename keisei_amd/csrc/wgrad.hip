@@ -362,14 +362,23 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
 // Bit-identical slabs (same products, same order within a lane's accumulator: steps in flat-row order).
 struct RowPtr { uint32_t y1, y2, x1, x2; };
 
-template <bool FUSED>
-__global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
+// NW = 8: 512 threads, 128 x 64 x 9 slab per workgroup (the CU is full: 2 waves x ~240 registers per SIMD, 160 KB of LDS).
+// NW = 4 ("lite"): 256 threads -- ONE wave per SIMD, which the in-step prefetch keeps busy without a partner -- and a
+//   128 x 32 x 9 slab: 256 registers per SIMD lane and 125 KB of LDS, so that a 512-thread board kernel workgroup (<= 80
+//   VGPRs, <= 32 KB: tail_bwd_fused, block_dx) fits on the SAME CU beside it.  The HBM-bound kernels of the backward then run
+//   under the weight gradients on all 256 CUs instead of sharing the chip by CU partition.
+template <bool FUSED, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
     typedef Elem<bf16_t> E;
     typedef bf16x8 vec16;
-    constexpr int TN = 128, NTHR = 512, P16 = 8;
-    constexpr int SY = WG<bf16_t, TN>::SY, SX = WG<bf16_t, TN>::SX, KROWS = WG<bf16_t, TN>::KROWS, PW = WG<bf16_t, TN>::PW;
-    constexpr int XSQ = 11 * PW, YB = KROWS * SY, TILE = YB + XSQ * SX;
-    constexpr int PY = TN * 2 / 16, PX = kTC * 2 / 16;
+    constexpr int TN = 128, NTHR = 64 * NW, P16 = 8, TC = 8 * NW;
+    // lite: the haloed X image is 10 squares wide (the right halo of a board row IS the left halo of the next) instead of 17:
+    // 103 KB of LDS instead of 125 -- measured with a synthetic MFMA kernel (tools/_diag/coresidency.py): a board kernel
+    // workgroup shares the CU beside 96 KB, not beside 124 KB -- at the price of one 2-way bank conflict in the transpose
+    // reads that straddle a board-row wrap (the 17-wide image has none: a wrap advances the square index by 9 = 1 mod 8)
+    constexpr int SY = WG<bf16_t, TN>::SY, SX = TC * 2 + 32, KROWS = WG<bf16_t, TN>::KROWS, PW = NW == 4 ? 10 : 17;
+    constexpr int XSQ = 11 * PW + 1, YB = KROWS * SY, TILE = (YB + XSQ * SX + 15) / 16 * 16;
+    constexpr int PY = TN * 2 / 16, PX = TC * 2 / 16;
     constexpr int NY = (KA_BOARD * PY + NTHR - 1) / NTHR, NX = (KA_BOARD * PX + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
     const int split = xcd + 8 * (slot / a.ntiles);
     if (split >= a.nsplit) return;
     const int tn = tile % a.ntn, tc = tile / a.ntn;
-    const int n0 = tn * TN, c0 = tc * kTC;
+    const int n0 = tn * TN, c0 = tc * TC;
     const int bbeg = split * a.boards_per_split;
     const int bend = min(a.B, bbeg + a.boards_per_split);
     const int nb = max(0, bend - bbeg);
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
     // k-slot (q, j) <-> row 4q + j (j < 4) / 16 + 4q + (j - 4) of the step, for both operands (see wgrad_kernel)
     const int l1 = 4 * q + (r >> 2);
     const uint32_t colA = (uint32_t)((nh * 64 + 4 * (r & 3)) * 2);
-    const uint32_t colX = (uint32_t)(YB + 18 * SX + (cq * 16 + 4 * (r & 3)) * 2);      // (+18 squares: image index of square 0)
+    const uint32_t colX = (uint32_t)(YB + (PW + 1) * SX + (cq * 16 + 4 * (r & 3)) * 2);  // (+PW+1 squares: image index of square 0)
     // rows p (< 81: in the tile at sbA) / p - 81 (in the tile at sbB) of a step whose first row is Fj within its board; `edge`:
     // the board after sbA's lies outside the range -- its rows read the zero row 81 of sbA's dY tile (the product vanishes)
     auto ptrs = [&](int Fj, uint32_t sbA, uint32_t sbB, bool edge) {
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         if (edge) { y1r = t1 ? KA_BOARD : p1; y2r = t2 ? KA_BOARD : p2; b1 = sbA; b2 = sbA; }
         const int d1 = (p1 * 57) >> 9, d2 = (p2 * 57) >> 9;               // p / 9 for 0 <= p < 81
         o.y1 = b1 + colA + (uint32_t)(y1r * SY); o.y2 = b2 + colA + (uint32_t)(y2r * SY);
-        o.x1 = b1 + colX + (uint32_t)((p1 + 8 * d1) * SX); o.x2 = b2 + colX + (uint32_t)((p2 + 8 * d2) * SX);
+        o.x1 = b1 + colX + (uint32_t)((p1 + (PW - 9) * d1) * SX); o.x2 = b2 + colX + (uint32_t)((p2 + (PW - 9) * d2) * SX);
         return o;
     };
     auto rd = [&](uint32_t off) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + off)); };
@@ -608,17 +617,32 @@ static int wgrad_tn(bool fused_input) {
     return 128;
 }
 
+// Which kernel takes a bf16 launch: 1 = wgrad_kernel (128 x 64 slab, 8 waves), 2 = the software-pipelined flat-K form with the
+// same slab, 3 = its 4-wave "lite" form (128 x 32 slab; leaves room for a co-resident board kernel workgroup).  KA_WGRAD_V.
+static int wgrad_variant(int dtype) {
+    if (dtype != KA_DTYPE_BF16 || wgrad_tn(false) != 128) return 1;
+    if (const char* e = getenv("KA_WGRAD_V")) { const int v = atoi(e); if (v >= 1 && v <= 3) return v; }
+    return 1;
+}
+
 // target_wgs: CUs to aim for (0 = all 256).  Fewer leaves CUs free for kernels that run concurrently on another
 // stream (the engine overlaps wgrad with the HBM-bound backward kernels and asks for 192).
-extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
+static int wgrad_splits_for(int B, int Cin, int Cout, int target_wgs, int tc) {
     const int tn = 128;            // the 64-wide variant has twice the tiles and twice the workgroups per CU: same count
-    const int tiles = ((Cout + tn - 1) / tn) * ((Cin + kTC - 1) / kTC);
+    const int tiles = ((Cout + tn - 1) / tn) * ((Cin + tc - 1) / tc);
     if (const char* e = getenv("KA_WGRAD_WGS")) { const int v = atoi(e); if (v > 0) target_wgs = v; }   // experiments
     int s = (target_wgs > 0 ? target_wgs : 256) / tiles;
     if (s < 1) s = 1;
     if (s > B) s = B;
     const int bps = (B + s - 1) / s;
     return (B + bps - 1) / bps;
+}
+
+// number of partial slabs the caller must provide room for ([splits][9][Cout][Cin] floats): the largest count any kernel
+// variant would use for this shape (the launch picks its own, never more)
+extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) {
+    const int a = wgrad_splits_for(B, Cin, Cout, target_wgs, kTC), b = wgrad_splits_for(B, Cin, Cout, 0, 32);
+    return a > b ? a : b;
 }
 
 template <typename T, int TN, bool FUSED>
@@ -639,31 +663,36 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad: scale/shift must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tn = wgrad_tn(in_scale || in_bias || relu);
-    const int nsplit = ka_wgrad_splits(B, Cin, Cout, target_wgs);
+    const int variant = wgrad_variant(dtype);
+    const int tcw = variant == 3 ? 32 : kTC;
+    // (the lite form always spreads over all CUs: board kernels share its CUs instead of taking the ones it leaves free)
+    const int nsplit = wgrad_splits_for(B, Cin, Cout, variant == 3 ? 0 : target_wgs, tcw);
     const int bps = (B + nsplit - 1) / nsplit;
-    const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + kTC - 1) / kTC);
+    const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + tcw - 1) / tcw);
     WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit};
     dim3 grid(8 * ntiles * ((nsplit + 7) / 8));
     int rc;
     const bool fused = in_scale || in_bias || relu;
 #define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
-    // bf16, 128-wide: the software-pipelined flat-K form (KA_WGRAD_V=1 selects the first form for A/B runs)
-    const char* ev = getenv("KA_WGRAD_V");
-    if (dtype == KA_DTYPE_BF16 && tn == 128 && !(ev && atoi(ev) == 1)) {
-        const size_t lds = 3 * (size_t)(WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + 11 * WG<bf16_t, 128>::PW * WG<bf16_t, 128>::SX);
-        static std::atomic<unsigned long long> d0{0}, d1{0};
-        if (fused) {
-            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<true>), d1, "wgrad (flat)")) return r2;
-            hipLaunchKernelGGL(wgrad_flat_kernel<true>, grid, dim3(512), lds, st, a);
-        } else {
-            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<false>), d0, "wgrad (flat)")) return r2;
-            hipLaunchKernelGGL(wgrad_flat_kernel<false>, grid, dim3(512), lds, st, a);
-        }
-        rc = ka_check_launch("wgrad (flat)");
-    } else
-    if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
+#define KA_WGF(NW_)                                                                                                         \
+    {                                                                                                                       \
+        const size_t lds = 3 * (((size_t)WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + (11 * (NW_ == 4 ? 10 : 17) + 1) * (16 * NW_ + 32) + 15) / 16 * 16); \
+        static std::atomic<unsigned long long> d0{0}, d1{0};                                                                \
+        if (fused) {                                                                                                        \
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<true, NW_>), d1, "wgrad (flat)")) return r2; \
+            hipLaunchKernelGGL((wgrad_flat_kernel<true, NW_>), grid, dim3(64 * NW_), lds, st, a);                           \
+        } else {                                                                                                            \
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<false, NW_>), d0, "wgrad (flat)")) return r2; \
+            hipLaunchKernelGGL((wgrad_flat_kernel<false, NW_>), grid, dim3(64 * NW_), lds, st, a);                          \
+        }                                                                                                                   \
+        rc = ka_check_launch("wgrad (flat)");                                                                               \
+    }
+    if (variant == 2) KA_WGF(8)
+    else if (variant == 3) KA_WGF(4)
+    else if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
     else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);
 #undef KA_WG
+#undef KA_WGF
     else { ka_set_error("wgrad: unknown dtype %d", dtype); return KA_ERR_ARG; }
     if (rc) return rc;
     const size_t total = (size_t)9 * Cout * (Cin / 4);

@@ -380,7 +380,7 @@ def test_rollout_helpers_of_the_loop_on_the_cpu():
     assert pend.finalize(torch.tensor([False, True, False]), torch.zeros(3, dtype=torch.bool), torch.zeros(3, dtype=torch.bool)) is None
 
 
-def test_bench_spawns_its_own_ranks(monkeypatch):
+def test_bench_spawns_its_own_ranks(monkeypatch, capsys):
     """bench.py --gpus N without a launcher: N children through torch.distributed.run on 127.0.0.1 with a free port, the
     parent's own arguments forwarded (VERDICT r2 'What's missing' 1; reference run.sh:309-310)."""
     import importlib.util
@@ -390,16 +390,22 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     spec.loader.exec_module(bench)
     seen = {}
 
-    def fake_run(cmd, env=None, **kw):
-        seen["cmd"], seen["env"] = cmd, env
-        return subprocess.CompletedProcess(cmd, 7)
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(["[Gloo] Rank 0 is connected to 1 peer ranks.\n", '{"metric": "x"}\n'])
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+        def wait(self):
+            return 7
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7                                   # the launcher's status is the parent's
+    printed = capsys.readouterr()
+    assert printed.out == '{"metric": "x"}\n' and "[Gloo]" in printed.err          # only the JSON line reaches stdout
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536

@@ -173,3 +173,71 @@ def test_split_merge_step_with_device_players_and_the_device_env():
     dead = legal.clone(); dead[5] = False
     with pytest.raises(RuntimeError, match="zero legal actions"):
         split_merge_step(obs, dead, torch.full((N,), 0, dtype=torch.uint8, device=DEV), learner, opponent_model=opp_a, learner_side=0)
+
+
+def test_pending_transitions_device_store_equals_the_host_store():
+    """The slot store of the split-merge protocol (keisei_amd/training/katago_loop.py; reference katago_loop.py:139-250): the
+    device backend (one `ka_pending_open` / `ka_pending_settle` launch per call, packed masks) against the host backend on the
+    same random protocol -- every settled row, the value labels, the slots left open; masks handed over as bool rows and as
+    the device env's packed rows; the fused reward accumulation; the "slot still taken" guard."""
+    import numpy as np
+    from keisei_amd.training.katago_loop import PendingTransitions, _compute_value_cats
+
+    N, shape, Asp = 37, (50, 9, 9), A
+    dev_store = PendingTransitions(N, shape, Asp, torch.device(DEV))
+    cpu_store = PendingTransitions(N, shape, Asp, torch.device("cpu"))
+    assert dev_store.legal_mask_bits.shape == (N, 352) and not hasattr(dev_store, "_legal_masks")
+    rng = np.random.default_rng(3)
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+    settled_rows = 0
+    for step in range(40):
+        lr = t(rng.integers(-1, 2, N).astype(np.float32))               # this step's learner-perspective rewards
+        dones = t(rng.random(N) < 0.2); terminated = dones & t(rng.random(N) < 0.7)
+        fin = t(rng.random(N) < 0.5) | dones
+        fuse = step % 2 == 0                                            # accumulate_reward() as its own call / inside finalize()
+        if not fuse:
+            dev_store.accumulate_reward(lr.to(DEV)); cpu_store.accumulate_reward(lr)
+        as_f = step % 3 != 0                                            # the loop passes float flags; bool flags work too
+        flag = (lambda x: x.float()) if as_f else (lambda x: x)
+        got = dev_store.finalize(fin.to(DEV), flag(dones).to(DEV), flag(terminated).to(DEV), accumulate=lr.to(DEV) if fuse else None)
+        want = cpu_store.finalize(fin, flag(dones), flag(terminated), accumulate=lr if fuse else None)
+        assert (got is None) == (want is None)
+        if want is not None:
+            settled_rows += want["env_ids"].numel()
+            for k in ("obs", "actions", "log_probs", "values", "rewards", "dones", "terminated", "score_targets", "env_ids",
+                      "legal_mask_bits", "value_cats", "legal_masks"):
+                assert torch.equal(got[k].cpu(), want[k]), (step, k)
+            assert torch.equal(got["value_cats"].cpu(), _compute_value_cats(want["rewards"], want["terminated"].bool(), torch.device("cpu")))
+            assert got["legal_masks"].dtype == torch.bool and got["legal_masks"].shape == (want["env_ids"].numel(), Asp)
+        assert torch.equal(dev_store.valid.cpu(), cpu_store.valid) and torch.equal(dev_store.rewards.cpu(), cpu_store.rewards)
+        # open new slots where none is pending
+        env_mask = t(rng.random(N) < 0.6) & ~cpu_store.valid
+        obs = t(rng.standard_normal((N, *shape)).astype(np.float32))
+        masks = t(rng.random((N, Asp)) < 0.05)
+        acts = t(rng.integers(0, Asp, N)); lp = t(-rng.random(N).astype(np.float32)); val = t(rng.standard_normal(N).astype(np.float32))
+        rew = t(rng.integers(-1, 2, N).astype(np.float32)); sc = t(rng.standard_normal(N).astype(np.float32))
+        cpu_store.create(env_mask, obs, acts, lp, val, masks, rew, sc)
+        if step % 2:                                                    # packed rows, as the device env hands them out
+            bits = torch.empty(N, 352, dtype=torch.int32, device=DEV)
+            from keisei_amd import _lib
+            _lib.call("ka_pack_mask_bits", masks.to(DEV), bits, N, Asp, _lib.stream_ptr())
+            dev_masks = bits
+        else:
+            dev_masks = masks.to(DEV)
+        dev_store.create(env_mask.to(DEV), obs.to(DEV), acts.to(DEV), lp.to(DEV), val.to(DEV), dev_masks, rew.to(DEV), sc.to(DEV))
+        for name in ("obs", "actions", "log_probs", "values", "rewards", "score_targets", "legal_mask_bits", "valid"):
+            assert torch.equal(getattr(dev_store, name).cpu(), getattr(cpu_store, name)), (step, name)
+    assert settled_rows > 100
+    assert torch.equal(dev_store.legal_masks.cpu(), cpu_store.legal_masks)
+    # a slot that is still open must not be opened again: nothing is written, RuntimeError like the reference's
+    taken = cpu_store.valid.clone()
+    assert bool(taken.any())
+    before = {k: getattr(dev_store, k).clone() for k in ("obs", "actions", "rewards", "legal_mask_bits", "valid")}
+    args = (torch.zeros(N, *shape), torch.zeros(N, dtype=torch.long), torch.zeros(N), torch.zeros(N),
+            torch.ones(N, Asp, dtype=torch.bool), torch.zeros(N), torch.zeros(N))
+    with pytest.raises(RuntimeError, match="already-valid pending transition"):
+        dev_store.create(torch.ones(N, dtype=torch.bool, device=DEV), *[a.to(DEV) for a in args])
+    with pytest.raises(RuntimeError, match="already-valid pending transition"):
+        cpu_store.create(torch.ones(N, dtype=torch.bool), *args)
+    for k, v in before.items():
+        assert torch.equal(getattr(dev_store, k), v), k

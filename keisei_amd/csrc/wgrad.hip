@@ -15,6 +15,7 @@
 //
 // Replaces: autograd's conv2d weight backward for se_resnet.py:50,52,110.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -367,16 +368,21 @@ struct RowPtr { uint32_t y1, y2, x1, x2; };
 //   128 x 32 x 9 slab: 256 registers per SIMD lane and 125 KB of LDS, so that a 512-thread board kernel workgroup (<= 80
 //   VGPRs, <= 32 KB: tail_bwd_fused, block_dx) fits on the SAME CU beside it.  The HBM-bound kernels of the backward then run
 //   under the weight gradients on all 256 CUs instead of sharing the chip by CU partition.
-template <bool FUSED, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
+// NW = 8, TC = 32 ("half"): 512 threads on a 128 x 32 x 9 slab; the two waves of a SIMD split the NINE TAPS (5 + 4) of the same
+//   64 x 16 output tile instead of owning different tiles: 80 accumulator registers per wave, <= 168 registers in all, so
+//   that two waves per SIMD (336 registers) leave room for a board kernel workgroup (2 x 80) -- the co-resident form.
+template <bool FUSED, int NW, int TC>
+__device__ __forceinline__ void wgrad_flat_body(const WgradArgs& a) {
     typedef Elem<bf16_t> E;
     typedef bf16x8 vec16;
-    constexpr int TN = 128, NTHR = 64 * NW, P16 = 8, TC = 8 * NW;
+    constexpr int TN = 128, NTHR = 64 * NW, P16 = 8;
+    constexpr int CT = TC / 16, NGRP = NW / (2 * CT), NTAP = NGRP == 1 ? 9 : 5;       // c-tiles, tap groups, taps per wave (at most)
+    static_assert(NGRP == 1 || NGRP == 2, "wgrad_flat_kernel: waves = 2 x c-tiles x {1, 2} tap groups");
     // lite: the haloed X image is 10 squares wide (the right halo of a board row IS the left halo of the next) instead of 17:
     // 103 KB of LDS instead of 125 -- measured with a synthetic MFMA kernel (tools/_diag/coresidency.py): a board kernel
     // workgroup shares the CU beside 96 KB, not beside 124 KB -- at the price of one 2-way bank conflict in the transpose
     // reads that straddle a board-row wrap (the 17-wide image has none: a wrap advances the square index by 9 = 1 mod 8)
-    constexpr int SY = WG<bf16_t, TN>::SY, SX = TC * 2 + 32, KROWS = WG<bf16_t, TN>::KROWS, PW = NW == 4 ? 10 : 17;
+    constexpr int SY = WG<bf16_t, TN>::SY, SX = TC * 2 + 32, KROWS = WG<bf16_t, TN>::KROWS, PW = TC == 32 ? 10 : 17;
     constexpr int XSQ = 11 * PW + 1, YB = KROWS * SY, TILE = (YB + XSQ * SX + 15) / 16 * 16;
     constexpr int PY = TN * 2 / 16, PX = TC * 2 / 16;
     constexpr int NY = (KA_BOARD * PY + NTHR - 1) / NTHR, NX = (KA_BOARD * PX + NTHR - 1) / NTHR;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int nh = wave & 1, cq = wave >> 1;
+    const int nh = wave & 1, cq = (wave >> 1) % CT, th = wave / (2 * CT);      // n half, c-tile, tap group (SIMD partners: w, w + 4)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // XCD-aware (tile, split) map: see wgrad_kernel
     const int tile = slot % a.ntiles;
     const int split = xcd + 8 * (slot / a.ntiles);
@@ -395,9 +401,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
     const int bend = min(a.B, bbeg + a.boards_per_split);
     const int nb = max(0, bend - bbeg);
 
-    f32x4 acc[9][4];
+    f32x4 acc[NTAP][4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < 3 * TILE / 16; i += NTHR) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
@@ -424,38 +430,40 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
         }
     };
     auto store_board = [&](int b, uint32_t tbase) {
-        f32x4 cf[FUSED ? 6 : 1];                 // scale | shift | per-board bias of this thread's 8 channels (re-read per board)
-        if (FUSED && xcol_ok) {
-            const int cc = c0 + xj * P16;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                cf[FUSED ? h : 0] = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + cc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
-                cf[FUSED ? 2 + h : 0] = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + cc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-                cf[FUSED ? 4 + h : 0] = a.in_bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b * a.Cin + cc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int row = (tid + i * NTHR) / PY;
             if (row < KA_BOARD) *reinterpret_cast<vec16*>(smem + tbase + row * SY + yj * 16) = ry[i];
         }
+        const bool xform = FUSED && xcol_ok && (has_aff || a.relu || a.in_bias);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int row = (tid + i * NTHR) / PX;
-            if (row < KA_BOARD) {
-                vec16 v = rx[i];
-                if (FUSED && xcol_ok && (has_aff || a.relu || a.in_bias)) {
+        for (int h = 0; h < 2; ++h) {
+            // scale | shift | per-board bias of four of this thread's 8 channels, re-read per board (L2) and four at a time:
+            // 12 registers alive during the transform instead of 24 across the whole MFMA loop
+            f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f}, bi4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (xform) {
+                const int cc = c0 + xj * P16 + 4 * h;
+                if (has_aff) { sc4 = *reinterpret_cast<const f32x4*>(a.in_scale + cc); sh4 = *reinterpret_cast<const f32x4*>(a.in_shift + cc); }
+                if (a.in_bias) bi4 = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b * a.Cin + cc);
+            }
 #pragma unroll
-                    for (int e = 0; e < P16; ++e) {
-                        float f = (float)v[e];
-                        if (has_aff) f = fmaf(f, cf[FUSED ? (e >> 2) : 0][e & 3], cf[FUSED ? 2 + (e >> 2) : 0][e & 3]);
+            for (int i = 0; i < NX; ++i) {
+                const int row = (tid + i * NTHR) / PX;
+                if (row >= KA_BOARD) continue;
+                if (xform) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float f = (float)rx[i][4 * h + e];
+                        if (has_aff) f = fmaf(f, sc4[e], sh4[e]);
                         if (a.relu) f = fmaxf(f, 0.f);
-                        if (a.in_bias) f += cf[FUSED ? 4 + (e >> 2) : 0][e & 3];
-                        v[e] = (__bf16)f;
+                        if (a.in_bias) f += bi4[e];
+                        rx[i][4 * h + e] = (__bf16)f;
                     }
                 }
-                const int sq = (row / 9 + 1) * PW + (row % 9) + 1;
-                *reinterpret_cast<vec16*>(smem + tbase + YB + sq * SX + xj * 16) = v;
+                if (h == 1) {
+                    const int sq = (row / 9 + 1) * PW + (row % 9) + 1;
+                    *reinterpret_cast<vec16*>(smem + tbase + YB + sq * SX + xj * 16) = rx[i];
+                }
             }
         }
     };
@@ -492,34 +500,35 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
         bf16x4 lo = rd(pt.x1 + toff), hi = rd(pt.x2 + toff);
         return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    // One k-step = 36 MFMAs.  On entry A[0..3] hold its four dY fragments and Bs[0], Bs[1] the X fragments of taps 0 and 1 --
-    // all fetched under the MFMAs of the step before.  X fragments run two taps ahead through five register slots; the
-    // last two taps go n-tile by n-tile, so that each dY fragment register is free a few MFMAs before the step ends and is
-    // refilled IN PLACE with the following step's fragment (no second fragment set: the slab leaves no room for one).
-    auto kstep = [&](const RowPtr& pc, const RowPtr& pn, bf16x8 (&A)[4], bf16x8 (&Bs)[5]) {
-#define KA_MM(tap_, t_, slot_) acc[tap_][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t_], Bs[slot_], acc[tap_][t_], 0, 0, 0)
-#define KA_TAP(tap_, slot_) KA_MM(tap_, 0, slot_); KA_MM(tap_, 1, slot_); KA_MM(tap_, 2, slot_); KA_MM(tap_, 3, slot_)
-        Bs[2] = load_b(pc, 2); KA_TAP(0, 0);
-        Bs[3] = load_b(pc, 3); KA_TAP(1, 1);
-        Bs[4] = load_b(pc, 4); KA_TAP(2, 2);
-        Bs[0] = load_b(pc, 5); KA_TAP(3, 3);
-        Bs[1] = load_b(pc, 6); KA_TAP(4, 4);
-        Bs[2] = load_b(pc, 7); KA_TAP(5, 0);
-        Bs[3] = load_b(pc, 8); KA_TAP(6, 1);
-        Bs[0] = load_b(pn, 0); KA_MM(7, 0, 2); KA_MM(7, 1, 2); KA_MM(8, 0, 3);
-        Bs[1] = load_b(pn, 1); A[0] = load_a(pn, 0); KA_MM(8, 1, 3);
-        A[1] = load_a(pn, 1); KA_MM(7, 2, 2); KA_MM(8, 2, 3);
-        A[2] = load_a(pn, 2); KA_MM(7, 3, 2); KA_MM(8, 3, 3);
-        A[3] = load_a(pn, 3);
-#undef KA_TAP
-#undef KA_MM
-        // issue order pinned: {LDS reads, MFMAs} groups exactly as written
+    // One k-step of a wave that owns taps T0 .. T0 + NT - 1 (NT x 4 MFMAs).  On entry A[0..3] hold its four dY fragments and
+    // Bs[0], Bs[1] the X fragments of its first two taps -- all fetched under the MFMAs of the step before.  X fragments run
+    // two taps ahead through five register slots; the last two taps go n-tile by n-tile, so that each dY fragment register is
+    // free a few MFMAs before the step ends and is refilled IN PLACE with the following step's fragment (no second fragment
+    // set: the slab leaves no room for one).
+#define KA_MM(tap_, t_, slot_) acc[(tap_) - T0][t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t_], Bs[slot_], acc[(tap_) - T0][t_], 0, 0, 0)
 #define KA_WG_GRP(d_, m_) __builtin_amdgcn_sched_group_barrier(0x100, d_, 0); __builtin_amdgcn_sched_group_barrier(0x008, m_, 0)
-        KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4); KA_WG_GRP(2, 4);
+    auto kstep = [&](auto t0c, auto ntc, const RowPtr& pc, const RowPtr& pn, bf16x8 (&A)[4], bf16x8 (&Bs)[5]) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(t0c)::value, NT = decltype(ntc)::value, LA = NT - 2, LB = NT - 1;   // the two tail taps
+#pragma unroll
+        for (int i = 0; i < NT - 2; ++i) {
+            Bs[(i + 2) % 5] = load_b(pc, T0 + i + 2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) KA_MM(T0 + i, t, i % 5);
+        }
+        Bs[0] = load_b(pn, T0); KA_MM(T0 + LA, 0, LA % 5); KA_MM(T0 + LA, 1, LA % 5); KA_MM(T0 + LB, 0, LB % 5);
+        Bs[1] = load_b(pn, T0 + 1); A[0] = load_a(pn, 0); KA_MM(T0 + LB, 1, LB % 5);
+        A[1] = load_a(pn, 1); KA_MM(T0 + LA, 2, LA % 5); KA_MM(T0 + LB, 2, LB % 5);
+        A[2] = load_a(pn, 2); KA_MM(T0 + LA, 3, LA % 5); KA_MM(T0 + LB, 3, LB % 5);
+        A[3] = load_a(pn, 3);
+        // issue order pinned: {LDS reads, MFMAs} groups exactly as written
+#pragma unroll
+        for (int i = 0; i < NT - 2; ++i) { KA_WG_GRP(2, 4); }
         KA_WG_GRP(2, 3); KA_WG_GRP(4, 1); KA_WG_GRP(2, 2); KA_WG_GRP(2, 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#undef KA_WG_GRP
     };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5;
+    typedef std::integral_constant<int, 9> I9;
+    const int tap0 = (NGRP == 2 && th == 1) ? 5 : 0;              // first tap of this wave (wave-uniform)
 
     // ---- prologue: tiles 0 and 1 published, board 2 in registers
     __syncthreads();                                    // zero fill complete
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
     bf16x8 A[4], Bs[5];
 #pragma unroll
     for (int t = 0; t < 4; ++t) A[t] = load_a(pc, t);
-    Bs[0] = load_b(pc, 0); Bs[1] = load_b(pc, 1); Bs[2] = Bs[3] = Bs[4] = bf16x8{};
+    Bs[0] = load_b(pc, tap0); Bs[1] = load_b(pc, tap0 + 1); Bs[2] = Bs[3] = Bs[4] = bf16x8{};
     if (nb > 2) {                                       // iteration 0's staging: tile 2, board 3 into the registers
         store_board(bbeg + 2, sC);
         if (nb > 3) load_board(bbeg + 3);
@@ -548,7 +557,11 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
         const int Fn = Fj + 32;
         const bool adv = Fn >= KA_BOARD;                // the following step opens board j + 1
         const RowPtr pn = ptrs(adv ? Fn - KA_BOARD : Fn, adv ? sB : sA, adv ? sC : sB, (adv ? j + 2 : j + 1) >= nb);
-        kstep(pc, pn, A, Bs);
+        if constexpr (NGRP == 1) kstep(I0{}, I9{}, pc, pn, A, Bs);
+        else {
+            if (th == 0) kstep(I0{}, I5{}, pc, pn, A, Bs);
+            else kstep(I5{}, I4{}, pc, pn, A, Bs);
+        }
         pc = pn;
         Fj = adv ? Fn - KA_BOARD : Fn;
         if (adv) {
@@ -562,21 +575,30 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) {
         }
     }
 
+#undef KA_MM
+#undef KA_WG_GRP
     // partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
     if (c0 + cq * 16 < a.Cin) {
         const int c = c0 + cq * 16 + r;
+        const int ntap = NGRP == 1 ? 9 : (th == 0 ? 5 : 4);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int k = 0; k < NTAP; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int n = n0 + (nh * 4 + t) * 16 + q * 4 + i;
-                    if (n < a.Cout && c < a.Cin)
-                        a.slab[(((size_t)split * 9 + tap) * a.Cout + n) * a.Cin + c] = acc[tap][t][i];
+                    if (k < ntap && n < a.Cout && c < a.Cin)
+                        a.slab[(((size_t)split * 9 + tap0 + k) * a.Cout + n) * a.Cin + c] = acc[k][t][i];
                 }
     }
 }
+
+template <bool FUSED, int NW, int TC>
+__global__ __launch_bounds__(64 * NW, 1) void wgrad_flat_kernel(WgradArgs a) { wgrad_flat_body<FUSED, NW, TC>(a); }
+// the co-resident form: 176 registers (2 x 176 + 2 x 80 = the 512 of a SIMD lane); the attribute takes a literal only
+__global__ __launch_bounds__(512, 3) void wgrad_half_plain_kernel(WgradArgs a) { wgrad_flat_body<false, 8, 32>(a); }
+__global__ __launch_bounds__(512, 3) void wgrad_half_fused_kernel(WgradArgs a) { wgrad_flat_body<true, 8, 32>(a); }
 
 // dW[n][c][tap] (Cout, Cin_real, 3, 3) = sum_s slab[s][tap][n][c]; optional accumulate into dW.
 // One thread sums 4 consecutive c of one (tap, n) over the splits: the slab reads -- nsplit times the bytes of the
@@ -621,7 +643,7 @@ static int wgrad_tn(bool fused_input) {
 // same slab, 3 = its 4-wave "lite" form (128 x 32 slab; leaves room for a co-resident board kernel workgroup).  KA_WGRAD_V.
 static int wgrad_variant(int dtype) {
     if (dtype != KA_DTYPE_BF16 || wgrad_tn(false) != 128) return 1;
-    if (const char* e = getenv("KA_WGRAD_V")) { const int v = atoi(e); if (v >= 1 && v <= 3) return v; }
+    if (const char* e = getenv("KA_WGRAD_V")) { const int v = atoi(e); if (v >= 1 && v <= 4) return v; }
     return 1;
 }
 
@@ -664,9 +686,9 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tn = wgrad_tn(in_scale || in_bias || relu);
     const int variant = wgrad_variant(dtype);
-    const int tcw = variant == 3 ? 32 : kTC;
+    const int tcw = variant >= 3 ? 32 : kTC;
     // (the lite form always spreads over all CUs: board kernels share its CUs instead of taking the ones it leaves free)
-    const int nsplit = wgrad_splits_for(B, Cin, Cout, variant == 3 ? 0 : target_wgs, tcw);
+    const int nsplit = wgrad_splits_for(B, Cin, Cout, variant == 3 ? 0 : target_wgs, tcw);    // (4: the caller's CU target)
     const int bps = (B + nsplit - 1) / nsplit;
     const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + tcw - 1) / tcw);
     WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit};
@@ -674,21 +696,33 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     int rc;
     const bool fused = in_scale || in_bias || relu;
 #define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
-#define KA_WGF(NW_)                                                                                                         \
+#define KA_WGF(NW_, TC_)                                                                                                    \
     {                                                                                                                       \
-        const size_t lds = 3 * (((size_t)WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + (11 * (NW_ == 4 ? 10 : 17) + 1) * (16 * NW_ + 32) + 15) / 16 * 16); \
+        const size_t lds = 3 * (((size_t)WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + (11 * (TC_ == 32 ? 10 : 17) + 1) * (2 * TC_ + 32) + 15) / 16 * 16); \
         static std::atomic<unsigned long long> d0{0}, d1{0};                                                                \
         if (fused) {                                                                                                        \
-            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<true, NW_>), d1, "wgrad (flat)")) return r2; \
-            hipLaunchKernelGGL((wgrad_flat_kernel<true, NW_>), grid, dim3(64 * NW_), lds, st, a);                           \
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<true, NW_, TC_>), d1, "wgrad (flat)")) return r2; \
+            hipLaunchKernelGGL((wgrad_flat_kernel<true, NW_, TC_>), grid, dim3(64 * NW_), lds, st, a);                      \
         } else {                                                                                                            \
-            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<false, NW_>), d0, "wgrad (flat)")) return r2; \
-            hipLaunchKernelGGL((wgrad_flat_kernel<false, NW_>), grid, dim3(64 * NW_), lds, st, a);                          \
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<false, NW_, TC_>), d0, "wgrad (flat)")) return r2; \
+            hipLaunchKernelGGL((wgrad_flat_kernel<false, NW_, TC_>), grid, dim3(64 * NW_), lds, st, a);                     \
         }                                                                                                                   \
         rc = ka_check_launch("wgrad (flat)");                                                                               \
     }
-    if (variant == 2) KA_WGF(8)
-    else if (variant == 3) KA_WGF(4)
+    if (variant == 2) KA_WGF(8, 64)
+    else if (variant == 3) KA_WGF(4, 32)
+    else if (variant == 4) {
+        const size_t lds = 3 * (((size_t)WG<bf16_t, 128>::KROWS * WG<bf16_t, 128>::SY + (11 * 10 + 1) * (2 * 32 + 32) + 15) / 16 * 16);
+        static std::atomic<unsigned long long> d0{0}, d1{0};
+        if (fused) {
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_half_fused_kernel), d1, "wgrad (half)")) return r2;
+            hipLaunchKernelGGL(wgrad_half_fused_kernel, grid, dim3(512), lds, st, a);
+        } else {
+            if (int r2 = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_half_plain_kernel), d0, "wgrad (half)")) return r2;
+            hipLaunchKernelGGL(wgrad_half_plain_kernel, grid, dim3(512), lds, st, a);
+        }
+        rc = ka_check_launch("wgrad (half)");
+    }
     else if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
     else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);
 #undef KA_WG

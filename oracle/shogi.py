@@ -42,6 +42,10 @@ def lib():
     return _lib
 
 
+def piece_value(piece_type: int, promoted: bool) -> int:
+    return lib().so_piece_value(piece_type, int(promoted))
+
+
 def _p(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -126,6 +130,7 @@ class OracleVecEnv:
     def impasse_score(self, i, color): return lib().so_impasse_score(self.h, i, color)
     def zone_count(self, i, color): return lib().so_zone_count(self.h, i, color)
     def material(self, i, who): return lib().so_material(self.h, i, who)
+    def piece_attacks(self, i, frm, piece, target): return bool(lib().so_piece_attacks(self.h, i, frm, piece, target))
     def repetition_count(self, i=0): return lib().so_repetition_count(self.h, i)
     def perft(self, depth, i=0): return int(lib().so_perft(self.h, i, depth))
     def play(self, i, frm, to, promote=False, drop=0): lib().so_play(self.h, i, frm, to, int(promote), drop)

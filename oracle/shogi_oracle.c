@@ -614,6 +614,9 @@ int so_impasse(void* h, int i, int* winner) { *winner = -1; return check_impasse
 int so_impasse_score(void* h, int i, int color) { return impasse_score(&((Env*)h)->g[i].pos, color); }
 int so_zone_count(void* h, int i, int color) { return zone_count(&((Env*)h)->g[i].pos, color); }
 int so_material(void* h, int i, int who) { return material_balance(&((Env*)h)->g[i].pos, who); }
+int so_piece_value(int type, int promoted) { return piece_value(type, promoted); }                  /* rules.rs:333-350 */
+/* does the piece byte `pc`, standing on `from` of game i's board, attack `target`?  (rules.rs:136-176; tests :1792-1919) */
+int so_piece_attacks(void* h, int i, int from, int pc, int target) { return piece_attacks_square(&((Env*)h)->g[i].pos, from, pc, target); }
 int so_result(void* h, int i, int* winner) { Game* g = &((Env*)h)->g[i]; *winner = g->winner; return g->result; }
 float so_reward(int result, int winner, int last_mover) { return reward_of(result, winner, last_mover); }
 int so_encode(int from, int to, int promote, int drop, int persp, int amode) { return encode_action((Mv){(uint8_t)from, (uint8_t)to, (uint8_t)promote, (uint8_t)drop}, persp, amode); }

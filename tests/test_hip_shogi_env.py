@@ -438,3 +438,37 @@ def test_device_env_reproduces_the_committed_playout():
 
     env, stats = _replay_golden(lambda n, mp: _env(n, mp), step)
     assert [env.episodes_completed, env.episodes_drawn, env.episodes_truncated] == stats[:3]
+
+
+def test_reference_vector_positions_on_the_device_env():
+    """The positions of tests/test_shogi_reference_vectors.py (known answers restated from rules.rs / game.rs / katago_observation.rs
+    with their reference lines) placed in the DEVICE env: same observation and mask as the oracle, and the reference's own numbers
+    read off the device's outputs -- legal-move counts from the mask, the check plane, the material balance and the reward of the
+    stalemate step from the step metadata."""
+    from tests.test_shogi_reference_vectors import POSITIONS, position
+    for name, (pieces, hands, side, want) in sorted(POSITIONS.items()):
+        kinds = {p & 15 | (p & WHITE) for _, _, p in pieces}
+        if KING not in kinds or (KING | WHITE) not in kinds:
+            continue                                                     # one-king score positions: no game to play
+        board, hnd, sd = position(pieces, hands, side)
+        dev, ref = _fixture(board, hnd, sd)
+        mask = _same_view(dev, ref)
+        cur = dev.current()
+        if "legal" in want:
+            assert int(cur.legal_masks[0].sum()) == want["legal"], name
+        if "in_check" in want:
+            assert bool(np.all(cur.observations[0][48] == (1.0 if want["in_check"] else 0.0))), name
+        if "material" in want and mask.any():
+            # rules.rs:968-1055 through vec_env.rs:371-374: after the mover's move the balance is reported for the mover
+            a = int(np.flatnonzero(mask)[0])
+            rd, rr = dev.step([a]), ref.step(np.array([a]))
+            assert int(rd.step_metadata.material_balance[0]) == int(rr["material_balance"][0])
+            m = S.decode(a, white=bool(sd))
+            if not m[3] and not board[m[1]]:                             # a quiet move: the balance is the table's, seen by the mover
+                assert int(rd.step_metadata.material_balance[0]) == (want["material"] if sd == 0 else -want["material"]), name
+    # game.rs:2051-2110 through a step: the rook arrives, White has no move and is not in check -> Checkmate{winner: Black}
+    pieces, hands, _, _ = POSITIONS["stalemate_white"]
+    pieces = [p for p in pieces if p[2] != ROOK] + [(0, 3, ROOK)]
+    dev, ref = _fixture(*position(pieces, hands, 0))
+    r = dev.step([S.encode(sq(0, 3), sq(8, 3))])
+    assert bool(r.terminated[0]) and int(r.step_metadata.termination_reason[0]) == S.R_CHECKMATE and float(r.rewards[0]) == 1.0

@@ -886,13 +886,19 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
             const int toff = toff_of(next_step);
 #pragma unroll
             for (int mt = 0; mt < kMTW; ++mt) {
+#ifndef KA_PC_NO_A
                 an[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+#else
+                an[mt] = ac[mt]; (void)toff;                 // ablation build (tools/_diag/build_variants.sh): no activation-fragment LDS reads
+#endif
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
             }
 #pragma unroll
             for (int mt = 0; mt < kMTW; ++mt) {
+#ifndef KA_PC_NO_A
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
         };
@@ -902,6 +908,10 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
 #pragma unroll
             for (int mt = 0; mt < kMTW; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
         }
+#ifdef KA_PC_NO_W
+#define wfrag(...) ((void)0)                                 // ablation build: the ring keeps its first fragments
+        if (u == 0) w3[0] = w3[1] = w0[0];
+#endif
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int s0 = tap * 4;
@@ -915,6 +925,9 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
             if (ahead) wfrag(kc, s0 + 6, w2);
             __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef KA_PC_NO_W
+#undef wfrag
+#endif
         if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
         KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete
         if (MASKED && kc) {

@@ -458,12 +458,27 @@ def main() -> None:
         dist.all_reduce = lambda t, *a, **k: None if t.dtype == torch.float64 else real(t, *a, **k)
         ms_nosync = timed5()
         dist.all_reduce = real
+        # how long the compute stream STALLS on each SyncBN statistics all-reduce: the collectives are issued asynchronously
+        # (the process group's stream) and waited for right before the coefficient kernel that reads them, with the independent
+        # global-pool chain launched in between where there is one; an event pair around every wait, two steps
+        engine = res["model"]._hip_engine
+        engine.sync_events = []
+        for i in range(2):
+            res["algo"]._fused_step(res["fs"], torch.arange(res["B"], device=device), device)
+        torch.cuda.synchronize()
+        pairs, engine.sync_events = engine.sync_events, None
+        stalls = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+        exposed = {"waits_per_step": len(stalls) // 2, "exposed_us_per_step": round(sum(stalls) / 2, 1),
+                   "median_us": round(stalls[len(stalls) // 2], 2) if stalls else None,
+                   "max_us": round(stalls[-1], 2) if stalls else None,
+                   "note": "stall of the compute stream per wait (event pair around work.wait()), world size 1: launch + stream hand-off, no wire time"}
         m = res["algo"]._fused_end(res["fs"])
         if rank == 0:
             print(json.dumps({"dist_dry_run": True, "backend": backend, "world": world, "collectives_per_step": counts,
                               "overlapped_gradient_exchange": res["fs"]["reducer"] is not None,
                               "ms_per_step_with_collectives_on_one_rank": round(ms_with, 2),
                               "ms_per_step_with_syncbn_allreduce_as_noop": round(ms_nosync, 2),
+                              "syncbn_allreduce_exposure": exposed,
                               "train_metrics": {k: round(v, 5) for k, v in m.items()}}), flush=True)
         dist.destroy_process_group()
         return

@@ -69,6 +69,7 @@ class SEResNetEngine:
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
         self.grad_reducer = None        # OverlappedGradReducer while a fused DDP step runs (hip/grad_reducer.py)
+        self.sync_events = None         # bench.py --dist-dry-run: event pairs around every wait for a SyncBN all-reduce
 
     # ------------------------------------------------------------------ helpers
     def _timed(self, kind: str, name: str, *args) -> None:
@@ -241,8 +242,48 @@ class SEResNetEngine:
             return dist.get_world_size() > 1 or os.environ.get("KA_FORCE_COLLECTIVES", "0") == "1"
         return False
 
-    def _bn_forward(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
+    def _allreduce_async(self, t):
+        """SyncBN statistics vector: all-reduce issued asynchronously (RCCL: on the process group's own stream, ordered after
+        the kernels already queued here), so that the independent launches the caller queues next run under it; the caller
+        hands the returned handle to ``_allreduce_wait`` right before the first kernel that reads ``t``."""
+        return dist.all_reduce(t, async_op=True)
+
+    def _allreduce_wait(self, work) -> None:
+        if work is None:
+            return
+        ev = self.sync_events
+        if ev is None or not torch.cuda.is_available():
+            work.wait()
+            return
+        # bench.py --dist-dry-run: how long the compute stream actually stalls on each statistics collective
+        stream = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        work.wait()
+        b.record(stream)
+        ev.append((a, b))
+
+    def _bn_forward_begin(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
+        """first half of a BatchNorm layer's statistics: the stage-1 reduce and, under SyncBatchNorm, the asynchronous
+        all-reduce of the packed vector.  Launches queued between this and ``_bn_forward_end`` overlap the collective."""
+        if not train:
+            return (bn, None, None, None, C, count, train, device, st)
+        sync = self._sync_group(bn)
+        ws = self._red_ws(C, device)
+        sums = work = None
+        if sync:
+            # [sum y | sum y^2 | count] in ONE vector = one all-reduce per layer (the count rides along, written by the
+            # reduce kernel itself); the dependency chain conv -> statistics -> next conv forbids merging layers
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
+            _call("ka_sync_reduce", bsum, rows_b, sq, rows_s, C, float(count), sums, None, ws, st)
+            work = self._allreduce_async(sums)
+        else:
+            _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, None, ws, st)     # stage 1 only: partials stay in ws
+        return (bn, sums, work, ws, C, count, train, device, st)
+
+    def _bn_forward_end(self, ctx):
         """returns scale, shift, mean, invstd (fp32 [C])"""
+        bn, sums, work, ws, C, count, train, device, st = ctx
         if not train and self._evalc_live is not None and id(bn) in self._evalc_live:
             scale, shift = self._evalc_live[id(bn)]
             return scale, shift, None, None
@@ -250,17 +291,6 @@ class SEResNetEngine:
         if not train:
             _call("ka_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C, st)
             return scale, shift, None, None
-        sync = self._sync_group(bn)
-        ws = self._red_ws(C, device)
-        if sync:
-            # [sum y | sum y^2 | count] in ONE vector = one all-reduce per layer (the count rides along, written by the
-            # reduce kernel itself); the dependency chain conv -> statistics -> next conv forbids merging layers
-            sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
-            _call("ka_sync_reduce", bsum, rows_b, sq, rows_s, C, float(count), sums, None, ws, st)
-            dist.all_reduce(sums)
-            count_t = sums[2 * C:]
-        else:
-            _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, None, ws, st)     # stage 1 only: partials stay in ws
         mean = torch.empty(C, device=device); invstd = torch.empty(C, device=device)
         track = bn.track_running_stats and bn.running_mean is not None
         if track and bn.momentum is None:
@@ -268,13 +298,17 @@ class SEResNetEngine:
         else:
             momentum = float(bn.momentum if bn.momentum is not None else 0.0)
         rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if track else (None, None, None)
-        if sync:
-            _call("ka_bn_coeffs", sums, float(count), count_t, bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
+        if sums is not None:
+            self._allreduce_wait(work)
+            _call("ka_bn_coeffs", sums, float(count), sums[2 * C:], bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
                   scale, shift, mean, invstd, C, st)
         else:
             _call("ka_bn_coeffs_parts", ws, float(count), bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
                   scale, shift, mean, invstd, C, st)
         return scale, shift, mean, invstd
+
+    def _bn_forward(self, bn, bsum, rows_b, sq, rows_s, C, count, train, device, st):
+        return self._bn_forward_end(self._bn_forward_begin(bn, bsum, rows_b, sq, rows_s, C, count, train, device, st))
 
     def _gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, st, abf=0, bbf=0, cbf=0, relu=0, acc=0, ns=1):
         _call("ka_gemm", A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, abf, bbf, cbf, relu, acc, ns, st)
@@ -529,11 +563,16 @@ class SEResNetEngine:
             _call("ka_tower_eval", x, pool, out, pool_out, tower_tab, len(m.blocks), B, C, blk0.global_fc[0].out_features,
                   blk0.se_fc1.out_features, code, st)
             x, pool = out, pool_out
-        fside = self._wgrad_side(1, dev)[0] if self.overlap_wgrad else None
+        # The global-pool FC chain (13 us at B = 4096) runs on the main stream, between conv1's statistics reduce and its
+        # coefficient kernel.  Forked onto the side stream (KA_FC_SIDE=1, the round-1/2 arrangement) it cannot share a CU with
+        # the persistent conv workgroups anyway: it either takes CUs first and delays conv1, or waits until conv1 has drained
+        # (336 us per launch in the round-2 trace).  Small batches (rollout inference without the tower kernel) keep the
+        # fork: their conv workgroups leave CUs free.
+        fc_side = os.environ.get("KA_FC_SIDE")
+        fside = self._wgrad_side(1, dev)[0] if (self.overlap_wgrad and (fc_side == "1" or (fc_side is None and B < 512))) else None
         main_f = torch.cuda.current_stream(dev)
         for i, blk in enumerate(m.blocks if tower_tab is None else ()):
-            # g = global_fc(pool(x)) is only needed by conv2: run its two small GEMMs on the side stream while conv1
-            # occupies the main stream
+            # g = global_fc(pool(x)) is only needed by conv2
             if fside is not None:
                 ev = torch.cuda.Event(); ev.record(main_f)
                 with torch.cuda.stream(fside):
@@ -544,13 +583,16 @@ class SEResNetEngine:
                 g.record_stream(main_f)
                 if g1 is not None:
                     g1.record_stream(main_f)
-            else:
-                _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], st, keep)
             y1 = new_act(C)
             bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
                   bsum1 if train else None, sq1 if train else None, B, C, C, code, st)
-            sc1, sh1, mu1, is1 = self._bn_forward(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
+            bn1_ctx = self._bn_forward_begin(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
+            if fside is None:
+                # on the main stream BEHIND conv1's statistics reduce: under SyncBatchNorm the chain (independent of bn1)
+                # runs while the layer's statistics all-reduce is on the wire
+                _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], st, keep)
+            sc1, sh1, mu1, is1 = self._bn_forward_end(bn1_ctx)
             if fside is not None:
                 main_f.wait_event(g_ready)               # global-pool FC chain ran on the side stream beside conv1
             y2 = new_act(C)
@@ -594,22 +636,33 @@ class SEResNetEngine:
         return logits, v, s, (sv if keep else None)
 
     # ------------------------------------------------------------------ backward
-    def _bn_backward(self, bn, s1p, s2p, rows, C, count, mu, istd, train, grads, prefix, dev, st):
-        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
-        k = torch.empty(3 * C, device=dev)
+    def _bn_backward_begin(self, bn, s1p, s2p, rows, C, count, train, dev, st):
+        """stage-1 reduce of the two BatchNorm-backward sums and, under SyncBatchNorm, their asynchronous all-reduce"""
         ws = self._red_ws(C, dev)
         if train and self._sync_group(bn):
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
             gsums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
             _call("ka_sync_reduce", s1p, rows, s2p, rows, C, float(count), gsums, sums, ws, st)
-            dist.all_reduce(gsums)
+            return (sums, gsums, self._allreduce_async(gsums), ws)
+        _call("ka_pair_reduce", s1p, s2p, rows, C, None, ws, st)             # stage 1 only: partials stay in ws
+        return (None, None, None, ws)
+
+    def _bn_backward_end(self, ctx, bn, C, count, mu, istd, train, grads, prefix, dev, st):
+        sums, gsums, work, ws = ctx
+        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
+        k = torch.empty(3 * C, device=dev)
+        if gsums is not None:
+            self._allreduce_wait(work)
             _call("ka_bn_bwd_coeffs", sums, gsums, float(count), gsums[2 * C:], bn.weight, mu, istd, dgam, dbet, k, C,
                   1 if train else 0, st)
         else:
-            _call("ka_pair_reduce", s1p, s2p, rows, C, None, ws, st)             # stage 1 only: partials stay in ws
             _call("ka_bn_bwd_coeffs_parts", ws, float(count), bn.weight, mu, istd, dgam, dbet, k, C, 1 if train else 0, st)
         grads[prefix + ".weight"], grads[prefix + ".bias"] = dgam, dbet
         return k
+
+    def _bn_backward(self, bn, s1p, s2p, rows, C, count, mu, istd, train, grads, prefix, dev, st):
+        ctx = self._bn_backward_begin(bn, s1p, s2p, rows, C, count, train, dev, st)
+        return self._bn_backward_end(ctx, bn, C, count, mu, istd, train, grads, prefix, dev, st)
 
     def backward(self, sv: _Saved, dlogits, dv, ds) -> Dict[str, torch.Tensor]:
         m = self.model
@@ -758,8 +811,10 @@ class SEResNetEngine:
                 dW2 = conv_grad(blk.conv2.weight, i, False)
                 self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
+                # the global-pool chain's backward (independent of bn1's coefficients) runs under bn1's statistics all-reduce
+                bn1_ctx = self._bn_backward_begin(blk.bn1, ep1, ep2, rows, C, count, train, dev, st)
                 dpool_x = self._gpool_bwd(i, blk, dg, g1, bpool, grads, pre, st, fc_tr)
-                k1 = self._bn_backward(blk.bn1, ep1, ep2, rows, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
+                k1 = self._bn_backward_end(bn1_ctx, blk.bn1, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
                 dy1, dxc = new_act(), new_act()
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dh, y1, k1, dy1, packs[pre + "conv1"][1], dxc, None,
                             None, None, None, None, None, None, None, B, C, C, code, st)

@@ -166,3 +166,6 @@ def test_rccl_initialises_and_carries_the_step_collectives():
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["collectives_per_step"]["syncbn"] == 2 * (2 + 2 * 2) and out["collectives_per_step"]["gradient"] >= 3
     assert all(map(lambda v: v == v, out["train_metrics"].values()))
+    # every statistics all-reduce is issued asynchronously and waited for once, right before its coefficient kernel
+    exp = out["syncbn_allreduce_exposure"]
+    assert exp["waits_per_step"] == out["collectives_per_step"]["syncbn"] and exp["exposed_us_per_step"] >= 0.0

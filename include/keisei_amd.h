@@ -146,6 +146,16 @@ int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, con
  * gradient is 0 where sigma == 0), using xpool = ka_block_tail_fwd's pool of x; dpool is (B,3C). */
 int ka_block_dx(const void* dxc, const void* dout, const void* out, const void* x, const float* xpool, const float* dpool,
                 void* dx, int B, int C, int dtype, void* stream);
+/* The two calls that meet at a block boundary of the backward pass in ONE launch: ka_block_dx of the block above (its
+ * result dx is this block's output gradient, its x this block's output: se_resnet.py:89-90, residual + ReLU) followed by
+ * ka_tail_bwd_fused of this block -- x, dxc, dout_up, out_up, y are read once and dx, dz written (7 activation passes instead
+ * of 9).  dx is rounded to the activation dtype before it is used: every output equals the two-launch sequence bit for bit.
+ * dxc may be NULL; dout_up and out_up are both NULL where the gradient enters the tower from the heads (se_resnet.py:147-157). */
+int ka_block_dx_tail_bwd_supported(int C, int H, int dtype);
+int ka_block_dx_tail_bwd(const void* dxc, const void* dout_up, const void* out_up, const void* x, const float* xpool,
+                         const float* dpool, void* dx, const void* y, const float* scale, const float* shift, const float* se,
+                         const float* se1, const float* W2, const float* W1, const float* mean, const float* invstd, void* dz,
+                         float* dse, float* dh, float* s1p, float* s2p, int B, int C, int H, int dtype, void* stream);
 
 /* ---- small dense layers: nn.Linear / 1x1 nn.Conv2d forward and backward (se_resnet.py:57-61,65-66,120-130) --
  * C[M,N] (+)= act(opA(A)[M,K] * opB(B)[K,N] + bias); opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k], likewise opB.

@@ -472,13 +472,23 @@ __global__ __launch_bounds__(kThreads) void tail_bwd_dz_kernel(
 // workgroups share a CU (the kernel waits on memory: more boards in flight per CU is what it needs), and the second
 // reduction through LDS is gone.
 // The FC weight gradients (dW2 = dse^T se1, dW1 = dh^T sqz) stay with the GEMM kernels, off the data-gradient chain.
-template <typename T, int MAXSQ, int NTHR>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6 ? 6 : 4))) void tail_bwd_fused_kernel(
+// DX = the block-input gradient of the block ABOVE (block_dx16_kernel) computed in the same pass: this block's `dout` is
+// that kernel's result dx and this block's `out` is that block's input x, so the fused launch reads x, dxc, dout', out', y
+// (5 tensors) and writes dx, dz instead of reading 4 + 3 and writing 1 + 1: two activation tensors less HBM traffic per
+// block.  dx is rounded to T before it is used, so dz / dse / dh / s1 / s2 are bit for bit those of the two launches.
+struct DxArgs {
+    const void* dxc; const void* dout_up; const void* out_up;   // conv1 data gradient, gradient and output of the block above (null for the heads)
+    const float* xpool; const float* dpool;                     // pooled statistics of x, gradient wrt them
+    void* dx;
+};
+
+template <typename T, int MAXSQ, int NTHR, bool DX>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 6 && !DX) ? 6 : 4))) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
     const float* __restrict__ W2, const float* __restrict__ W1, const float* __restrict__ mean,
     const float* __restrict__ invstd, T* __restrict__ dz, float* __restrict__ dse_out, float* __restrict__ dh_out,
-    float* __restrict__ s1p, float* __restrict__ s2p, int C, int H) {
+    float* __restrict__ s1p, float* __restrict__ s2p, int C, int H, DxArgs dxa) {
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int P16 = E::kPer16;
@@ -498,9 +508,22 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
     float* v_dsq = v_dh + H;                 // [C]
     float* v_gate = v_dsq + C;               // [C]: sigmoid of the gate logits, one evaluation per channel
     float* v_mu = v_gate + C;                // [C]: BatchNorm mean (read per square: eight registers fewer across the loop)
+    float* v_dx = v_mu + C;                  // DX: [5][C] pooling-gradient coefficients of block_dx16_kernel (read per square)
     const size_t base = (size_t)b * KA_BOARD * C + c0;
 
     for (int c = tid; c < C; c += NTHR) v_mu[c] = mean[c];
+    if constexpr (DX) {
+        const float* xp = dxa.xpool + (size_t)b * 4 * C;
+        const float* dp = dxa.dpool + (size_t)b * 3 * C;
+        for (int c = tid; c < C; c += NTHR) {
+            const float sd = xp[2 * C + c];
+            v_dx[c] = xp[c];
+            v_dx[C + c] = xp[C + c];
+            v_dx[2 * C + c] = dp[c] / KA_BOARD;
+            v_dx[3 * C + c] = dp[C + c] / xp[3 * C + c];
+            v_dx[4 * C + c] = sd > 0.f ? dp[2 * C + c] / (KA_BOARD * sd) : 0.f;
+        }
+    }
     float sg[P16], sgy[P16], sy[P16];
 #pragma unroll
     for (int e = 0; e < P16; ++e) { sg[e] = 0.f; sgy[e] = 0.f; sy[e] = 0.f; }
@@ -511,17 +534,51 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
         const int p = slice + i * nsl;
         du[i] = vec16{};
         if (p < KA_BOARD) {
-            const vec16 g = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C));
+            vec16 g;
             const vec16 o = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(out + base + (size_t)p * C));
             const vec16 yv = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(y + base + (size_t)p * C));
             float gf[P16], of[P16], yf[P16];
-            E::unpack(g, gf); E::unpack(o, of); E::unpack(yv, yf);
+            E::unpack(o, of);
+            if constexpr (DX) {
+                // dx = pooling gradients + conv1 data gradient + the residual branch of the block above (block_dx16_kernel, term for term)
+                const T* dxc = static_cast<const T*>(dxa.dxc);
+                const T* dup = static_cast<const T*>(dxa.dout_up);
+                const T* oup = static_cast<const T*>(dxa.out_up);
+                vec16 t1 = vec16{}, t2 = vec16{}, t3 = vec16{};
+                if (dxc) t1 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C));
+                if (dup) {
+                    t2 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dup + base + (size_t)p * C));
+                    t3 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(oup + base + (size_t)p * C));
+                }
+#pragma unroll
+                for (int e = 0; e < P16; ++e) {
+                    const float v = of[e];
+                    gf[e] = v_dx[2 * C + c0 + e] + v_dx[4 * C + c0 + e] * (v - v_dx[c0 + e]) + (v == v_dx[C + c0 + e] ? v_dx[3 * C + c0 + e] : 0.f);
+                }
+                if (dxc) {
+                    float t[P16];
+                    E::unpack(t1, t);
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) gf[e] += t[e];
+                }
+                if (dup) {
+                    float t[P16], o2[P16];
+                    E::unpack(t2, t); E::unpack(t3, o2);
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) gf[e] += o2[e] > 0.f ? t[e] : 0.f;
+                }
+                g = E::pack(gf);
+                __builtin_nontemporal_store(g, reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
+            } else {
+                g = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C));
+            }
+            E::unpack(g, gf); E::unpack(yv, yf);
 #pragma unroll
             for (int e = 0; e < P16; ++e) {
                 const float yc = yf[e] - v_mu[c0 + e];
                 gf[e] = of[e] > 0.f ? gf[e] : 0.f;
                 sg[e] += gf[e];
-                sgy[e] += gf[e] * yc;
+                sgy[e] = fmaf(gf[e], yc, sgy[e]);      // (explicit: both instantiations must round alike)
                 sy[e] += yc;
             }
             du[i] = E::pack(gf);             // exact: a masked copy of dout
@@ -546,7 +603,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
         for (int s = 0; s < nrow; ++s) { tg += red_g[s * C + c]; tgy += red_gy[s * C + c]; ty += red_y[s * C + c]; }
         red_g[c] = tg; red_gy[c] = tgy; red_y[c] = ty;        // row 0 now holds the totals (read again by this thread only)
         const float scl = scale[c];
-        const float t1 = scl * tgy + (shift[c] + mean[c] * scl) * tg;     // sum_p du*z
+        const float t1 = fmaf(scl, tgy, fmaf(mean[c], scl, shift[c]) * tg);     // sum_p du*z
         const float sgm = sigmoidf_(se[(size_t)b * 2 * C + c]);
         const float d1 = t1 * sgm * (1.f - sgm);
         v_gate[c] = sgm;
@@ -557,7 +614,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
     {   // dh[j] = sum_k dse[k] W2[k][j]: thread (j, part) sums every parts-th k
         const int parts = NTHR / H, j = tid % H, part = tid / H;
         float a = 0.f;
-        for (int k = part; k < 2 * C; k += parts) a += v_dse[k] * W2[(size_t)k * H + j];
+        for (int k = part; k < 2 * C; k += parts) a = fmaf(v_dse[k], W2[(size_t)k * H + j], a);
         v_part[tid] = a;
     }
     __syncthreads();
@@ -572,11 +629,11 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
     __syncthreads();
     for (int c = tid; c < C; c += NTHR) {
         float a = 0.f;
-        for (int j = 0; j < H; ++j) a += v_dh[j] * W1[(size_t)j * C + c];
+        for (int j = 0; j < H; ++j) a = fmaf(v_dh[j], W1[(size_t)j * C + c], a);
         v_dsq[c] = a;
         const float gate = v_gate[c], add = a / KA_BOARD;
-        s1p[(size_t)b * C + c] = gate * red_g[c] + KA_BOARD * add;
-        s2p[(size_t)b * C + c] = invstd[c] * (gate * red_gy[c] + add * red_y[c]);
+        s1p[(size_t)b * C + c] = fmaf(gate, red_g[c], KA_BOARD * add);
+        s2p[(size_t)b * C + c] = invstd[c] * fmaf(gate, red_gy[c], add * red_y[c]);
     }
     __syncthreads();
     float gate[P16], add[P16];
@@ -589,7 +646,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
             float df[P16];
             E::unpack(du[i], df);
 #pragma unroll
-            for (int e = 0; e < P16; ++e) df[e] = df[e] * gate[e] + add[e];
+            for (int e = 0; e < P16; ++e) df[e] = fmaf(df[e], gate[e], add[e]);
             __builtin_nontemporal_store(E::pack(df), reinterpret_cast<vec16*>(dz + base + (size_t)p * C));
         }
     }
@@ -1111,6 +1168,38 @@ extern "C" int ka_tail_bwd_fused_supported(int C, int H, int dtype) {
     return n > 0 && n <= 11;
 }
 
+// the fused block-boundary launch: shapes whose board tile fits 128 registers with the pooling coefficients (6 squares per thread;
+// every fp32 shape the single-pass tail covers)
+extern "C" int ka_block_dx_tail_bwd_supported(int C, int H, int dtype) {
+    int nt = 0;
+    const int n = tail_fused_plan(C, H, dtype, &nt);
+    return n > 0 && (dtype == KA_DTYPE_F32 ? n <= 11 : n <= 6);
+}
+
+static int tail_bwd_launch(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
+                           const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
+                           const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                           int H, int dtype, const DxArgs* dxp, hipStream_t st) {
+    int nt = 0;
+    const int nsq = tail_fused_plan(C, H, dtype, &nt);
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
+    const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
+    const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 3 * C + (dxp ? 5 * C : 0)) * sizeof(float);
+    KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
+    const DxArgs dxa = dxp ? *dxp : DxArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#define KA_TAIL_LAUNCH(MAXSQ, NTHR, DX_) \
+    KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR, DX_>), dim3(B), dim3(NTHR), lds, st, \
+                                            (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, \
+                                            invstd, (T*)dz, dse, dh, s1p, s2p, C, H, dxa))
+#define KA_TAIL_PICK(DX_) \
+    if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512, DX_); else KA_TAIL_LAUNCH(11, 512, DX_); } \
+    else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256, DX_); else KA_TAIL_LAUNCH(11, 256, DX_); }
+    if (dxp) { KA_TAIL_PICK(true) } else { KA_TAIL_PICK(false) }
+#undef KA_TAIL_PICK
+#undef KA_TAIL_LAUNCH
+    return ka_check_launch(dxp ? "block_dx_tail_bwd" : "tail_bwd_fused");
+}
+
 extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* y, const float* scale, const float* shift,
                                  const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
                                  const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
@@ -1119,20 +1208,26 @@ extern "C" int ka_tail_bwd_fused(const void* dout, const void* out, const void* 
                "tail_bwd_fused: null tensor");
     KA_REQUIRE(B > 0 && ka_tail_bwd_fused_supported(C, H, dtype), "tail_bwd_fused: unsupported shape C=%d H=%d", C, H);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int nt = 0;
-    const int nsq = tail_fused_plan(C, H, dtype, &nt);
-    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
-    const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
-    const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 3 * C) * sizeof(float);
-    KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
-#define KA_TAIL_LAUNCH(MAXSQ, NTHR) \
-    KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
-                                            (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, \
-                                            invstd, (T*)dz, dse, dh, s1p, s2p, C, H))
-    if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512); else KA_TAIL_LAUNCH(11, 512); }
-    else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256); else KA_TAIL_LAUNCH(11, 256); }
-#undef KA_TAIL_LAUNCH
-    return ka_check_launch("tail_bwd_fused");
+    return tail_bwd_launch(dout, out, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, nullptr, st);
+}
+
+// The block-input gradient of the block above and this block's backward tail in one launch (see DxArgs):
+//   dx  = ka_block_dx(dxc, dout_up, out_up, x, xpool, dpool)          (written: the block above's `dout` is read again by
+//                                                                       the residual branch one block further down)
+//   ... = ka_tail_bwd_fused(dout = dx, out = x, y, ...)
+// dxc may be NULL; dout_up / out_up are both NULL for the gradient that enters the tower from the heads.
+extern "C" int ka_block_dx_tail_bwd(const void* dxc, const void* dout_up, const void* out_up, const void* x, const float* xpool,
+                                    const float* dpool, void* dx, const void* y, const float* scale, const float* shift,
+                                    const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
+                                    const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                                    int H, int dtype, void* stream) {
+    KA_REQUIRE(x && xpool && dpool && dx && ((dout_up == nullptr) == (out_up == nullptr)), "block_dx_tail_bwd: bad block_dx arguments");
+    KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
+               "block_dx_tail_bwd: null tensor");
+    KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd: unsupported shape C=%d H=%d", C, H);
+    DxArgs dxa{dxc, dout_up, out_up, xpool, dpool, dx};
+    return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
+                           static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ka_relu_bn_bwd_reduce(const void* dh, const void* y, const float* scale, const float* shift,

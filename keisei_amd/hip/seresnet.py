@@ -729,8 +729,17 @@ class SEResNetEngine:
                          ("policy_bn1.weight", m.policy_bn1.weight), ("policy_bn1.bias", m.policy_bn1.bias),
                          ("policy_conv1.weight", m.policy_conv1.weight)):
                 grads[n] = torch.zeros_like(t)
-        dout = new_act()
-        _call("ka_block_dx", dxc, None, None, x, pool, dpool, dout, B, C, code, st)
+        # The block-input gradient of the block above and the backward tail of the next block meet at every block boundary:
+        # one launch for the two (ka_block_dx_tail_bwd: 7 activation passes instead of 9, same results bit for bit) wherever the
+        # shape allows it.  `pend` = the ka_block_dx call still owed: (dxc, dout_up, out_up, x, xpool, dpool, dx).
+        Hse = m.blocks[0].se_fc1.weight.shape[0] if len(m.blocks) > 0 else 0
+        fuse_dx = (len(m.blocks) > 0 and os.environ.get("KA_DX_TAIL", "1") != "0"
+                   and bool(_lib.query("ka_block_dx_tail_bwd_supported", C, Hse, code)))
+        pend = (dxc, None, None, x, pool, dpool, new_act())
+        dout = pend[6]
+        if not fuse_dx:
+            _call("ka_block_dx", *pend, B, C, code, st)
+            pend = None
 
         s1p = torch.empty(B, C, device=dev); s2p = torch.empty(B, C, device=dev)
         # overlapped wgrad leaves a quarter of the CUs to the concurrent main-stream kernels (measured best: 192 of 256)
@@ -785,7 +794,14 @@ class SEResNetEngine:
             dse = torch.empty(B, 2 * C, device=dev)
             dz = new_act()
             H = blk.se_fc1.weight.shape[0]
-            if _lib.query("ka_tail_bwd_fused_supported", C, H, code):
+            if pend is not None:
+                # (pend[3], the input of the block above, IS this block's output `out`)
+                dse1 = torch.empty(B, H, device=dev)
+                _call("ka_block_dx_tail_bwd", *pend, y2, sc2, sh2, se, se1, blk.se_fc2.weight, blk.se_fc1.weight, mu2, is2,
+                      dz, dse, dse1, s1p, s2p, B, C, H, code, st)
+                self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
+                self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st, need_dx=False)
+            elif _lib.query("ka_tail_bwd_fused_supported", C, H, code):
                 # one read of dout / out / y2: SE-gate reductions, the per-board FC chain backward and dz in one kernel
                 dse1 = torch.empty(B, H, device=dev)
                 _call("ka_tail_bwd_fused", dout, out, y2, sc2, sh2, se, se1, blk.se_fc2.weight, blk.se_fc1.weight, mu2, is2,
@@ -841,7 +857,11 @@ class SEResNetEngine:
                 grads[pre + "conv1.weight"] = dW1
                 conv_grads_done(i)
                 dx = new_act() if side is not None else dh
-            _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
+            if fuse_dx and i > 0:
+                pend = (dxc, dout, out, bx, bpool, dpool_x, dx)        # joins the next block's tail
+            else:
+                _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
+                pend = None
             dout = dx
 
         # ---- stem

@@ -566,6 +566,43 @@ def test_tail_bwd_fused_matches_unfused_sequence(dtn, B, C, H):
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,H,heads", [(3, 32, 4, False), (5, 128, 8, True), (4, 256, 16, False), (515, 256, 16, False)])
+def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
+    """ka_block_dx_tail_bwd == ka_block_dx followed by ka_tail_bwd_fused (dout = its dx, out = its x), every output bit for bit;
+    `heads`: the form that enters the tower (no residual branch above)."""
+    dt = DT[dtn]
+    code = _lib.dtype_code(dt)
+    if not _lib.query("ka_block_dx_tail_bwd_supported", C, H, code):
+        pytest.skip("shape not covered by the fused boundary launch")
+    g = torch.Generator().manual_seed(77 + C + B)
+    A = lambda: to_nhwc(torch.randn(B, C, 9, 9, generator=g), dt)
+    dxc, dout_up, out_up, y = A(), A(), A(), A()
+    x = to_nhwc(torch.relu(torch.randn(B, C, 9, 9, generator=g)), dt)          # a block output: ReLU'd, with exact zeros and ties
+    pool = torch.empty(B, 4 * C, device=DEV)
+    _lib.call("ka_pool_fwd", x, pool, B, C, code, st())
+    dpool = torch.randn(B, 3 * C, generator=g).to(DEV)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (0.3 * torch.randn(C, generator=g)).to(DEV)
+    mu, istd = (0.1 * torch.randn(C, generator=g)).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    se, se1 = torch.randn(B, 2 * C, generator=g).to(DEV), torch.randn(B, H, generator=g).to(DEV)
+    W2 = (torch.randn(2 * C, H, generator=g) / H ** 0.5).to(DEV)
+    W1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(DEV)
+    up = (None, None) if heads else (dout_up, out_up)
+
+    def outs():
+        return (torch.empty_like(x), torch.empty_like(x), torch.empty(B, 2 * C, device=DEV), torch.empty(B, H, device=DEV),
+                torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV))
+    dx_r, dz_r, dse_r, dh_r, s1_r, s2_r = outs()
+    _lib.call("ka_block_dx", dxc, *up, x, pool, dpool, dx_r, B, C, code, st())
+    _lib.call("ka_tail_bwd_fused", dx_r, x, y, sc, sh, se, se1, W2, W1, mu, istd, dz_r, dse_r, dh_r, s1_r, s2_r, B, C, H, code, st())
+    dx, dz, dse, dh, s1, s2 = outs()
+    _lib.call("ka_block_dx_tail_bwd", dxc, *up, x, pool, dpool, dx, y, sc, sh, se, se1, W2, W1, mu, istd, dz, dse, dh, s1, s2,
+              B, C, H, code, st())
+    torch.cuda.synchronize()
+    for name, a, b in (("dx", dx, dx_r), ("dz", dz, dz_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
+        assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("dtn", ["f32", "bf16"])
 def test_pack_multi_equals_single_packs(dtn):
     """ka_pack_conv3x3_multi (all layers in one launch) writes byte-identical packs to per-layer ka_pack_conv3x3 calls."""
     dt = DT[dtn]

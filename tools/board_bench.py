@@ -31,6 +31,13 @@ cases = [
     ("block_tail_fwd (2R+1W)", 3, lambda: _lib.call("ka_block_tail_fwd", y, sc, sh, se, x, out, pool, B, C, code, st())),
     ("block_dx (4R+1W)", 5, lambda: _lib.call("ka_block_dx", dxc, dout, out, x, pool, dpool, dz, B, C, code, st())),
 ]
+dx2 = torch.empty_like(dz)
+cases += [
+    ("block_dx + tail_bwd, two launches (7R+2W)", 9, lambda: (_lib.call("ka_block_dx", dxc, dout, out, x, pool, dpool, dx2, B, C, code, st()),
+                                                              _lib.call("ka_tail_bwd_fused", dx2, x, y, sc, sh, se, se1, W2, W1, mu, istd, dz, dse, dh, s1, s2, B, C, H, code, st()))),
+    ("block_dx_tail_bwd, one launch (5R+2W)", 7, lambda: _lib.call("ka_block_dx_tail_bwd", dxc, dout, out, x, pool, dpool, dx2, y, sc, sh, se, se1, W2, W1, mu, istd,
+                                                                   dz, dse, dh, s1, s2, B, C, H, code, st())),
+]
 for name, passes, fn in cases:
     ms = timeit(fn)
-    print(f"{name:28s} {ms * 1e3:8.1f} us  {passes * abytes / ms / 1e9:6.2f} TB/s", flush=True)
+    print(f"{name:44s} {ms * 1e3:8.1f} us  {passes * abytes / ms / 1e9:6.2f} TB/s", flush=True)

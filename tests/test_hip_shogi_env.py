@@ -472,3 +472,80 @@ def test_reference_vector_positions_on_the_device_env():
     dev, ref = _fixture(*position(pieces, hands, 0))
     r = dev.step([S.encode(sq(0, 3), sq(8, 3))])
     assert bool(r.terminated[0]) and int(r.step_metadata.termination_reason[0]) == S.R_CHECKMATE and float(r.rewards[0]) == 1.0
+
+
+def test_python_api_tests_of_the_reference_restated():
+    """shogi-gym/tests/test_vec_env.py, the classes that do not need the spectator dictionaries, restated on the device env with the
+    constructor defaults the reference's tests use (46 planes, 13 527 actions); the reference line beside each block."""
+    first = lambda masks: [int(np.flatnonzero(m)[0]) for m in masks]
+    # TestVecEnvSfen: test_vec_env.py:73-80, :82-87, :89-94, :96-102, :104-112
+    env = VecEnv(num_envs=3, max_ply=100)
+    r = env.reset()
+    sfens = env.get_sfens()
+    assert isinstance(sfens, list) and len(sfens) == 3 and all(isinstance(s, str) for s in sfens)
+    assert sfens[0] == sfens[1] and "lnsgkgsnl" in sfens[0].lower()
+    assert [env.get_sfen(i) for i in range(3)] == sfens
+    for bad in (3, 100):
+        with pytest.raises(IndexError):
+            env.get_sfen(bad)
+    before = env.get_sfen(0)
+    env.step(first(r.legal_masks))
+    assert env.get_sfen(0) != before
+    # TestVecEnvEpisodeStats: :149-152, :154-157, :159-166, :168-174, :176-184, :186-196
+    env = VecEnv(num_envs=1, max_ply=100)
+    env.reset()
+    assert env.mean_episode_length == 0.0 and env.truncation_rate == 0.0
+    env = VecEnv(num_envs=2, max_ply=1)
+    r = env.reset()
+    env.step(first(r.legal_masks))
+    assert env.episodes_completed == 2 and env.truncation_rate == 1.0 and env.mean_episode_length == 1.0
+    env = VecEnv(num_envs=1, max_ply=1)
+    r = env.reset()
+    for _ in range(5):
+        r = env.step(first(r.legal_masks))
+    assert env.episodes_completed == 5 and env.mean_episode_length == 1.0
+    env.reset_stats()
+    assert env.mean_episode_length == 0.0 and env.truncation_rate == 0.0
+    # TestVecEnvStepping: :199-216 shapes, :218-222 wrong count, :224-231 illegal action, :233-243 metadata
+    env = VecEnv(num_envs=2, max_ply=100)
+    r = env.reset()
+    s = env.step(first(r.legal_masks))
+    assert s.observations.shape == (2, 46, 9, 9) and s.legal_masks.shape == (2, 13527)
+    assert s.rewards.shape == s.terminated.shape == s.truncated.shape == (2,)
+    m = s.step_metadata
+    assert m.captured_piece.shape == m.termination_reason.shape == m.ply_count.shape == (2,)
+    # :275-284 terminal observations, :286-298 current players (White after the first move)
+    assert s.terminal_observations.shape == (2, 46, 9, 9) and s.terminal_observations.dtype == np.float32
+    assert s.current_players.shape == (2,) and s.current_players.dtype == np.uint8 and s.current_players.tolist() == [1, 1]
+    with pytest.raises(ValueError):
+        env.step([0])
+    env1 = VecEnv(num_envs=1, max_ply=100)
+    r1 = env1.reset()
+    with pytest.raises(RuntimeError):
+        env1.step([int(np.flatnonzero(~r1.legal_masks[0])[0])])
+    # :245-255 twenty random steps of four games, :300-316 rewards are -1, 0 or 1 over thirty steps
+    env = VecEnv(num_envs=4, max_ply=50)
+    masks = env.reset().legal_masks
+    rng = np.random.default_rng(5)
+    for _ in range(30):
+        s = env.step([int(rng.choice(np.flatnonzero(mk))) for mk in masks])
+        assert set(np.unique(s.rewards).tolist()) <= {-1.0, 0.0, 1.0}
+        masks = s.legal_masks
+    # :257-273 auto-reset after a truncation: start-position masks (30 moves), non-zero terminal observation, Black to move
+    env = VecEnv(num_envs=1, max_ply=1)
+    s = env.step(first(env.reset().legal_masks))
+    assert bool(s.truncated[0]) and int(s.legal_masks[0].sum()) == 30
+    assert s.terminal_observations.shape == (1, 46, 9, 9) and float(s.terminal_observations[0].sum()) != 0.0 and int(s.current_players[0]) == 0
+    # TestVecEnvObservation: :320-334 different moves give different observations, :336-346 piece planes are binary,
+    # :348-353 mask width = action space, :355-370 a second reset() gives the first one's state
+    env = VecEnv(num_envs=2, max_ply=100)
+    r = env.reset()
+    obs1, masks1 = r.observations.copy(), r.legal_masks.copy()
+    assert obs1.dtype == np.float32 and set(np.unique(obs1[0, :28]).tolist()) <= {0.0, 1.0}
+    assert masks1.shape == (2, env.action_space_size)
+    acts = [int(np.flatnonzero(masks1[0])[0]), int(np.flatnonzero(masks1[1])[-1])]
+    assert acts[0] != acts[1]
+    s = env.step(acts)
+    assert not np.array_equal(s.observations[0], s.observations[1])
+    r2 = env.reset()
+    assert np.array_equal(r2.observations, obs1) and np.array_equal(r2.legal_masks, masks1)

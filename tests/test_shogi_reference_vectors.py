@@ -352,3 +352,66 @@ def test_legal_moves_round_trip_through_the_spatial_mapper_for_twelve_plies():
             m = S.decode(int(a), white)
             assert m is not None and S.encode(m[0], m[1], bool(m[2]), m[3], white) == int(a)
         mask = e.step([int(idxs[0])])["legal_masks"]
+
+
+# ---------------------------------------------------------------- step_result.rs: TerminationReason codes
+def test_termination_reason_codes():
+    """step_result.rs:103-107 in progress 0, :109-115 checkmate 1, :117-121 repetition 2, :123-129 perpetual check 3,
+    :131-137 impasse with a winner 4, :139-143 impasse draw 4, :145-149 max moves 5 -- the u8 the env writes into
+    step_metadata.termination_reason (the oracle's result codes are these numbers)."""
+    assert (S.R_PROGRESS, S.R_CHECKMATE, S.R_REPETITION, S.R_PERPETUAL, S.R_IMPASSE, S.R_MAXMOVES) == (0, 1, 2, 3, 4, 5)
+    e = OracleVecEnv(2, 1)                                           # max_ply 1: the first move truncates -> code 5
+    _, mask = e.reset()
+    r = e.step(np.array([int(np.flatnonzero(m)[0]) for m in mask], dtype=np.int64))
+    assert r["termination_reason"].tolist() == [5, 5] and r["truncated"].tolist() == [True, True]
+    e = OracleVecEnv(1, 100)
+    _, mask = e.reset()
+    r = e.step(np.array([int(np.flatnonzero(mask[0])[0])], dtype=np.int64))
+    assert r["termination_reason"].tolist() == [0]
+
+
+def test_plane_counts_and_action_space_sizes():
+    """katago_observation.rs:116-123 (50 channels), :125-132 (buffer 50 * 81 = 4050); observation.rs:248-252 (46 channels);
+    action_mapper.rs:241-246 and shogi-gym/tests/test_action_mapper.py:10-11 (13 527); spatial_action_mapper.rs:373-379 (11 259)."""
+    for omode, planes in (("katago", 50), ("default", 46)):
+        for amode, size in (("spatial", 11259), ("default", 13527)):
+            obs, mask = OracleVecEnv(1, 100, omode, amode).reset()
+            assert obs.shape == (1, planes, 9, 9) and obs[0].size == planes * 81 and mask.shape == (1, size)
+    assert S.A_SIZE == 11259 and S.A_DEFAULT == 13527
+
+
+def test_white_drops_exclude_dead_squares():
+    """movegen.rs:1163-1213: White's pawn / lance never drop on row 8, White's knight never on rows 7-8."""
+    e = _env(*position(KINGS, [(1, PAWN, 1), (1, KNIGHT, 1), (1, LANCE, 1)], side=1))
+    drops = [(to, kind) for _, to, _, kind in e.pseudo_moves(0, 1, boards_only=False) if kind]       # (from, to, promote, drop type)
+    assert {k for _, k in drops} == {PAWN, KNIGHT, LANCE}
+    for to, kind in drops:
+        row = to // 9
+        if kind in (PAWN, LANCE):
+            assert row != 8
+        if kind == KNIGHT:
+            assert row < 7
+
+
+def test_random_games_stay_consistent():
+    """game.rs:2159-2215 plays 100 xorshift-random games of up to 200 plies and recomputes its incremental hash, attack map and
+    pawn columns after every move.  The oracle keeps no incremental state (it recomputes everything per call), so what remains
+    of that test here is its walk: the same 100 seeds and move choices, every position reached must keep 40 pieces with two kings,
+    a legal-move count equal to the mask's popcount, and an attack map that agrees with in_check."""
+    for seed in range(100):
+        e = OracleVecEnv(1, 200)
+        _, mask = e.reset()
+        x = seed
+        for _ply in range(200):
+            legal = np.flatnonzero(mask[0])
+            assert len(legal) == e.legal_count(0) > 0
+            x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF; x ^= x >> 7; x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+            r = e.step(np.array([int(legal[x % len(legal)])], dtype=np.int64))
+            mask = r["legal_masks"]
+            if r["terminated"][0] or r["truncated"][0]:
+                break
+            board, hands, side, _ = e.state(0)
+            assert int((board != 0).sum() + hands.sum()) == 40 and int(((board & 15) == KING).sum()) == 2
+            amap = e.attack_map(0).reshape(2, 81)
+            king = int(np.flatnonzero(board == (KING | (WHITE if side else 0)))[0])
+            assert (amap[1 - side][king] > 0) == e.in_check(0, side)

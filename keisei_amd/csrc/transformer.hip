@@ -60,6 +60,7 @@ struct NtArgs {
     int c_bf16, relu, ksplit_len;              // ksplit_len < K: gridDim.z slabs of fp32 [z][M][ldc], no epilogue
     int lds_epilogue;                          // full bf16 tiles leave through LDS as whole-row 16-byte pieces (KA_TF_LDS_EPI=0: off)
     float drop_p; unsigned long long seed;     // dropout on the (bias, relu)'d value before the residual add
+    int row0;                                  // gemm_nt_k256_kernel: first row of this launch's panels (the ragged last panel is its own launch)
 };
 
 constexpr int kBM = 128, kBN = 128, kBK = 64, kLdsStride = kBK * 2 + 16;     // bytes per tile row (144: 16 rows x 16 B land on 64 different banks)
@@ -256,6 +257,148 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ NT GEMM, K = 256: activations stationary in registers
+// With d_model = 256 an output tile of gemm_nt_bf16_kernel has four k-tiles: prologue, four barriers and the epilogue of a
+// 128 x 128 tile take 13.7 us for 1 us of MFMAs, and the N = 1024 products (FFN linear1, the input gradient of linear2) ran at
+// 1.5 TB/s of their 850 MB (profiles/r03_transformer_by_shape.txt).  Here the contraction is turned inside out: a 256-thread
+// workgroup owns 128 token rows and keeps them -- 32 rows x 256 k per wave = 16 operand fragments, 64 registers -- for its
+// whole life, and walks ALL the output columns in chunks of 64: the chunk's weights (64 x 256, 32 KB from L2) sit in one of
+// two LDS buffers, the next chunk is in flight in registers meanwhile, one barrier per chunk.  Per chunk and wave 32 LDS
+// fragment reads feed 64 MFMAs; what leaves the kernel is the output, in 32-byte runs per lane (the weight rows of a chunk are
+// permuted so that a lane owns 16 consecutive columns of its row).  Same products in the same k order as
+// gemm_nt_bf16_kernel and the same epilogue statements: results are bit-identical (tests/test_hip_transformer.py).
+constexpr int kKsK = 256, kKsCols = 64, kKsRows = 128, kKsStride = kKsK * 2 + 32;      // 544-byte weight rows: conflict-free ds_read_b128
+constexpr int kKsLds = 2 * kKsCols * kKsStride;                                         // + N floats of bias behind the two buffers
+
+// FULL: every row of the panel exists; RES / ACT: the epilogue reads a residual / a saved activation.  They are template
+// parameters (and N is a multiple of 64, the bias sits in LDS) so that the NUMBER of vector-memory instructions per chunk is
+// a compile-time constant: loads, stores and their waits share one in-order counter, and with a run-time count the compiler
+// must wait `vmcnt(0)` for the next chunk's weights -- i.e. for the output stores just issued (measured: 4.1 us per chunk for
+// 0.5 us of MFMAs).  With static counts the wait for the weights leaves the chunk's stores in flight.
+template <bool FULL, bool RES, bool ACT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_k256_kernel(NtArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char ks_smem[];
+    float* lbias = reinterpret_cast<float*>(ks_smem + kKsLds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int m0 = g.row0 + blockIdx.x * kKsRows + wave * 32;
+    for (int i = tid; i < g.N; i += 256) lbias[i] = g.bias ? g.bias[i] : 0.f;
+    // ---- this wave's 32 rows, all of K: X[rt][ks] = rows m0 + rt*16 + r, k = ks*32 + 8q .. +7
+    bf16x8 X[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = m0 + rt * 16 + r;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            X[rt][ks] = (FULL || m < g.M) ? *reinterpret_cast<const bf16x8*>(g.A + (size_t)m * g.lda + ks * 32 + q * 8) : bf16x8{};
+    }
+    // ---- weight chunk staging: 64 rows x 32 pieces, eight per thread.  MFMA tile ct, row 4*qq + i of the chunk is output column
+    // (ct >> 1)*32 + qq*8 + (ct & 1)*4 + i: lane qq then owns columns qq*8 .. +7 of each half of the chunk, and the four lanes
+    // of a token row write one whole 64-byte sector per store instruction
+    const int spc = tid & 31, srow0 = tid >> 5;                      // piece (16 B) and first of 8 rows (stride 8)
+    // (macros, not lambdas over a shared array: hipcc kept such an array in scratch)
+    const uint16_t* wsrc = g.B + (size_t)srow0 * g.ldb + spc * 8;
+    uint32_t wdst[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int nl = srow0 + 8 * h;                                // column within the chunk = hh*32 + qq*8 + c1*4 + i
+        const int L = ((nl >> 5) * 2 + ((nl >> 2) & 1)) * 16 + ((nl >> 3) & 3) * 4 + (nl & 3);      // LDS row (hh*2 + c1)*16 + 4*qq + i
+        wdst[h] = (uint32_t)(L * kKsStride + spc * 16);
+    }
+#define KA_WLOAD(W_, n0_)                                                                                       \
+    _Pragma("unroll") for (int h = 0; h < 8; ++h)                                                               \
+        W_[h] = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)((n0_) + 8 * h) * g.ldb);
+#define KA_WSTORE(W_, buf_)                                                                                     \
+    _Pragma("unroll") for (int h = 0; h < 8; ++h)                                                               \
+        *reinterpret_cast<bf16x8*>(ks_smem + (buf_) * (kKsCols * kKsStride) + wdst[h]) = W_[h];
+    const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(g.drop_p), key = drop_key(g.seed);
+    const int nchunks = g.N / kKsCols;
+    {
+        bf16x8 w0[8];
+        KA_WLOAD(w0, 0)
+        KA_WSTORE(w0, 0)
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1, n0 = c * kKsCols;
+        bf16x8 wr[8];                                                   // (a plain vector type: an array of HIP's uint4 structs stayed in scratch)
+        KA_WLOAD(wr, min(c + 1, nchunks - 1) * kKsCols)              // (the last iteration re-reads its own chunk: a static count)
+        // the epilogue's residual / activation pieces are requested before the MFMAs that hide their latency
+        bf16x8 rres[RES ? 4 : 1], ract[ACT ? 4 : 1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = FULL ? m0 + rt * 16 + r : min(m0 + rt * 16 + r, g.M - 1);
+                const size_t ob = (size_t)m * g.ldc + n0 + h * 32 + q * 8;
+                if (RES) rres[RES ? rt * 2 + h : 0] = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(g.residual) + ob);
+                if (ACT) ract[ACT ? rt * 2 + h : 0] = *reinterpret_cast<const bf16x8*>(static_cast<const uint16_t*>(g.relu_act) + ob);
+            }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* wb = ks_smem + buf * (kKsCols * kKsStride) + r * kKsStride + q * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + ct * 16 * kKsStride + ks * 64);
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, X[0][ks], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, X[1][ks], acc[1][ct], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane (r, q) holds, for row tile rt and half h of the chunk, columns n0 + h*32 + q*8 .. +7
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int nb = n0 + h * 32 + q * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lbias + nb), b1 = *reinterpret_cast<const f32x4*>(lbias + nb + 4);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int m = m0 + rt * 16 + r;
+                const size_t ob = (size_t)m * g.ldc + nb;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = acc[rt][2 * h][i] + b0[i]; v[4 + i] = acc[rt][2 * h + 1][i] + b1[i]; }
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (g.drop_p > 0.f) {
+                    if ((unsigned long long)g.M * (unsigned long long)g.ldc <= 0xFFFFFFFFull) {      // (uniform) one 32-bit hash per element pair
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {             // ob is even: elements e, e + 1 share a hash
+                            const uint32_t hsh = hash32((((uint32_t)ob + e) >> 1) * 0x9E3779B1U + key);
+                            v[e] *= (hsh & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+                            v[e + 1] *= (hsh >> 16) >= thresh ? inv_keep : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= keep_scale(g.seed, ob + e, thresh, inv_keep);
+                    }
+                }
+                if (ACT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)ract[ACT ? rt * 2 + h : 0][e] > 0.f ? v[e] : 0.f;
+                }
+                if (RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rres[RES ? rt * 2 + h : 0][e];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                if (FULL || m < g.M) *reinterpret_cast<bf16x8*>(static_cast<uint16_t*>(g.C) + ob) = o;
+            }
+        }
+        KA_WSTORE(wr, buf ^ 1)
+        __syncthreads();
+    }
+#undef KA_WLOAD
+#undef KA_WSTORE
 }
 
 // ------------------------------------------------------------------ TN GEMM: C[n][k] = sum_m A[m][n] * B[m][k]
@@ -1368,6 +1511,34 @@ static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* b
     NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, relu_act, M, N, K, lda, ldb, ldc,
              c_bf16, relu, len, 1, drop_p, seed};
     if (const char* e = getenv("KA_TF_LDS_EPI")) g.lds_epilogue = atoi(e);
+    // K = 256 (d_model of BASELINE config 5), bf16 output, whole 16-column runs: the activation-stationary form (KA_TF_K256=0: off)
+    const char* ek = getenv("KA_TF_K256");
+    const bool k256 = !(ek && atoi(ek) == 0);
+    if (k256 && K == kKsK && nsplit == 1 && c_bf16 && N % kKsCols == 0 && N <= 4096 && ldc % 8 == 0 && lda >= K && ldb >= K) {
+        const size_t lds = kKsLds + (size_t)N * sizeof(float);
+        const int full = M / kKsRows, tail = M % kKsRows ? 1 : 0;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+#define KA_K256(FULL_, RES_, ACT_, GRID_, ARGS_)                                                                              \
+        {                                                                                                                     \
+            static std::atomic<unsigned long long> d{0};                                                                      \
+            if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_k256_kernel<FULL_, RES_, ACT_>), d, "tf_gemm_nt (k256)")) return rc; \
+            hipLaunchKernelGGL((gemm_nt_k256_kernel<FULL_, RES_, ACT_>), dim3(GRID_), dim3(256), lds, st, ARGS_);             \
+        }
+#define KA_K256_FORMS(FULL_, GRID_, ARGS_)                                                                                    \
+        if (residual && relu_act) KA_K256(FULL_, true, true, GRID_, ARGS_)                                                    \
+        else if (residual) KA_K256(FULL_, true, false, GRID_, ARGS_)                                                          \
+        else if (relu_act) KA_K256(FULL_, false, true, GRID_, ARGS_)                                                          \
+        else KA_K256(FULL_, false, false, GRID_, ARGS_)
+        if (full > 0) { KA_K256_FORMS(true, full, g) }
+        if (tail) {                                              // the ragged last panel: one more workgroup of the guarded instantiation
+            NtArgs t = g;
+            t.row0 = full * kKsRows;
+            KA_K256_FORMS(false, 1, t)
+        }
+#undef KA_K256_FORMS
+#undef KA_K256
+        return ka_check_launch("tf_gemm_nt (k256)");
+    }
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel), done, "tf_gemm_nt")) return rc;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256),

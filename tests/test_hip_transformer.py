@@ -60,6 +60,36 @@ def test_gemm_tn_bf16(M, N, K, ldb, split):
     assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(M) / 4)
 
 
+@pytest.mark.parametrize("M,N", [(81, 256), (300, 1024), (4096, 768), (1000, 272), (129, 64)])
+def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
+    """K = 256 with a bf16 output takes the activation-stationary kernel (gemm_nt_k256_kernel); KA_TF_K256=0 sends the same call to
+    gemm_nt_bf16_kernel.  Same products in the same k order, same epilogue statements: every epilogue form bit for bit
+    (bias + ReLU + dropout, bias + dropout + residual, the masked input-gradient form), ragged row counts, partial last chunk."""
+    K = 256
+    g = torch.Generator().manual_seed(M * 3 + N)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    b = (torch.randn(N, K, generator=g) / 16).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    act = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+
+    def run():
+        outs = [torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(4)]
+        _lib.call("ka_tf_gemm_nt", a, b, outs[0], bias, None, M, N, K, K, K, N, 1, 1, 1, 0.1, 777, st())
+        _lib.call("ka_tf_gemm_nt", a, b, outs[1], bias, res, M, N, K, K, K, N, 1, 0, 1, 0.2, 4242, st())
+        _lib.call("ka_tf_gemm_nt", a, b, outs[2], None, None, M, N, K, K, K, N, 1, 0, 1, 0.0, 0, st())
+        _lib.call("ka_tf_gemm_nt_masked", a, b, outs[3], act, M, N, K, K, K, N, 0.1, 99, st())
+        torch.cuda.synchronize()
+        return outs
+    new = run()
+    monkeypatch.setenv("KA_TF_K256", "0")
+    old = run()
+    for k, (x, y) in enumerate(zip(new, old)):
+        assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y), k
+    want = (a.float() @ b.float().T).cpu()
+    assert float((new[2].float().cpu() - want).abs().max()) <= 0.02 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("M,N,K,p", [(300, 256, 96, 0.1), (130, 200, 64, 0.0), (257, 1024, 256, 0.3)])
 def test_masked_gemm_equals_gemm_then_dropout_relu_backward(M, N, K, p):
     """ka_tf_gemm_nt_masked (dropout + ReLU backward in the epilogue of the input-gradient GEMM) against the two-launch

@@ -356,6 +356,10 @@ int ka_tf_gemm_nt_masked(const void* A, const void* B, void* C, const void* relu
  * fp32 slabs over token ranges (z < ka_tf_gemm_tn_slabs(M, nsplit); one slab = the result), A [M][lda] (N columns) and
  * B [M][ldb] (K columns) bf16, N / K / lda / ldb multiples of 8.  Operand fragments by LDS transpose reads: no transposed copies. */
 int ka_tf_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nsplit, void* stream);
+/* the same launch also producing the bias gradient of the layer: colsum [ka_tf_gemm_tn_slabs(M, nsplit)][N] = column sums of A
+ * per token range (four more MFMAs per step against an all-ones fragment; db = sum of the slabs) */
+int ka_tf_gemm_tn_bias(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, int lda, int ldb, int ldc,
+                       int nsplit, void* stream);
 int ka_tf_gemm_tn_slabs(int M, int nsplit);
 int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream);
 int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream);

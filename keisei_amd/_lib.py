@@ -89,6 +89,7 @@ _SIGS = {
     "ka_tf_gemm_nt_slabs": "ii",
     "ka_tf_gemm_nt_masked": "pppp iii iii f q p",
     "ka_tf_gemm_tn": "ppp iii iii i p",
+    "ka_tf_gemm_tn_bias": "pppp iii iii i p",
     "ka_tf_gemm_tn_slabs": "ii",
     "ka_tf_transpose_pad": "pp iiii i p",
     "ka_tf_cast_pad": "pp q iii i p",

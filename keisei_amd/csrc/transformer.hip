@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k256_kernel(NtArgs g) {
 struct TnArgs {
     const uint16_t* A; const uint16_t* B; float* C;      // A [M][lda] (N columns used), B [M][ldb] (K columns used), C [z][N][ldc]
     int M, N, K, lda, ldb, ldc, msplit_len;
+    float* colsum;                                       // [z][N] or null: column sums of A (the layer's bias gradient), see below
 };
 constexpr int kTnRows = 64, kTnStride = 128 * 2 + 32;    // 288 B: 8 consecutive rows of a transpose read spread over all banks
 typedef __attribute__((address_space(3))) bf16x4* tn_lds_ptr;
@@ -456,6 +457,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool cs_wave = g.colsum != nullptr && bx == 0 && wk == 0;          // (wave-uniform)
+    f32x4 acs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     if (mbeg < mend) {
         load(mbeg);
         store(0);
@@ -484,10 +492,24 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnArgs g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bk[j], an[i], acc[i][j], 0, 0, 0);
+                // the bias gradient rides along: the product with an all-ones B fragment is the column sum of the A tile in every
+                // row of the result (exact products, fp32 accumulation) -- four more MFMAs per step in the first k-tile's
+                // workgroups instead of a second pass over dY (colsum_T_kernel: 25 launches, 1.9 ms per transformer step)
+                if (cs_wave) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, an[i], acs[i], 0, 0, 0);
+                }
             }
             if (more) store(buf ^ 1);
             __syncthreads();
             buf ^= 1;
+        }
+    }
+    if (cs_wave && q == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + r;
+            if (n < g.N) g.colsum[(size_t)bz * g.N + n] = acs[i][0];
         }
     }
     // lane (r, q) of tile (i, j): row n = i*16 + r, columns k = j*16 + 4q .. +3
@@ -1553,14 +1575,27 @@ extern "C" int ka_tf_gemm_tn_slabs(int M, int nsplit) {
     const int len = ((M + kTnRows - 1) / kTnRows + nsplit - 1) / nsplit * kTnRows;
     return (M + len - 1) / len;
 }
+static int tf_gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, int lda, int ldb, int ldc,
+                           int nsplit, void* stream);
 extern "C" int ka_tf_gemm_tn(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nsplit,
                              void* stream) {
+    return tf_gemm_tn_impl(A, B, C, nullptr, M, N, K, lda, ldb, ldc, nsplit, stream);
+}
+// ... and the layer's bias gradient in the same launch: colsum [ka_tf_gemm_tn_slabs(M, nsplit)][N] = per-slab column sums of A
+// (db = their sum; transformer.py:40-61, the bias of nn.Linear)
+extern "C" int ka_tf_gemm_tn_bias(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, int lda, int ldb,
+                                  int ldc, int nsplit, void* stream) {
+    KA_REQUIRE(colsum, "tf_gemm_tn_bias: null column-sum slab");
+    return tf_gemm_tn_impl(A, B, C, colsum, M, N, K, lda, ldb, ldc, nsplit, stream);
+}
+static int tf_gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, int lda, int ldb, int ldc,
+                           int nsplit, void* stream) {
     KA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "tf_gemm_tn: bad arguments");
     KA_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N && ldb >= K && ldc >= K,
                "tf_gemm_tn: N, K, lda, ldb must be multiples of 8 (N=%d K=%d lda=%d ldb=%d ldc=%d)", N, K, lda, ldb, ldc);
     const int ns = ka_tf_gemm_tn_slabs(M, nsplit);
     const int len = ns == 1 ? M : ((M + kTnRows - 1) / kTnRows + nsplit - 1) / nsplit * kTnRows;
-    TnArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, M, N, K, lda, ldb, ldc, len};
+    TnArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, M, N, K, lda, ldb, ldc, len, colsum};
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_tn_bf16_kernel), done, "tf_gemm_tn")) return rc;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((K + 127) / 128, (N + 127) / 128, ns), dim3(256), 4 * kTnRows * kTnStride,
@@ -1637,20 +1672,29 @@ extern "C" int ka_tf_layernorm_parts(long long M) { const long long p = (M + 127
 extern "C" int ka_tf_drop_apply(const void* g_in, const void* act, const void* res, void* g_out, long long n, float drop_p,
                                 unsigned long long seed, int dtype, void* stream);
 // sums of the [dgamma | dbeta] part rows straight into the two gradient tensors
-__global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ part, float* __restrict__ outa, float* __restrict__ outb,
-                                                         int nparts, int d) {
-    __shared__ float red[8][32];
+// (1024 threads = 32 row groups per 32 columns, four rows in flight per thread: with 8 groups the 2048 part rows of a B = 4096 step
+//  were a 256-deep chain of dependent row reads per thread -- 100 us for 4 MB, 12 launches per step; fixed group order: deterministic)
+__global__ __launch_bounds__(1024) void sum_parts2_kernel(const float* __restrict__ part, float* __restrict__ outa, float* __restrict__ outb,
+                                                          int nparts, int d) {
+    __shared__ float red[32][32];
     const int col = threadIdx.x & 31, g = threadIdx.x >> 5, n = 2 * d;
     const int i = blockIdx.x * 32 + col;
-    const int per = (nparts + 7) / 8, lo = g * per, hi = min(nparts, lo + per);
-    float s = 0.f;
-    if (i < n) for (int p = lo; p < hi; ++p) s += part[(size_t)p * n + i];
-    red[g][col] = s;
+    const int per = (nparts + 31) / 32, lo = g * per, hi = min(nparts, lo + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = lo;
+        for (; p + 3 < hi; p += 4) {
+            s0 += part[(size_t)p * n + i]; s1 += part[(size_t)(p + 1) * n + i];
+            s2 += part[(size_t)(p + 2) * n + i]; s3 += part[(size_t)(p + 3) * n + i];
+        }
+        for (; p < hi; ++p) s0 += part[(size_t)p * n + i];
+    }
+    red[g][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n) {
         float t = red[0][col];
 #pragma unroll
-        for (int u = 1; u < 8; ++u) t += red[u][col];
+        for (int u = 1; u < 32; ++u) t += red[u][col];
         if (i < d) outa[i] = t; else outb[i - d] = t;
     }
 }
@@ -1686,7 +1730,7 @@ extern "C" int ka_tf_layernorm_bwd_drop(const void* dy, const void* x, const flo
         }
     }
     // part rows are [dgamma | dbeta]
-    hipLaunchKernelGGL(sum_parts2_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, st, part, dgamma, dbeta, nparts, d);
+    hipLaunchKernelGGL(sum_parts2_kernel, dim3((2 * d + 31) / 32), dim3(1024), 0, st, part, dgamma, dbeta, nparts, d);
     return ka_check_launch("tf_layernorm_bwd");
 }
 

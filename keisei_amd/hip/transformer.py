@@ -112,27 +112,30 @@ class TransformerEngine:
         dev = dy.device
         code = _lib.dtype_code(T)
         dy_code = _lib.DTYPE_F32 if dy_is_f32 else code
-        # bias gradient
-        nsb = max(1, min(1024, (M + 255) // 256))
-        part = self._buf("colsum", nsb * N, torch.float32, dev)
         db = torch.empty(N, device=dev)
-        _call("ka_tf_colsum", dy, part, db, M, N, nsb, dy_code, st)
         grads[bname] = db
         dW = torch.empty(N, K, device=dev)
         dx = None
         tn_ok = (T == torch.bfloat16 and not dy_is_f32 and N % 8 == 0 and K % 8 == 0 and x.shape[1] % 8 == 0
                  and os.environ.get("KA_TF_TN", "1") != "0")
         if tn_ok:
-            # weight gradient straight from the row-major activations (LDS transpose reads: no transposed copies)
+            # weight gradient straight from the row-major activations (LDS transpose reads: no transposed copies), and the
+            # bias gradient in the same launch (column sums of dy against an all-ones fragment: no second pass over dy)
             tiles = ((N + 127) // 128) * ((K + 127) // 128)
             want = max(1, min(M // 64, (512 + tiles - 1) // tiles))
             ns = _lib.query("ka_tf_gemm_tn_slabs", M, want)
             if ns == 1:
-                _call("ka_tf_gemm_tn", dy, x, dW, M, N, K, N, x.shape[1], K, 1, st)
+                _call("ka_tf_gemm_tn_bias", dy, x, dW, db, M, N, K, N, x.shape[1], K, 1, st)
             else:
                 slab = self._buf("slab", ns * N * K, torch.float32, dev)
-                _call("ka_tf_gemm_tn", dy, x, slab, M, N, K, N, x.shape[1], K, want, st)
+                cs = self._buf("colsum", ns * N, torch.float32, dev)
+                _call("ka_tf_gemm_tn_bias", dy, x, slab, cs, M, N, K, N, x.shape[1], K, want, st)
                 _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
+                _call("ka_reduce_slabs", cs, db, ns, N, 0, st)
+        else:
+            nsb = max(1, min(1024, (M + 255) // 256))
+            part = self._buf("colsum", nsb * N, torch.float32, dev)
+            _call("ka_tf_colsum", dy, part, db, M, N, nsb, dy_code, st)
         if T == torch.bfloat16 and not tn_ok:
             Mp = _r32(M)
             dyT = self._buf("dyT", N * Mp, torch.bfloat16, dev)

@@ -58,6 +58,12 @@ def test_gemm_tn_bf16(M, N, K, ldb, split):
     torch.cuda.synchronize()
     assert ns >= 1 and (split == 1) == (ns == 1)
     assert torch.allclose(slab.sum(0).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(M) / 4)
+    # the same launch with the bias gradient riding along: identical slabs, column sums of A per token range
+    slab2 = torch.full((ns, N, K), float("nan"), device=DEV); cs = torch.full((ns, N), float("nan"), device=DEV)
+    _lib.call("ka_tf_gemm_tn_bias", a.to(DEV), b.to(DEV), slab2, cs, M, N, K, N, ldb, K, split, st())
+    torch.cuda.synchronize()
+    assert torch.equal(slab2, slab)
+    assert torch.allclose(cs.sum(0).cpu(), a.float().sum(0), rtol=1e-5, atol=1e-3 * math.sqrt(M) / 4)
 
 
 @pytest.mark.parametrize("M,N", [(81, 256), (300, 1024), (4096, 768), (1000, 272), (129, 64)])

@@ -44,6 +44,7 @@ elif which == "conv":
             ("bn+relu+bias input (conv2 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, code, _lib.stream_ptr())),
             ("dgrad fused, masked epilogue (conv2 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, code, _lib.stream_ptr())),
             ("dgrad fused, plain epilogue (conv1 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, code, _lib.stream_ptr())),
+            ("dgrad fused, plain epilogue, no dy write-back", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, None, wp, out, None, None, None, None, None, None, None, None, B, C, C, code, _lib.stream_ptr())),
         ):
             ms = timeit(fn, n=20)
             print(f"conv KC={kc:3d} WM={wm} {name:42s}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)

@@ -21,6 +21,7 @@ Fixture inventory:
   g6_adam       clip_grad_norm_ + Adam, 3 steps
   g7_scalar     mlp / transformer tiny forward
   g9_transformer TransformerModel (2 small configs, hash weights): eval / train(dropout 0) outputs, fp64 gradients
+  g9_transformer_d256  the same at the benched head shape (d 256, 8 heads, 1 layer, 2 boards): `make_golden.py g9_d256`
   g8_sl         two SLTrainer.train_epoch() calls on a 3-shard directory: shard arrays, visiting order, metrics, weights
 """
 
@@ -474,13 +475,16 @@ def g7_scalar() -> None:
     npz("g7_scalar", **arrays)
 
 
-def g9_transformer() -> None:
+def g9_transformer(which: str = "small") -> None:
     """TransformerModel (transformer.py:37-95) with init-like hash weights: eval outputs, and -- with every dropout of the
     encoder layers set to p = 0, so that train mode is deterministic -- train-mode outputs and fp64 gradients (norms of
-    every tensor, every tensor of <= 20 000 elements in full, 8 rows of the policy matrix)."""
+    every tensor, every tensor of <= 20 000 elements in full, 8 rows of the policy matrix).  `which="d256"`: the head shape
+    bench.py's transformer workload runs (d 256, 8 heads; one layer, two boards: the 233 M-parameter policy layer is
+    hash-filled on both sides, never stored) into its own file g9_transformer_d256.npz."""
     arrays = {}
-    for tag, p, batch in (("d32h4L2.", {"d_model": 32, "nhead": 4, "num_layers": 2}, 3),
-                          ("d64h2L1.", {"d_model": 64, "nhead": 2, "num_layers": 1}, 5)):
+    cases = ((("d32h4L2.", {"d_model": 32, "nhead": 4, "num_layers": 2}, 3), ("d64h2L1.", {"d_model": 64, "nhead": 2, "num_layers": 1}, 5))
+             if which == "small" else (("d256h8L1.", {"d_model": 256, "nhead": 8, "num_layers": 1}, 2),))
+    for tag, p, batch in cases:
         m = build_model("transformer", p)
         sd = orc.hash_fill(m.state_dict())
         m.load_state_dict(sd, strict=True)
@@ -517,7 +521,7 @@ def g9_transformer() -> None:
             if g.numel() <= SMALL:
                 arrays[f"{tag}grad64.{n}"] = g.float()
         arrays[tag + "grad64.policy_fc.weight[:8]"] = grads["policy_fc.weight"][:8].float()
-    npz("g9_transformer", **arrays)
+    npz("g9_transformer" if which == "small" else "g9_transformer_d256", **arrays)
 
 
 def g8_sl() -> None:
@@ -574,6 +578,10 @@ def g8_sl() -> None:
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "g9_d256":
+        g9_transformer("d256")
+        print("wrote g9_transformer_d256")
+        sys.exit(0)
     for fn in (g1_block, g2_model_tiny, g2_model_mid16, g2_model_full, g3_loss, g4_gae, g5_update, g6_adam, g7_scalar, g8_sl, g9_transformer):
         if only and fn.__name__ not in only:
             continue

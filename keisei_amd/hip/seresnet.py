@@ -64,7 +64,13 @@ class SEResNetEngine:
         self._tensor_lists = None                   # (buffers, parameters, structure version) of the eval-graph key
         self._tower_tabs = {}                       # pointer tables of the one-launch eval tower (kept: graphs read them)
         self._evalc_live = None
-        self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "1") != "0"
+        # Weight gradients on a second stream beside the data-gradient chain: off by default since round 3.  The MFMA kernels are
+        # power-bound: two of them sharing the chip finish no sooner than one after the other, and with the
+        # main queue's small kernels shortened the second stream no longer fills anything (110.6 / 111.2 ms without it against
+        # 111.0 / 111.2 with, one job) -- while every launch now runs at its stand-alone rate (data gradient 0.45 instead of
+        # 0.73 ms in the step's trace).  KA_WGRAD_OVERLAP=1 brings the two-stream schedule back.
+        self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "0") != "0"
+        self.fork_fc = os.environ.get("KA_FC_FORK", "1") != "0"      # small-batch forward: global-pool FC chain beside conv1
         self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
@@ -495,10 +501,10 @@ class SEResNetEngine:
                 if len(self._graphs) >= 8:
                     self._graphs.clear()
                 static_in = obs.clone()
-                saved_overlap = self.overlap_wgrad
+                saved_overlap = self.fork_fc
                 # KA_EVAL_GRAPH_FORK=1: keep the global-pool FC chain on the side stream inside the capture (a fork /
                 # join in the graph, beside conv1); 0 = single-stream capture
-                self.overlap_wgrad = saved_overlap and os.environ.get("KA_EVAL_GRAPH_FORK", "1") != "0"
+                self.fork_fc = saved_overlap and os.environ.get("KA_EVAL_GRAPH_FORK", "1") != "0"
                 try:
                     self.forward(static_in, False, False, T, None)            # warm-up: one-time kernel attributes etc.
                     torch.cuda.synchronize(dev)
@@ -506,7 +512,7 @@ class SEResNetEngine:
                     with torch.cuda.graph(graph):
                         out = self.forward(static_in, False, False, T, None)[:3]
                 finally:
-                    self.overlap_wgrad = saved_overlap
+                    self.fork_fc = saved_overlap
                 ent = (graph, static_in, out)
                 self._graphs[key] = ent
             graph, static_in, out = ent
@@ -569,7 +575,7 @@ class SEResNetEngine:
         # (336 us per launch in the round-2 trace).  Small batches (rollout inference without the tower kernel) keep the
         # fork: their conv workgroups leave CUs free.
         fc_side = os.environ.get("KA_FC_SIDE")
-        fside = self._wgrad_side(1, dev)[0] if (self.overlap_wgrad and (fc_side == "1" or (fc_side is None and B < 512))) else None
+        fside = self._wgrad_side(1, dev)[0] if (self.fork_fc and (fc_side == "1" or (fc_side is None and B < 512))) else None
         main_f = torch.cuda.current_stream(dev)
         for i, blk in enumerate(m.blocks if tower_tab is None else ()):
             # g = global_fc(pool(x)) is only needed by conv2

@@ -278,6 +278,37 @@ def test_bf16_backward_tracks_fp32_gradients():
     print("worst cosine", worst)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_backward_schedules_give_identical_gradients(monkeypatch, amp):
+    """The backward's launch schedule is a choice, not arithmetic: weight gradients on the main stream (default) or on a second
+    stream (KA_WGRAD_OVERLAP=1), block boundaries as one launch (default) or two (KA_DX_TAIL=0) -- every parameter gradient bit
+    for bit the same."""
+    shape = orc.NetShape(3, 64, 8, 32, 16, 64, 32)
+    sd = orc.init_like_state_dict(shape)
+    g = torch.Generator().manual_seed(11)
+    B = 37
+    obs = torch.randn(B, 50, 9, 9, generator=g).to(DEV)
+    cp, cv, cs = torch.randn(B, 9, 9, 139, generator=g).to(DEV), torch.randn(B, 3, generator=g).to(DEV), torch.randn(B, 1, generator=g).to(DEV)
+    grads = {}
+    for name, env in (("default", {}), ("two streams", {"KA_WGRAD_OVERLAP": "1"}), ("two launches", {"KA_DX_TAIL": "0"})):
+        for k in ("KA_WGRAD_OVERLAP", "KA_DX_TAIL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = SEResNetModel(SEResNetParams(**shape.__dict__))              # (the engine reads its switches when it is built)
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        if amp:
+            m.configure_amp(True, torch.bfloat16, "cuda")
+        o = m(obs)
+        ((o.policy_logits * cp).sum() / B + (o.value_logits * cv).sum() + (o.score_lead * cs).sum()).backward()
+        torch.cuda.synchronize()
+        grads[name] = {n: prm.grad.clone() for n, prm in m.named_parameters()}
+    for name in ("two streams", "two launches"):
+        for n, ref in grads["default"].items():
+            assert torch.equal(grads[name][n], ref), (name, n)
+
+
 @pytest.mark.parametrize("nb,B", [(3, 5), (40, 130)])
 def test_eval_tower_kernel_matches_the_per_layer_path(monkeypatch, nb, B):
     """bf16 eval forward of a 256-channel model: the one-launch tower (csrc/tower.hip, the default in eval mode) against the

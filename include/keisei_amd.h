@@ -393,6 +393,10 @@ int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B, int H, in
                         int dtype, void* stream);
 int ka_tf_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int H, int dh, float drop_p,
                         unsigned long long seed, int dtype, void* stream);
+/* ... with the forward's output handed in: D[query] = rowsum(dout * out) makes dQ and dK / dV two independent launches on the
+ * register-resident path (bf16, dh <= 32); other shapes fall through to ka_tf_attention_bwd */
+int ka_tf_attention_bwd_o(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int H, int dh,
+                          float drop_p, unsigned long long seed, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

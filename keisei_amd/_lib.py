@@ -107,6 +107,7 @@ _SIGS = {
     "ka_tf_tanh_bwd": "ppp q p",
     "ka_tf_attention_fwd": "ppp iii f q i p",
     "ka_tf_attention_bwd": "pppp iii f q i p",
+    "ka_tf_attention_bwd_o": "ppppp iii f q i p",
     "ka_version": "",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}   # q also carries 64-bit seeds

@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(AttnArgs a) {
 // orientations (the MFMAs are not what this kernel waits for): pass A per query tile (softmax terms, D, dQ), pass B per
 // key tile (dK, dV); D[query] travels between the passes through 96 floats of LDS.
 constexpr int kAtStride = 96;                // bytes per row of the natural-layout LDS matrix (<= 64 B of data; 32 x odd)
-constexpr int kAtWaveLds = kSP * kAtStride + kSP * 4;
+constexpr int kAtWaveLds = kSP * kAtStride + 2 * kSP * 4;      // the matrix + two float rows (D, log-sum-exp) per wave
 typedef __attribute__((address_space(3))) bf16x4* at_lds_ptr;
 
 struct AtCtx {
@@ -1474,6 +1474,198 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         }
     }
 }
+
+// ------------------------------------------------------------------ the backward in two launches: dQ | dK, dV
+// attention_bwd_reg_kernel spends its 1.23 ms (4096 boards, 8 heads of 32) waiting, not computing: 252 MFMAs per wave, three
+// waves per SIMD (168 registers, 30 of them spilled), and pass B cannot start before pass A has D[query] = sum_key P dP.
+// D is also rowsum(dO * O) with O the forward's (dropped) output -- the identity flash attention uses -- so with O handed in the
+// two passes are independent kernels: twice the waves, each with the registers of ONE pass (no spills, 4-5 waves per SIMD), and a
+// score tile of pass A is finished as soon as it is computed instead of waiting in registers for the row's D.
+// D from the bf16 O differs from the fp32 sum by O's rounding (2^-9 relative): tests/test_hip_transformer.py bounds the result.
+__device__ __forceinline__ void at_rowdot(const AtCtx& c, const uint16_t* gb, const uint16_t* ob, size_t ld, float* Dq) {
+    for (int row = c.lane; row < kSP; row += 64) {
+        float s = 0.f;
+        if (row < kS) {
+            for (int c0 = 0; c0 < c.dh; c0 += 8) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(gb + (size_t)row * ld + c0);
+                const bf16x8 o = *reinterpret_cast<const bf16x8*>(ob + (size_t)row * ld + c0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf((float)g[e], (float)o[e], s);
+            }
+        }
+        Dq[row] = s;
+    }
+}
+
+#ifndef KA_ATT_DQ_OCC
+#define KA_ATT_DQ_OCC 3
+#endif
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KA_ATT_DQ_OCC))) void attention_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
+    const int wave = threadIdx.x >> 6;
+    AtCtx c{(int)(threadIdx.x & 63), (int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), a.dh, at_smem + wave * kAtWaveLds};
+    float* Dq = reinterpret_cast<float*>(c.buf + kSP * kAtStride);          // [96]
+    const int r = c.r, q = c.q;
+    const int bh = min(blockIdx.x * 4 + wave, a.B * a.H - 1);
+    const int b = bh / a.H, h = bh - b * a.H;
+    const uint16_t* qb = static_cast<const uint16_t*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const uint16_t* gb = static_cast<const uint16_t*>(a.dout) + (size_t)b * kS * a.d + h * a.dh;
+    const uint16_t* ob = static_cast<const uint16_t*>(a.out) + (size_t)b * kS * a.d + h * a.dh;
+    uint16_t* dqb = static_cast<uint16_t*>(a.dqkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const float* lse = a.lse + ((size_t)b * a.H + h) * kS;
+    const size_t ldg = 3 * (size_t)a.d;
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(a.drop_p), dkey = drop_key(a.seed), ibase = (uint32_t)bh * kSP * kSP;
+    c.stage(qb + a.d, ldg, NT * 2);                                   // K
+    at_rowdot(c, gb, ob, a.d, Dq);
+    bf16x8 Kf[6], Vf[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { Kf[j] = c.frag_g(qb + a.d, ldg, j, 0); Vf[j] = c.frag_g(qb + 2 * a.d, ldg, j, 0); }
+    __syncthreads();
+    bf16x8 Kt[3][NT];
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Kt[pr][nt] = c.frag_t(pr, nt);
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        const bf16x8 Qf = c.frag_g(qb, ldg, i, 0), Gf = c.frag_g(gb, a.d, i, 0);
+        const int row = i * 16 + r;
+        const float l = row < kS ? lse[row] : 0.f, D = Dq[row];
+        f32x4 ds[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[j], Qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[j], Gf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = j * 16 + 4 * q + e;
+                const bool ok = col < kS && row < kS;
+                const float pv = ok ? __expf(p[e] * a.scale - l) : 0.f;
+                float m = 1.f;
+                if (a.drop_p > 0.f) m = keep_scale32(dkey, ibase + row * kSP + col, thresh, inv_keep);
+                ds[j][e] = pv * ((ok ? dp[e] * m : 0.f) - D) * a.scale;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kt[pr][nt], at_pack(ds[2 * pr], ds[2 * pr + 1]), o, 0, 0, 0);
+            const int cc = nt * 16 + 4 * q;
+            if (row < kS && cc < a.dh) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (__bf16)o[e];
+                *reinterpret_cast<bf16x4*>(dqb + (size_t)row * ldg + cc) = ov;
+            }
+        }
+    }
+}
+
+#ifndef KA_ATT_DKV_OCC
+#define KA_ATT_DKV_OCC 2      // two waves per SIMD with the query-side fragments in registers: 893 us for both passes against 1061 with three
+#endif
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KA_ATT_DKV_OCC))) void attention_bwd_dkv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];
+    const int wave = threadIdx.x >> 6;
+    AtCtx c{(int)(threadIdx.x & 63), (int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), a.dh, at_smem + wave * kAtWaveLds};
+    float* Dq = reinterpret_cast<float*>(c.buf + kSP * kAtStride);          // [96]
+    const int r = c.r, q = c.q;
+    const int bh = min(blockIdx.x * 4 + wave, a.B * a.H - 1);
+    const int b = bh / a.H, h = bh - b * a.H;
+    const uint16_t* qb = static_cast<const uint16_t*>(a.qkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const uint16_t* gb = static_cast<const uint16_t*>(a.dout) + (size_t)b * kS * a.d + h * a.dh;
+    const uint16_t* ob = static_cast<const uint16_t*>(a.out) + (size_t)b * kS * a.d + h * a.dh;
+    uint16_t* dqb = static_cast<uint16_t*>(a.dqkv) + (size_t)b * kS * 3 * a.d + h * a.dh;
+    const float* lse = a.lse + ((size_t)b * a.H + h) * kS;
+    const size_t ldg = 3 * (size_t)a.d;
+    const float inv_keep = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thresh = drop_thresh(a.drop_p), dkey = drop_key(a.seed), ibase = (uint32_t)bh * kSP * kSP;
+    // D[query] and the queries' log-sum-exp through LDS: lane (key r, q) needs them for the queries 4q + e of every tile (read
+    // from global memory per element, the 144 log-sum-exp loads per lane were what this pass waited for: 82 % of its wave
+    // cycles in s_waitcnt, 238 vector-memory instructions per wave against 52 in the dQ pass)
+    float* Ls = Dq + kSP;                                             // [96]
+    at_rowdot(c, gb, ob, a.d, Dq);
+    for (int row = c.lane; row < kSP; row += 64) Ls[row] = row < kS ? lse[row] : 0.f;
+    c.stage(qb, ldg, NT * 2);                                         // Q
+    __syncthreads();
+    bf16x8 Qt[3][NT], Gt[3][NT];
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Qt[pr][nt] = c.frag_t(pr, nt);
+    __syncthreads();
+    c.stage(gb, a.d, NT * 2);                                         // dO
+    __syncthreads();
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Gt[pr][nt] = c.frag_t(pr, nt);
+    auto store4 = [&](uint16_t* base, int row, int cc, const f32x4& v) {
+        if (row < kS && cc < a.dh) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(base + (size_t)row * ldg + cc) = o;
+        }
+    };
+#if KA_ATT_DKV_OCC == 2
+    bf16x8 Qr[6], Gr[6];                                               // row-major query / dO fragments: the same for every key tile
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { Qr[i] = c.frag_g(qb, ldg, i, 0); Gr[i] = c.frag_g(gb, a.d, i, 0); }
+#define KA_QR(i_) Qr[i_]
+#define KA_GR(i_) Gr[i_]
+#else
+#define KA_QR(i_) c.frag_g(qb, ldg, i_, 0)
+#define KA_GR(i_) c.frag_g(gb, a.d, i_, 0)
+#endif
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const bf16x8 Kf = c.frag_g(qb + a.d, ldg, j, 0), Vf = c.frag_g(qb + 2 * a.d, ldg, j, 0);
+        const int col = j * 16 + r;
+        f32x4 dK[NT], dV[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dK[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            f32x4 ds[2], pd[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int i = 2 * pr + hf;
+                const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KA_QR(i), Kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KA_GR(i), Vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = i * 16 + 4 * q + e;
+                    const bool ok = col < kS && row < kS;
+                    const float pv = ok ? __expf(sc[e] * a.scale - Ls[row]) : 0.f;
+                    float m = 1.f;
+                    if (a.drop_p > 0.f) m = keep_scale32(dkey, ibase + row * kSP + col, thresh, inv_keep);
+                    const float dpv = ok ? g[e] * m : 0.f;
+                    ds[hf][e] = pv * (dpv - Dq[row]) * a.scale;
+                    pd[hf][e] = pv * m;
+                }
+            }
+            const bf16x8 dsf = at_pack(ds[0], ds[1]), pdf = at_pack(pd[0], pd[1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                dK[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[pr][nt], dsf, dK[nt], 0, 0, 0);
+                dV[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gt[pr][nt], pdf, dV[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            store4(dqb + a.d, col, nt * 16 + 4 * q, dK[nt]);
+            store4(dqb + 2 * a.d, col, nt * 16 + 4 * q, dV[nt]);
+        }
+    }
+}
+#undef KA_QR
+#undef KA_GR
 
 template <typename T> size_t attn_fwd_lds(int dh) {
     const int KP = attn_kp<T>(dh), NP = attn_np(dh);
@@ -1807,6 +1999,29 @@ extern "C" int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B
         hipLaunchKernelGGL(attention_fwd_kernel<float>, dim3(B * H), dim3(64), attn_fwd_lds<float>(dh), st, a);
     } else { ka_set_error("tf_attention_fwd: unknown dtype %d", dtype); return KA_ERR_ARG; }
     return ka_check_launch("tf_attention_fwd");
+}
+// The backward with the forward's output handed in (D = rowsum(dO * O)): dQ and dK / dV as two independent launches on the
+// register-resident path (bf16, dh <= 32); every other shape / dtype goes to ka_tf_attention_bwd and ignores `out`.
+extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int H, int dh,
+                                   float drop_p, unsigned long long seed, int dtype, void* stream);
+extern "C" int ka_tf_attention_bwd_o(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int H,
+                                     int dh, float drop_p, unsigned long long seed, int dtype, void* stream) {
+    KA_REQUIRE(qkv && out && dout && lse && dqkv && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_bwd_o: bad arguments (dh <= 64)");
+    if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
+        !getenv("KA_TF_ATTN_LDS") && !getenv("KA_TF_ATTN_ONE")) {
+        AttnArgs a{qkv, const_cast<void*>(out), const_cast<float*>(lse), dout, dqkv, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int grid = (B * H + 3) / 4;
+        if (dh <= 16) {
+            hipLaunchKernelGGL(attention_bwd_dq_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+            hipLaunchKernelGGL(attention_bwd_dkv_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        } else {
+            hipLaunchKernelGGL(attention_bwd_dq_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+            hipLaunchKernelGGL(attention_bwd_dkv_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
+        }
+        return ka_check_launch("tf_attention_bwd_o");
+    }
+    return ka_tf_attention_bwd(qkv, dout, lse, dqkv, B, H, dh, drop_p, seed, dtype, stream);
 }
 extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int H, int dh,
                                    float drop_p, unsigned long long seed, int dtype, void* stream) {

@@ -324,7 +324,8 @@ class TransformerEngine:
             dattn = self._lin_bwd(g1, attn, pre + "self_attn.out_proj", lyr.self_attn.out_proj.weight, grads,
                                   pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", T, st)
             dqkv = torch.empty_like(qkv)
-            _call("ka_tf_attention_bwd", qkv, dattn, lse, dqkv, B, H, d // H, p_attn, s_base + 1, code, st)
+            # (the forward's output `attn` gives D = rowsum(dattn * attn): dQ and dK / dV run as two independent launches)
+            _call("ka_tf_attention_bwd_o", qkv, attn, dattn, lse, dqkv, B, H, d // H, p_attn, s_base + 1, code, st)
             dh1 = self._lin_bwd(dqkv, h1, pre + "self_attn.in_proj", lyr.self_attn.in_proj_weight, grads,
                                 pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias", T, st)
             dx_new = torch.empty_like(dx)

@@ -242,6 +242,18 @@ def test_register_attention_equals_the_lds_form(monkeypatch, H, dh, p):
     assert torch.allclose(l1, l0, rtol=1e-5, atol=1e-5)
     assert float((o1 - o0).abs().max()) <= 2e-2 * float(o0.abs().max())
     assert float((g1 - g0).norm() / g0.norm()) < 1e-2
+    # ... and the two-launch backward (dQ | dK, dV with D = rowsum(dout * out) from the forward's bf16 output) against both
+    out = torch.empty(B * 81, d, dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, H, 81, device=DEV)
+    _lib.call("ka_tf_attention_fwd", qkv, out, lse, B, H, dh, p, seed, _lib.DTYPE_BF16, st())
+    dq2 = torch.full((B * 81, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("ka_tf_attention_bwd_o", qkv, out, dout, lse, dq2, B, H, dh, p, seed, _lib.DTYPE_BF16, st())
+    torch.cuda.synchronize()
+    g2 = dq2.float().cpu()
+    assert bool(torch.isfinite(g2).all())
+    assert float((g2 - g1).norm() / g1.norm()) < 1e-2 and float((g2 - g0).norm() / g0.norm()) < 1.5e-2
+    for blk in range(3):                                     # dQ, dK, dV separately
+        a, b_ = g2[:, blk * d:(blk + 1) * d], g1[:, blk * d:(blk + 1) * d]
+        assert float((a - b_).norm() / b_.norm()) < 1.5e-2, blk
 
 
 def test_attention_dropout_is_consistent_between_forward_and_backward():

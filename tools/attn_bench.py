@@ -21,4 +21,5 @@ def timeit(fn, n=10):
 for p in (0.0, 0.1):
     f = timeit(lambda: _lib.call("ka_tf_attention_fwd", qkv, out, lse, B, H, dh, p, 12345, _lib.DTYPE_BF16, st()))
     b = timeit(lambda: _lib.call("ka_tf_attention_bwd", qkv, dout, lse, dqkv, B, H, dh, p, 12345, _lib.DTYPE_BF16, st()))
-    print(f"dropout {p}: forward {f:7.1f} us   backward {b:7.1f} us", flush=True)
+    b2 = timeit(lambda: _lib.call("ka_tf_attention_bwd_o", qkv, out, dout, lse, dqkv, B, H, dh, p, 12345, _lib.DTYPE_BF16, st()))
+    print(f"dropout {p}: forward {f:7.1f} us   backward {b:7.1f} us   backward in two launches (dQ | dK,dV) {b2:7.1f} us", flush=True)

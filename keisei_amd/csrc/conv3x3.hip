@@ -869,12 +869,21 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
     bf16x8 w0[2], w1[2], w2[2], w3[2];
     wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);
     f32x4 acc[kMTW][2];
+#ifdef KA_PC_MFMA32
+    f32x16 acc32[3];
+#endif
     KA_LDS_BARRIER();                                        // unit 0 is staged
     for (int u = 0; u < nunits; ++u) {
         const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1;
         if (!kc) {
 #pragma unroll
             for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#ifdef KA_PC_MFMA32
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[t][e] = 0.f;
+#endif
         }
         int rowoff[kMTW];
 #pragma unroll
@@ -891,15 +900,25 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
 #else
                 an[mt] = ac[mt]; (void)toff;                 // ablation build (tools/_diag/build_variants.sh): no activation-fragment LDS reads
 #endif
+#ifndef KA_PC_MFMA32
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
+#else
+                // ablation build (timing / held clock only, WRONG results): the same operand registers and the same matrix-pipe
+                // cycles as ONE v_mfma_f32_32x32x16_bf16 per (row tile, k-step) -- half the instructions and operand reads per FLOP
+                acc32[mt >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mt & 1], ac[mt], acc32[mt >> 1], 0, 0, 0);
+#endif
             }
 #pragma unroll
             for (int mt = 0; mt < kMTW; ++mt) {
 #ifndef KA_PC_NO_A
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #endif
+#ifndef KA_PC_MFMA32
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#else
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
             }
         };
         bf16x8 fa[kMTW], fb[kMTW];
@@ -927,6 +946,16 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
         }
 #ifdef KA_PC_NO_W
 #undef wfrag
+#endif
+#ifdef KA_PC_MFMA32
+        if (kc) {
+#pragma unroll
+            for (int mt = 0; mt < kMTW; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][j][e] = acc32[mt >> 1][(mt & 1) * 8 + j * 4 + e];
+        }
 #endif
         if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
         KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete

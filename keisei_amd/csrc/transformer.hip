@@ -61,6 +61,7 @@ struct NtArgs {
     int lds_epilogue;                          // full bf16 tiles leave through LDS as whole-row 16-byte pieces (KA_TF_LDS_EPI=0: off)
     float drop_p; unsigned long long seed;     // dropout on the (bias, relu)'d value before the residual add
     int row0;                                  // gemm_nt_k256_kernel: first row of this launch's panels (the ragged last panel is its own launch)
+    int map_gx, map_gy;                        // gemm_nt_bf16_kernel: > 0 = one-dimensional grid walked as 8 x 8 super-tiles per XCD (n-tiles, m-tiles)
 };
 
 constexpr int kBM = 128, kBN = 128, kBK = 64, kLdsStride = kBK * 2 + 16;     // bytes per tile row (144: 16 rows x 16 B land on 64 different banks)
@@ -78,8 +79,19 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     // XCD-aware tile map: workgroups are dealt round-robin over the 8 XCDs (linear id L sits on XCD L % 8), each with its own
     // L2.  The n-tiles of one m-tile read the same 128 rows of A: they are given consecutive slots of ONE XCD, so A comes
     // from HBM once instead of once per XCD that happens to run one of its n-tiles (N = 1024: 8 n-tiles).  Placement only.
+    // Many n-tiles AND many m-tiles (the policy layer: 88 x 32 tiles over K = 20 736): neither operand panel fits a cache, and
+    // with one m-tile per XCD at a time every m-tile streams the whole weight matrix through its L2 (measured: 15.6 GB of L2
+    // misses per launch for 0.64 GB of operands, 5.4 TB/s -- the fabric, not the matrix pipe, paced it).  There the grid is
+    // one-dimensional and an XCD walks 8 x 8 super-tiles: the 64 workgroups resident on it share 8 A and 8 B panels.
     int bx = blockIdx.x, by = blockIdx.y;
-    {
+    if (g.map_gx > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int sm_n = (g.map_gy + 7) >> 3;                // super-tiles along m
+        const int G = (slot >> 6) * 8 + xcd, within = slot & 63;
+        by = (G % sm_n) * 8 + (within & 7);
+        bx = (G / sm_n) * 8 + (within >> 3);
+        if (by >= g.map_gy || bx >= g.map_gx) return;        // padding of the last super-tiles (uniform exit, no barrier yet)
+    } else {
         const int gx = gridDim.x, gy = gridDim.y, L = by * gx + bx;
         const int full = (gy / 8) * 8;                       // m-tiles covered by whole groups of 8
         const int xcd = L & 7, slot = L >> 3;
@@ -254,6 +266,145 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
                     if (g.residual) v += static_cast<const float*>(g.residual)[o];
                     static_cast<float*>(g.C)[o] = v;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ NT GEMM, 256 x 256 x 64 tiles: the policy layer
+// M, N and K all large (policy_fc: 4096 x 11 259 x 20 736 forward, and its two gradients): with 128 x 128 tiles every
+// workgroup pulls 256 operand rows per 64 k through the L2 for 32 MFMAs per wave -- 10.7 TB/s of L2 -> CU traffic at
+// 0.7 PFLOP/s, matrix pipe 30-34 % busy.  Here a 512-thread workgroup owns a 256 x 256 tile: 8 waves as 2 (m) x 4 (n), wave
+// tile 128 x 64 = 32 accumulator tiles (128 registers), 12 fragment reads per 32 MFMAs instead of 16, half the operand
+// bytes per FLOP through L2 and LDS, and a k-tile's MFMA phase twice as long for the same prefetch.  One workgroup per CU
+// (2 x 73.7 KB of LDS), register-staged double buffering as in gemm_nt_bf16_kernel; an XCD walks 4 (m) x 8 (n) super-tiles
+// (its 32 resident workgroups share 4 A and 8 B panels).  Bias-only epilogue, fp32 or bf16 output, ragged M / N edges;
+// K a multiple of 64.  Same products in the same k order as the 128 x 128 kernel: results are bit-identical.
+constexpr int kGM = 256, kGN = 256;
+constexpr int kGLds = 2 * (kGM + kGN) * kLdsStride;
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(NtArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char big_smem[];
+    auto As = [&](int buf) { return big_smem + buf * ((kGM + kGN) * kLdsStride); };
+    auto Bs = [&](int buf) { return big_smem + buf * ((kGM + kGN) * kLdsStride) + kGM * kLdsStride; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    int bx, by;
+    {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int sm_n = (g.map_gy + 3) >> 2;                // super-tiles along m
+        const int G = (slot >> 5) * 8 + xcd, within = slot & 31;
+        by = (G % sm_n) * 4 + (within & 3);
+        bx = (G / sm_n) * 8 + (within >> 2);
+        if (by >= g.map_gy || bx >= g.map_gx) return;        // padding of the last super-tiles (uniform exit, no barrier yet)
+    }
+    const int m0 = by * kGM, n0 = bx * kGN;
+    // staging role: 256 rows x 8 pieces (16 B) per operand tile = 2048 pieces, four per thread and operand
+    const int srow = tid >> 3, spc = tid & 7;
+    bf16x8 ra[4], rb[4];
+    // (32-bit byte offsets from the uniform operand bases, recomputed per k-tile from an opaque copy of the row index: kept
+    //  across the loop as eight 64-bit row pointers they cost 16 registers this kernel lacks; rows past the edge read the
+    //  operand's last row -- their products land in accumulators that are never stored)
+    auto load = [&](int k0) {
+        int sr = srow;
+        asm volatile("" : "+v"(sr));
+        const char* ak = reinterpret_cast<const char*>(g.A) + (size_t)k0 * 2;       // uniform
+        const char* bk = reinterpret_cast<const char*>(g.B) + (size_t)k0 * 2;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const uint32_t ao = (uint32_t)(min(m0 + sr + 64 * h, g.M - 1) * g.lda + spc * 8) * 2u;
+            const uint32_t bo = (uint32_t)(min(n0 + sr + 64 * h, g.N - 1) * g.ldb + spc * 8) * 2u;
+            ra[h] = *reinterpret_cast<const bf16x8*>(ak + ao);
+            rb[h] = *reinterpret_cast<const bf16x8*>(bk + bo);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int row = srow + 64 * h;
+            *reinterpret_cast<bf16x8*>(As(buf) + row * kLdsStride + spc * 16) = ra[h];
+            *reinterpret_cast<bf16x8*>(Bs(buf) + row * kLdsStride + spc * 16) = rb[h];
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int k0, int buf) {
+        const bool more = k0 + kBK < g.K;
+        if (more) load(k0 + kBK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // the four B fragments of the k-step, then the A fragments one row tile ahead of their four MFMAs (issue order
+            // pinned): 24 fragment registers instead of 48 -- with both k-steps' fragments hoisted the kernel spilled
+            const char* ab = As(buf) + (wm * 128 + r) * kLdsStride + kk * 64 + q * 16;
+            bf16x8 bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs(buf) + (wn * 64 + j * 16 + r) * kLdsStride + kk * 64 + q * 16);
+            bf16x8 a_cur = *reinterpret_cast<const bf16x8*>(ab);
+            // C^T tiles, as gemm_nt_bf16_kernel: a lane holds 4 consecutive columns n of one row m
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16x8 a_nxt = a_cur;
+                if (i < 7) a_nxt = *reinterpret_cast<const bf16x8*>(ab + (i + 1) * 16 * kLdsStride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], a_cur, acc[i][j], 0, 0, 0);
+                a_cur = a_nxt;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    int k0 = 0;
+    for (; k0 + kBK < g.K; k0 += 2 * kBK) {
+        step(k0, 0);
+        step(k0 + kBK, 1);
+    }
+    if (k0 < g.K) step(k0, 0);
+    // epilogue: lane (r, q) of tile (i, j): row m = i*16 + r, columns n = j*16 + 4q .. +3
+    const bool vec4 = (g.N & 3) == 0 && (g.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = n0 + wn * 64 + j * 16 + 4 * q;
+            if (nb >= g.N) continue;
+            const size_t ob = (size_t)m * g.ldc + nb;
+            if (vec4) {
+                f32x4 v = acc[i][j];
+                if (g.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + nb); v += bv; }
+                if (g.c_bf16) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(static_cast<uint16_t*>(g.C) + ob) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(g.C) + ob) = v;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nb + e;
+                if (n >= g.N) continue;
+                float v = acc[i][j][e];
+                if (g.bias) v += g.bias[n];
+                if (g.c_bf16) static_cast<uint16_t*>(g.C)[ob + e] = f2bf(v);
+                else static_cast<float*>(g.C)[ob + e] = v;
             }
         }
     }
@@ -1755,8 +1906,26 @@ static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* b
     }
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel), done, "tf_gemm_nt")) return rc;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nsplit), dim3(256),
-                       2 * (kBM + kBN) * kLdsStride, static_cast<hipStream_t>(stream), g);
+    // all three extents large, nothing but a bias in the epilogue: the 256 x 256 tile form (KA_TF_BIG=0: off)
+    const char* eb = getenv("KA_TF_BIG");
+    if (!(eb && atoi(eb) == 0) && nsplit == 1 && M >= 1024 && N >= 1024 && K >= 1024 && K % kBK == 0 && !residual && !relu_act &&
+        !relu && drop_p == 0.f && (size_t)M * lda < (1ull << 31) && (size_t)N * ldb < (1ull << 31)) {      // (32-bit operand byte offsets)
+        g.map_gx = (N + kGN - 1) / kGN; g.map_gy = (M + kGM - 1) / kGM;
+        const int supers = ((g.map_gx + 7) / 8) * ((g.map_gy + 3) / 4);
+        static std::atomic<unsigned long long> dbig{0};
+        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_big_kernel), dbig, "tf_gemm_nt (big)")) return rc;
+        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3(((supers + 7) / 8) * 8 * 32), dim3(512), kGLds, static_cast<hipStream_t>(stream), g);
+        return ka_check_launch("tf_gemm_nt (big)");
+    }
+    const int gx = (N + kBN - 1) / kBN, gy = (M + kBM - 1) / kBM;
+    dim3 grid(gx, gy, nsplit);
+    const char* e2 = getenv("KA_TF_MAP2D");                  // (0: the one-m-tile-per-XCD map for every shape)
+    if (gx > 8 && gy >= 8 && !(e2 && atoi(e2) == 0)) {
+        g.map_gx = gx; g.map_gy = gy;
+        const int supers = ((gx + 7) / 8) * ((gy + 7) / 8);
+        grid = dim3(((supers + 7) / 8) * 8 * 64, 1, nsplit);
+    }
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 2 * (kBM + kBN) * kLdsStride, static_cast<hipStream_t>(stream), g);
     return ka_check_launch("tf_gemm_nt");
 }
 // C[z][N][ldc] (fp32 slabs, z < ka_tf_gemm_tn_slabs(M, nsplit)) = partial sums over token ranges of A^T B, A [M][lda] and

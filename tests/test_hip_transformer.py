@@ -96,6 +96,36 @@ def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
     assert float((new[2].float().cpu() - want).abs().max()) <= 0.02 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1300, 1024), (1024, 1027, 1088), (1281, 2048, 1024)])
+def test_gemm_nt_big_tile_form_equals_the_tiled_kernel(monkeypatch, M, N, K):
+    """M, N, K >= 1024 with a bias-only epilogue (the policy layer's three products) take gemm_nt_big_kernel (256 x 256 tiles, an XCD
+    walking 4 x 8 super-tiles); KA_TF_BIG=0 sends the call to gemm_nt_bf16_kernel, whose grid for these shapes is the 8 x 8
+    super-tile map, and KA_TF_MAP2D=0 to its one-m-tile-per-XCD map.  Same products in the same k order: bit for bit, fp32
+    and bf16 outputs, ragged M and N (N not a multiple of 4: the scalar store path), and against fp32 math."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    b = (torch.randn(N, K, generator=g) / 32).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+
+    def run():
+        o32 = torch.full((M, N), float("nan"), device=DEV)
+        _lib.call("ka_tf_gemm_nt", a, b, o32, bias, None, M, N, K, K, K, N, 0, 0, 1, 0.0, 0, st())
+        ldc = (N + 7) // 8 * 8
+        o16 = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.call("ka_tf_gemm_nt", a, b, o16, None, None, M, N, K, K, K, ldc, 1, 0, 1, 0.0, 0, st())
+        torch.cuda.synchronize()
+        return o32, o16[:, :N].clone()
+    big = run()
+    monkeypatch.setenv("KA_TF_BIG", "0")
+    tiled = run()
+    monkeypatch.setenv("KA_TF_MAP2D", "0")
+    plain = run()
+    for x, y, z in zip(big, tiled, plain):
+        assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y) and torch.equal(y, z)
+    want = (a.float() @ b.float().T + bias).cpu()
+    assert torch.allclose(big[0].cpu(), want, rtol=1e-4, atol=1e-3 * math.sqrt(K) / 8)
+
+
 @pytest.mark.parametrize("M,N,K,p", [(300, 256, 96, 0.1), (130, 200, 64, 0.0), (257, 1024, 256, 0.3)])
 def test_masked_gemm_equals_gemm_then_dropout_relu_backward(M, N, K, p):
     """ka_tf_gemm_nt_masked (dropout + ReLU backward in the epilogue of the input-gradient GEMM) against the two-launch

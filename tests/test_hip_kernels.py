@@ -788,11 +788,12 @@ def test_streaming_conv_is_bit_identical_to_the_default_kernel(monkeypatch, tran
     assert torch.equal(out0, out1) and torch.equal(bsum0, bsum1) and torch.equal(sq0, sq1)
 
 
-@pytest.mark.parametrize("B", [515, 1024])
+@pytest.mark.parametrize("B", [515, 1024, 4096])
 def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(monkeypatch, B):
     """conv3x3_pc_kernel (staging waves + MFMA waves, the default for the forward forms at training batch sizes): the same
     summation order, weight packs and epilogues as conv3x3_kernel -- all four launch kinds agree bit for bit, including a
-    board count that does not divide the 256 persistent workgroups."""
+    board count that does not divide the 256 persistent workgroups and the headline minibatch (4096: 16 boards per
+    workgroup, the transform-input form conv2 runs in the step)."""
     C = 256
     g = torch.Generator(device=DEV).manual_seed(B)
     rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)

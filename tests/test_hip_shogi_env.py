@@ -238,6 +238,68 @@ def test_repetition_and_perpetual_check_through_the_step_api():
     assert last["termination_reason"][0] == S.R_PERPETUAL and last["rewards"][0] == -1.0      # Black moved last and loses
 
 
+def test_repetition_heavy_play_matches_the_oracle():
+    """The device env recognises a repeated position by a 64-bit key of (board, hands, side), the oracle by comparing whole
+    positions: 96 sparse games (two kings and up to four other pieces, hands part of the position) in which both sides mostly
+    take their last move back, with random other moves, drops and captures mixed in -- hundreds of fourfold repetitions and
+    perpetual checks reached through transpositions, every output of every step identical."""
+    n, rng = 96, np.random.default_rng(77)
+    boards, hands, sides = np.zeros((n, 81), np.uint8), np.zeros((n, 2, 7), np.uint8), np.zeros(n, np.uint8)
+    kinds = [GOLD, SILVER, ROOK, BISHOP, LANCE, S.KNIGHT, GOLD, SILVER]
+    probe = OracleVecEnv(1, 300); probe.reset()
+    i = 0
+    while i < n:
+        b, h = S.empty_board()
+        free = list(rng.permutation(81))
+        b[free.pop()] = KING; b[free.pop()] = KING | WHITE
+        for _ in range(int(rng.integers(0, 5))):
+            k = kinds[int(rng.integers(len(kinds)))]
+            cell = free.pop()
+            if k in (LANCE, S.KNIGHT) and not 2 <= cell // 9 <= 6: continue        # (no piece without a move)
+            b[cell] = k | (WHITE if rng.random() < 0.5 else 0)
+        if rng.random() < 0.5: h[int(rng.integers(2)), int(rng.integers(1, 7))] = 1
+        side = int(rng.integers(2))
+        probe.set_state(0, b, h, side)
+        other_king = int(np.flatnonzero(b == (KING if side else KING | WHITE))[0])
+        if probe.attack_map(0)[side][other_king] or probe.legal_count(0) == 0: continue   # (a legal position with a move to make)
+        boards[i], hands[i], sides[i] = b, h, side
+        i += 1
+    dev, ref = _env(n, 300), OracleVecEnv(n, 300)
+    dev.reset(); ref.reset()
+    dev.set_states(boards, hands, sides)
+    for i in range(n): ref.set_state(i, boards[i], hands[i], int(sides[i]))
+    cur = dev.current()
+    mask, players = cur.legal_masks, sides.copy()
+    for i in range(n):
+        assert np.array_equal(mask[i], ref.observe(i)[1]), i
+    last = {}                                                # (game, colour) -> (from, to) of that side's previous board move
+    reasons = np.zeros(6, int)
+    for step in range(260):
+        acts = np.zeros(n, np.int64)
+        for i in range(n):
+            w = bool(players[i])
+            legal = np.flatnonzero(mask[i])
+            a = None
+            if (i, w) in last and rng.random() < 0.85:
+                f, t = last[(i, w)]
+                back = S.encode(t, f, white=w)
+                if back >= 0 and mask[i][back]: a = back
+            if a is None: a = int(rng.choice(legal))
+            d = S.decode(a, white=w)                         # (from, to, promote, drop)
+            if d is not None and d[3] == 0: last[(i, w)] = (d[0], d[1])
+            else: last.pop((i, w), None)
+            acts[i] = a
+        rd, rr = dev.step(acts), ref.step(acts)
+        _compare_step(rd, rr, f"step {step}")
+        mask, players = rr["legal_masks"], rr["current_players"]
+        done = rr["terminated"] | rr["truncated"]
+        for i in np.flatnonzero(done):
+            reasons[rr["termination_reason"][i]] += 1
+            last.pop((i, False), None); last.pop((i, True), None)
+    assert reasons[S.R_REPETITION] >= 100, reasons
+    assert dev.episodes_drawn == ref.stats()["episodes_drawn"]
+
+
 def test_impasse_through_the_step_api():
     # rules.rs:1190-1290: both kings entered, ten pieces each in the zone, Black reaches 24 points with three rooks in hand
     b, h = S.empty_board()

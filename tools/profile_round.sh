@@ -24,8 +24,8 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_tffetch -o f -- python3 $root/bench.py --workload transformer --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_tffetch.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_tfwrite -o w -- python3 $root/bench.py --workload transformer --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_tfwrite.log 2>&1
 cd $root
-python3 tools/pmc_traffic.py $(find $out/${tag}_tffetch -name "*counter_collection.csv" | head -1) $(find $out/${tag}_tfwrite -name "*counter_collection.csv" | head -1) $out/${tag}_transformer_pmc_hbm_traffic.json "bench.py --workload transformer (d 256, 8 heads, 6 layers, minibatch 4096, bf16), 1 warm-up + 1 timed step"
-python3 - $out/${tag}_transformer_pmc_hbm_traffic.json $out/${tag}_transformer_bench_under_rocprof.json <<'PY'
+python3 tools/pmc_traffic.py $(find $out/${tag}_tffetch -name "*counter_collection.csv" | head -1) $(find $out/${tag}_tfwrite -name "*counter_collection.csv" | head -1) $out/${tag}_transformer_hbm_traffic.json "bench.py --workload transformer (d 256, 8 heads, 6 layers, minibatch 4096, bf16), 1 warm-up + 1 timed step"
+python3 - $out/${tag}_transformer_hbm_traffic.json $out/${tag}_transformer_bench_under_rocprof.json <<'PY'
 import json, sys
 t = json.load(open(sys.argv[1]))
 tot = sum(k["launches"] * k["hbm_bytes_per_launch"] for k in t["kernels"].values()) / 2        # two steps in the trace

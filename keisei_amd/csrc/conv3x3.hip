@@ -87,6 +87,7 @@ struct ConvArgs {
     float* ep_s1; float* ep_s2;
     int tune_stagger, tune_prio;  // experiments: s_sleep count / static priority of the second wave of every SIMD
     unsigned long long* stamps;   // diagnostic only: [workgroup][8] s_memtime at phase boundaries (null in production)
+    int mt5;                      // five row tiles (squares 0..79) in the tower kernels, square 80 by conv3x3_corner_kernel
 };
 
 std::atomic<unsigned long long*> g_stamps{nullptr};   // diagnostic only (ka_debug_conv_stamps); null in production
@@ -110,8 +111,8 @@ template <> struct Mma<float> {
 
 // ---- epilogue, all in registers: lane (r, q) holds square mt*16+r of board bb for every row tile mt, and for
 // tile j the 4 consecutive channels cb[j] .. cb[j]+3 (tiles 2k and 2k+1 together: 8 consecutive channels)
-template <typename T, int NTW>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kMTW][NTW], int bb, int nt0, int NT, int r, int q) {
+template <typename T, int NTW, int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NTW], int bb, int nt0, int NT, int r, int q) {
     int cb[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) cb[j] = chan_of(min(nt0 + j, NT - 1), 4 * q, NT);
@@ -119,11 +120,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
     // then covers their HBM latency (requesting both pairs up front spills and is slower)
     constexpr int TP0 = NTW >= 2 ? 2 : 1;
     typedef __attribute__((ext_vector_type(4 * TP0))) __bf16 bvec0;
-    bvec0 yv0[kMTW];
+    bvec0 yv0[MT];
     if constexpr (sizeof(T) == 2) {
         if (a.ep_y) {
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const int p = mt * 16 + r;
                 yv0[mt] = bvec0{};
                 if (p < KA_BOARD)
@@ -139,7 +140,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s0[i] = 0.f; ss[i] = 0.f; }
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const bool in = mt * 16 + r < KA_BOARD;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -158,7 +159,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
     if constexpr (sizeof(T) == 2) {
         if (!a.ep_y) {
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const int p = mt * 16 + r;
                 if (p >= KA_BOARD) continue;
                 char* orow = static_cast<char*>(a.out) + (size_t)(bb * KA_BOARD + p) * a.Cout * 2;
@@ -185,9 +186,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
 #pragma unroll
             for (int j = 0; j < NTW; j += TP) {
                 if (nt0 + j >= NT) continue;
-                bvec yv[kMTW];
+                bvec yv[MT];
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const int p = mt * 16 + r;
                     if (j == 0) { yv[mt] = yv0[mt]; continue; }
                     yv[mt] = bvec{};
@@ -203,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
                     t1[e] = 0.f; t2[e] = 0.f;
                 }
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const int p = mt * 16 + r;
                     const bool in = p < KA_BOARD;
                     bvec o;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
     } else {
         float* out = static_cast<float*>(a.out);
 #pragma unroll
-        for (int mt = 0; mt < kMTW; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + r;
             if (p >= KA_BOARD) continue;
 #pragma unroll
@@ -245,7 +246,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[kM
 // workgroup: 2 -> 512 threads, the second wave of every SIMD owns the second board and its MFMAs fill the first one's
 // LDS/L2 stalls; 1 -> 256 threads and two INDEPENDENT workgroups per CU (registers capped at 256 by the launch
 // bounds), so that the staging and epilogue of one overlap the MFMA loop of the other.
-template <typename T, int NTW, int WM>
+template <typename T, int NTW, int WM, int MT>
 __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     constexpr int kThreads = 256 * WM;
     constexpr int kRows = WM * KA_BOARD;         // staged squares
@@ -265,15 +266,15 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
     const int KSG = a.Cin / CPK;                 // k-steps over all input channels
     const int KS = a.KC / CPK;                   // k-steps per LDS chunk
 
-    f32x4 acc[kMTW][NTW];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int mt = 0; mt < kMTW; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int rowoff[kMTW];
+    int rowoff[MT];
 #pragma unroll
-    for (int mt = 0; mt < kMTW; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int p = mt * 16 + r;                     // square of board `mhalf`
         // dummy rows (81 -> 96 padding; never stored) read an all-zero region behind the image: every tap offset of its
         // centre square stays inside it.  Zero operands cost the matrix pipe less power than duplicates of square 0,
@@ -440,13 +441,13 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
             };
             // A fragments are double-buffered in registers across steps: while step s multiplies from `ac`, the
             // 11 LDS reads of step s+1 land in `an` (a whole step of MFMA time to hide LDS latency/conflicts).
-            auto load_a = [&](vec16 (&av)[kMTW], int toff) {
+            auto load_a = [&](vec16 (&av)[MT], int toff) {
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) av[mt] = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff);
             };
-            auto compute = [&](const vec16 (&bw)[NTW], const vec16 (&av)[kMTW], vec16 (&anext)[kMTW], int toff_next) {
+            auto compute = [&](const vec16 (&bw)[NTW], const vec16 (&av)[MT], vec16 (&anext)[MT], int toff_next) {
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
 #ifndef KA_DIAG_NO_A
                     anext[mt] = *reinterpret_cast<const vec16*>(smem + rowoff[mt] + toff_next);
 #else
@@ -458,12 +459,12 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
                 // pin the issue order: one LDS read ahead of every group of MFMAs (the scheduler otherwise
                 // sinks all 11 reads behind the MFMA block and the next step starts by waiting for them)
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NTW * (sizeof(T) == 2 ? 1 : 4), 0);
                 }
             };
-            vec16 b0[NTW], b1[NTW], a0[kMTW], a1[kMTW];
+            vec16 b0[NTW], b1[NTW], a0[MT], a1[MT];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) b0[j] = bpre[j];
             load_a(a0, lds_off(0));
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3x3_kernel(ConvArgs a) {
 
     if (a.stamps && tid == 0) a.stamps[wg_lin * 8 + 2] = __builtin_amdgcn_s_memtime();
     const int bb = b0 + mhalf;
-    if (wave_active && bb < a.B) conv_epilogue<T, NTW>(a, acc, bb, nt0, NT, r, q);
+    if (wave_active && bb < a.B) conv_epilogue<T, NTW, MT>(a, acc, bb, nt0, NT, r, q);
     if (a.stamps && tid == 0) {
         a.stamps[wg_lin * 8 + 7] = __builtin_amdgcn_s_memtime();
         a.stamps[wg_lin * 8 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -576,177 +577,27 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int BN = 64 * NTW;
     const size_t lds = (size_t)((WM == 2 ? kLdsSquares : kImgSquares1) + kZeroSquares) * (a.KC * E::kSize + 32);
     KA_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS tile %zu B exceeds 160 KiB (KC=%d)", lds, a.KC);
-    static std::atomic<unsigned long long> attr_done{0};   // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM>), attr_done, "conv3x3")) return rc;
     dim3 grid((a.B + WM - 1) / WM, (a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM>), grid, dim3(256 * WM), lds, st, a);
+    if constexpr (sizeof(T) == 2 && NTW == 4 && WM == 1) {
+        if (a.mt5) {
+            static std::atomic<unsigned long long> attr5{0};
+            if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM, 5>), attr5, "conv3x3 (5 row tiles)")) return rc;
+            hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM, 5>), grid, dim3(256 * WM), lds, st, a);
+            return ka_check_launch("conv3x3 (5 row tiles)");
+        }
+    }
+    KA_REQUIRE(!a.mt5, "conv3x3: the five-row-tile form exists for bf16, 4 tiles per wave, one board per workgroup");
+    static std::atomic<unsigned long long> attr_done{0};   // per instantiation: devices already configured
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_kernel<T, NTW, WM, kMTW>), attr_done, "conv3x3")) return rc;
+    hipLaunchKernelGGL((conv3x3_kernel<T, NTW, WM, kMTW>), grid, dim3(256 * WM), lds, st, a);
     return ka_check_launch("conv3x3");
 }
 
-// ---------------------------------------------------------------- streaming form (bf16, Cin = Cout = 256, training batches)
-// The MFMA loop of the one-launch eval tower (tower.hip) as a training convolution: a persistent 512-thread workgroup
-// per CU walks its boards; 8 waves x (6 row tiles x 2 channel tiles), fragment-ordered weights through a four-slot
-// register ring three k-steps ahead, activation fragments double-buffered across k-steps with the issue order pinned --
-// that loop runs at the matrix-core issue rate (tower_bench: 239 us per 4096-board convolution), where the two
-// 256-thread workgroups of conv3x3_kernel spend 370 us.  What the second workgroup gave for free is done by hand here:
-// the NEXT board's input pieces are requested from HBM before this board's MFMA phases and written (input transform
-// applied) into the other natural-layout LDS buffer after them; the haloed 128-channel image is rebuilt LDS -> LDS per
-// chunk.  Same ConvArgs, same epilogue (conv_epilogue<bf16_t, 2>), same weight packs as conv3x3_kernel: bit-identical results.
-// Measured (B = 4096): 5 % faster than conv3x3_kernel alone (0.373 vs 0.393 ms; 15 % under sustained back-to-back launches),
-// 1 % SLOWER inside the training step (119.0 vs 117.7 ms: it fills every CU, so the side-stream FC chain of the forward no
-// longer runs beside conv1) -- opt-in (KA_CONV_T=1, forward convolutions only), conv3x3_kernel stays the default.
-constexpr int kStNat = KA_BOARD * 512;                     // natural [81][256] bf16
-constexpr int kStImgStride = 128 * 2 + 32;
-constexpr int kStImg = 2 * kStNat;
-constexpr int kStLds = kStImg + (kImgSquares1 + kZeroSquares) * kStImgStride;   // + the all-zero squares the padded rows read
-
-template <bool TWO>      // TWO: the two-tensor input of the data-gradient convolutions (and their optional masked epilogue)
-__global__ __launch_bounds__(512) void conv3x3_stream_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    const int nwg = gridDim.x;
-    if ((int)blockIdx.x >= a.B) return;
-    for (int i = tid; i < (kImgSquares1 + kZeroSquares) * kStImgStride / 16; i += 512) reinterpret_cast<uint4*>(smem + kStImg)[i] = uint4{0, 0, 0, 0};
-
-    // ---- staging role: piece i = tid + 512 u (u < 6) of a board = row i / 32, 16-byte piece i % 32 = tid % 32 (8 channels)
-    const int pc = tid & 31, ch0 = pc * 8;
-    const bool has_aff = a.in_scale != nullptr;
-    constexpr bool two = TWO;
-    if (!TWO) a.ep_y = nullptr;                              // (compile-time: the masked epilogue belongs to the data-gradient form)
-    bf16x8 pv[6], pw[TWO ? 6 : 1];
-    f32x4 pb[2];
-    auto request = [&](int bb) {                            // raw pieces of board bb into registers
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int i = tid + 512 * u;
-            pv[u] = bf16x8{};
-            if (TWO) pw[TWO ? u : 0] = bf16x8{};
-            if (i < KA_BOARD * 32) {
-                const size_t off = ((size_t)bb * KA_BOARD * 32 + i) * 16;
-                pv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
-                if (TWO) pw[TWO ? u : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
-            }
-        }
-        if (!TWO && a.in_bias) {
-            pb[0] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0);
-            pb[1] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0 + 4);
-        }
-    };
-    auto commit = [&](int bb, int buf) {                    // transform and write into natural buffer `buf`
-        float sc[8], sh[8], k3[8];                           // (re-read per board: cache-resident, and 24 registers fewer across the MFMAs)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
-            k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int i = tid + 512 * u;
-            if (i >= KA_BOARD * 32) continue;
-            bf16x8 v = pv[u];
-            if (two) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? u : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
-                if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + ((size_t)bb * KA_BOARD * 32 + i) * 16) = v;
-            } else if (has_aff || a.relu || a.in_bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f = (float)v[e];
-                    if (has_aff) f = fmaf(f, sc[e], sh[e]);
-                    if (a.relu) f = fmaxf(f, 0.f);
-                    if (a.in_bias) f += pb[e >> 2][e & 3];
-                    v[e] = (__bf16)f;
-                }
-            }
-            *reinterpret_cast<bf16x8*>(smem + buf * kStNat + i * 16) = v;
-        }
-    };
-
-    int rowoff[kMTW];
-#pragma unroll
-    for (int mt = 0; mt < kMTW; ++mt) {
-        const int p = mt * 16 + r;
-        rowoff[mt] = kStImg + (p < KA_BOARD ? lds_square(0, p) : kImgSquares1 + kPW + 1) * kStImgStride + q * 16;
-    }
-    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
-    auto wfrag = [&](int kc, int step, bf16x8 (&f)[2]) {   // step = tap*4 + ks4 within the 128-channel chunk (clamped)
-        step = min(step, 35);
-        const int tap = step >> 2, ks = kc * 4 + (step & 3);
-        const char* p = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
-        f[0] = *reinterpret_cast<const bf16x8*>(p);
-        f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
-    };
-    auto toff_of = [&](int step) {
-        step = min(step, 35);
-        const int tap = step >> 2, ks = step & 3;
-        return ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kStImgStride + ks * 64;
-    };
-
-    int bb = blockIdx.x, it = 0;
-    request(bb);
-    commit(bb, 0);
-    // The pieces of board n+1 are requested right after board n's pieces have been written to LDS -- i.e. BEFORE the
-    // epilogue of board n-1 -- not at the top of board n's MFMA phases: vector-memory returns are counted in order, so
-    // the first wait for a weight fragment is also a wait for that request, and the epilogue + image build in between
-    // give HBM its 2-3 us.
-    if (bb + nwg < a.B && !(a.tune_stagger & 2)) request(bb + nwg);
-    for (; bb < a.B; bb += nwg, ++it) {
-        const int cur = it & 1, nb = bb + nwg;
-        f32x4 acc[kMTW][2];
-#pragma unroll
-        for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const int abl = a.tune_stagger;                      // diagnostics (KA_CONV_T_ABL): 1 no epilogue, 2 no staging of the next board, 4 no MFMA steps, 8 no image builds
-        for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 w0[2], w1[2], w2[2], w3[2];
-            wfrag(kc, 0, w0); wfrag(kc, 1, w1); wfrag(kc, 2, w2);
-            KA_LDS_BARRIER();                                // the image's previous readers are done; the natural buffer is complete
-            if (!(abl & 8)) for (int i = tid; i < KA_BOARD * 16; i += 512) {
-                const int row = i >> 4, p16 = i & 15;
-                *reinterpret_cast<uint4*>(smem + kStImg + lds_square(0, row) * kStImgStride + p16 * 16) =
-                    *reinterpret_cast<const uint4*>(smem + cur * kStNat + row * 512 + kc * 256 + p16 * 16);
-            }
-            KA_LDS_BARRIER();
-            auto mm = [&](const bf16x8 (&wf)[2], const bf16x8 (&ac)[kMTW], bf16x8 (&an)[kMTW], int next_step) {
-                const int toff = toff_of(next_step);
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
-                    an[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-            };
-            bf16x8 fa[kMTW], fb[kMTW];
-            {
-                const int toff = toff_of(0);
-#pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
-            }
-#pragma unroll 1
-            for (int tap = 0; tap < ((abl & 4) ? 0 : 9); ++tap) {
-                const int s0 = tap * 4;
-                wfrag(kc, s0 + 3, w3); __builtin_amdgcn_sched_barrier(0); mm(w0, fa, fb, s0 + 1); __builtin_amdgcn_sched_barrier(0);
-                wfrag(kc, s0 + 4, w0); __builtin_amdgcn_sched_barrier(0); mm(w1, fb, fa, s0 + 2); __builtin_amdgcn_sched_barrier(0);
-                wfrag(kc, s0 + 5, w1); __builtin_amdgcn_sched_barrier(0); mm(w2, fa, fb, s0 + 3); __builtin_amdgcn_sched_barrier(0);
-                wfrag(kc, s0 + 6, w2); __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (nb < a.B && !(abl & 2)) {
-            commit(nb, cur ^ 1);                             // (the other natural buffer: last read two boards ago)
-            if (nb + nwg < a.B) request(nb + nwg);
-        }
-        if (!(abl & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
-    }
-}
-
+constexpr int kStImgStride = 128 * 2 + 32;                 // bytes per square of a 128-channel LDS image (32 B more than a multiple of 256)
 // ---------------------------------------------------------------- producer / consumer form (bf16, Cin = Cout = 256)
-// What keeps conv3x3_kernel and the streaming form at ~365 us is that staging (HBM latency + input transform + LDS
+// What keeps conv3x3_kernel at ~365 us is that staging (HBM latency + input transform + LDS
 // writes) and the MFMA phases of a workgroup are serial; two workgroups per CU overlap them only by chance.  Here the
-// overlap is explicit: a persistent 768-thread workgroup per CU, waves 0-7 multiply (the streaming form's loop, weights
+// overlap is explicit: a persistent 768-thread workgroup per CU, waves 0-7 multiply (the eval tower's loop, weights
 // through the register ring, continuous across units), waves 8-11 stage the NEXT unit -- one (board, 128-channel chunk)
 // -- straight into the other of two zero-haloed LDS images while the current one is multiplied.  One LDS-only barrier
 // per unit.  The input transforms (BatchNorm + ReLU + bias, or the two-tensor data-gradient input and its write-back)
@@ -758,7 +609,7 @@ constexpr int kPcLds = kPcZero + kZeroSquares * kStImgStride;
 constexpr int kPcYStride = 256 * 2 + 16;                                  // the masked epilogue's y rows in LDS (16 B of padding: 2-way conflicts at most)
 constexpr int kPcLdsMasked = kPcLds + KA_BOARD * kPcYStride;
 
-template <bool TWO, bool MASKED, int NPW = 4>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue; NPW staging waves
+template <bool TWO, bool MASKED, int NPW = 4, int MT = 6>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue; NPW staging waves; MT row tiles
 __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) {
     constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
     constexpr int KP = (KA_BOARD * 16 + NP - 1) / NP, KY = (KA_BOARD * 32 + NP - 1) / NP;
@@ -868,64 +719,45 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
     };
     bf16x8 w0[2], w1[2], w2[2], w3[2];
     wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);
-    f32x4 acc[kMTW][2];
-#ifdef KA_PC_MFMA32
-    f32x16 acc32[3];
-#endif
+    f32x4 acc[MT][2];
     KA_LDS_BARRIER();                                        // unit 0 is staged
     for (int u = 0; u < nunits; ++u) {
         const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1;
         if (!kc) {
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#ifdef KA_PC_MFMA32
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc32[t][e] = 0.f;
-#endif
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
-        int rowoff[kMTW];
+        int rowoff[MT];
 #pragma unroll
-        for (int mt = 0; mt < kMTW; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + r;
             rowoff[mt] = (p < KA_BOARD ? (u & 1) * kPcImg + lds_square(0, p) * kStImgStride : kPcZero + (kPW + 1) * kStImgStride) + q * 16;
         }
-        auto mm = [&](const bf16x8 (&wf)[2], const bf16x8 (&ac)[kMTW], bf16x8 (&an)[kMTW], int next_step) {
+        auto mm = [&](const bf16x8 (&wf)[2], const bf16x8 (&ac)[MT], bf16x8 (&an)[MT], int next_step) {
             const int toff = toff_of(next_step);
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #ifndef KA_PC_NO_A
                 an[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
 #else
                 an[mt] = ac[mt]; (void)toff;                 // ablation build (tools/_diag/build_variants.sh): no activation-fragment LDS reads
 #endif
-#ifndef KA_PC_MFMA32
                 acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], ac[mt], acc[mt][0], 0, 0, 0);
                 acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], ac[mt], acc[mt][1], 0, 0, 0);
-#else
-                // ablation build (timing / held clock only, WRONG results): the same operand registers and the same matrix-pipe
-                // cycles as ONE v_mfma_f32_32x32x16_bf16 per (row tile, k-step) -- half the instructions and operand reads per FLOP
-                acc32[mt >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mt & 1], ac[mt], acc32[mt >> 1], 0, 0, 0);
-#endif
             }
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #ifndef KA_PC_NO_A
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #endif
-#ifndef KA_PC_MFMA32
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#else
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#endif
             }
         };
-        bf16x8 fa[kMTW], fb[kMTW];
+        bf16x8 fa[MT], fb[MT];
         {
             const int toff = toff_of(0);
 #pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const bf16x8*>(smem + rowoff[mt] + toff);
         }
 #ifdef KA_PC_NO_W
 #define wfrag(...) ((void)0)                                 // ablation build: the ring keeps its first fragments
@@ -947,17 +779,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
 #ifdef KA_PC_NO_W
 #undef wfrag
 #endif
-#ifdef KA_PC_MFMA32
-        if (kc) {
-#pragma unroll
-            for (int mt = 0; mt < kMTW; ++mt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][j][e] = acc32[mt >> 1][(mt & 1) * 8 + j * 4 + e];
-        }
-#endif
-        if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2>(a, acc, bb, wave * 2, 16, r, q);
+        if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2, MT>(a, acc, bb, wave * 2, 16, r, q);
         KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete
         if (MASKED && kc) {
             // da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums (conv_epilogue's masked branch, term for term), y from LDS
@@ -972,7 +794,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
                 for (int j = 0; j < 2; ++j) {
                     float s0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int mt = 0; mt < kMTW; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         const bool in = mt * 16 + rl < KA_BOARD;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) s0[i] += in ? acc[mt][j][i] : 0.f;
@@ -984,7 +806,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
             }
             // two passes of four channels (one MFMA tile each): half the coefficient / sum registers at a time; the first
             // pass's bf16 results wait in 12 registers so that the rows still leave as 16-byte pieces
-            bf16x4 o0[kMTW];
+            bf16x4 o0[MT];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float esc[4], esh[4], emu[4], eis[4], t1[4], t2[4];
@@ -995,7 +817,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
                     t1[e] = 0.f; t2[e] = 0.f;
                 }
 #pragma unroll
-                for (int mt = 0; mt < kMTW; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const int p = mt * 16 + rl;
                     const bool in = p < KA_BOARD;
                     bf16x4 yv = bf16x4{};
@@ -1029,45 +851,186 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
     }
 }
 
+template <bool TWO, bool MASKED, int NPW, int MT>
+static int launch_conv_pc_form(const ConvArgs& a, int grid, size_t lds, hipStream_t st, const char* what) {
+    static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<TWO, MASKED, NPW, MT>), done, what)) return rc;
+    hipLaunchKernelGGL((conv3x3_pc_kernel<TWO, MASKED, NPW, MT>), dim3(grid), dim3(512 + 64 * NPW), lds, st, a);
+    return ka_check_launch(what);
+}
 static int launch_conv_pc(ConvArgs a, hipStream_t st) {
-    static std::atomic<unsigned long long> done0{0}, done1{0};
     a.tune_stagger = 0; a.tune_prio = 0;                       // diagnostics: KA_CONV_P_ABL 1 no epilogue, 2 no staging after the first unit
     if (const char* e = ka_diag_env("KA_CONV_P_ABL")) a.tune_stagger = atoi(e);
     if (const char* e = getenv("KA_CONV_P_PRIO")) a.tune_prio = atoi(e);
     int grid = 256;
     if (const char* e = getenv("KA_CONV_P_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
     if (grid > a.B) grid = a.B;
-    static std::atomic<unsigned long long> done2{0};
-    if (a.in2 && a.ep_y) {
-        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, true>), done2, "conv3x3 (pc, masked)")) return rc;
-        hipLaunchKernelGGL((conv3x3_pc_kernel<true, true>), dim3(grid), dim3(768), kPcLdsMasked, st, a);
-    } else if (a.in2) {
-        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<true, false>), done1, "conv3x3 (pc, two-tensor)")) return rc;
-        hipLaunchKernelGGL((conv3x3_pc_kernel<true, false>), dim3(grid), dim3(768), kPcLds, st, a);
-    } else if (const char* e = getenv("KA_CONV_P_NPW"); e ? atoi(e) == 2 : (a.in_scale || a.relu || a.in_bias)) {
-        // two staging waves where the input carries a transform (its arithmetic shares the SIMDs with the MFMA waves: measured
-        // 0.369-0.374 against 0.380-0.386 ms with four), four for the plain input (0.339 against 0.349); KA_CONV_P_NPW forces one
-        static std::atomic<unsigned long long> done3{0};
-        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false, 2>), done3, "conv3x3 (pc, 2 staging waves)")) return rc;
-        hipLaunchKernelGGL((conv3x3_pc_kernel<false, false, 2>), dim3(grid), dim3(640), kPcLds, st, a);
-    } else {
-        if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<false, false>), done0, "conv3x3 (pc)")) return rc;
-        hipLaunchKernelGGL((conv3x3_pc_kernel<false, false>), dim3(grid), dim3(768), kPcLds, st, a);
-    }
-    return ka_check_launch("conv3x3 (pc)");
+#define KA_PC_FORM(TWO_, MASKED_, NPW_, LDS_, WHAT_)                                                         \
+    (a.mt5 ? launch_conv_pc_form<TWO_, MASKED_, NPW_, 5>(a, grid, LDS_, st, WHAT_ ", 5 row tiles")            \
+           : launch_conv_pc_form<TWO_, MASKED_, NPW_, kMTW>(a, grid, LDS_, st, WHAT_))
+    if (a.in2 && a.ep_y) return KA_PC_FORM(true, true, 4, kPcLdsMasked, "conv3x3 (pc, masked)");
+    if (a.in2) return KA_PC_FORM(true, false, 4, kPcLds, "conv3x3 (pc, two-tensor)");
+    // two staging waves where the input carries a transform (its arithmetic shares the SIMDs with the MFMA waves: measured
+    // 0.369-0.374 against 0.380-0.386 ms with four), four for the plain input (0.339 against 0.349); KA_CONV_P_NPW forces one
+    if (const char* e = getenv("KA_CONV_P_NPW"); e ? atoi(e) == 2 : (a.in_scale || a.relu || a.in_bias))
+        return KA_PC_FORM(false, false, 2, kPcLds, "conv3x3 (pc, 2 staging waves)");
+    return KA_PC_FORM(false, false, 4, kPcLds, "conv3x3 (pc)");
+#undef KA_PC_FORM
 }
 
-static int launch_conv_stream(ConvArgs a, hipStream_t st) {
-    a.tune_stagger = 0;
-    if (const char* e = ka_diag_env("KA_CONV_T_ABL")) a.tune_stagger = atoi(e);      // diagnostics only
-    static std::atomic<unsigned long long> done{0};
-    int grid = 256;
-    if (const char* e = getenv("KA_CONV_T_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
-    if (grid > a.B) grid = a.B;
-    // (the two-tensor data-gradient form, conv3x3_stream_kernel<true>, compiles but spills at 256 registers: not dispatched)
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_stream_kernel<false>), done, "conv3x3 (stream)")) return rc;
-    hipLaunchKernelGGL(conv3x3_stream_kernel<false>, dim3(grid), dim3(512), kStLds, st, a);
-    return ka_check_launch("conv3x3 (stream)");
+// ---------------------------------------------------------------- square 80 of sixteen boards as one row tile
+// 81 squares are five row tiles and one square.  As a sixth tile that square cost every (tap, k-step) of every wave two MFMAs
+// on 15 zero rows -- 16.7 % of the matrix work and of the activation-fragment reads for 1.2 % of the output (measured: the
+// tower kernels are 6-7 % faster without it, tools/_diag/job_r3_j.sh).  The tower kernels therefore compute squares 0..79
+// (MT = 5) and this kernel the corner: a workgroup takes SIXTEEN boards, whose corner squares are the 16 rows of ONE tile,
+// over K = 4 taps x 256 channels -- only the taps (-1,-1), (-1,0), (0,-1), (0,0) of square (8,8) lie on the board; the
+// other five multiplied zeros.  Same weight pack, same input transforms, same (chunk, tap, k-step) order: out[b, 80, :] is
+// bit-identical to the six-tile kernels'.  The per-board sums the tower kernel wrote (over 80 squares) receive the corner's
+// terms here (+=: one lane per (board, channel), stream-ordered behind the tower kernel; a fixed order of additions).
+constexpr int kCornerBoards = 16, kCornerStride = 4 * 512 + 16;      // 2064 B per board: 16 fragment lanes on 16 bank slots
+
+__global__ __launch_bounds__(256) void conv3x3_corner_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) char cs[kCornerBoards * kCornerStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * kCornerBoards;
+    // ---- stage [board][tap slot][256 channels]: squares 70, 71, 79, 80 = taps 0, 1, 3, 4 of square 80, transformed as the tower
+    // kernels' staging transforms them (statement for statement)
+    const bool has_aff = a.in_scale != nullptr;
+    const int pc = tid & 31, ch0 = pc * 8;                   // this thread's channel piece is the same for its 8 pieces
+    float sc[8], sh[8], k3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; k3[e] = 0.f; }
+    if (has_aff) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0), s1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0), t1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = t0[e]; sh[4 + e] = t1[e]; }
+    }
+    if (a.in2) {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0), u1 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k3[e] = u0[e]; k3[4 + e] = u1[e]; }
+    }
+    bf16x8 pv[8], pw[8];
+    f32x4 pb[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                            // every load of the 8 pieces in flight before the first is used
+        const int i = tid + 256 * k, bl = i >> 7, ps = (i >> 5) & 3, bb = min(b0 + bl, a.B - 1);
+        const int p = ps == 0 ? 70 : ps == 1 ? 71 : ps == 2 ? 79 : 80;
+        const size_t off = (((size_t)bb * KA_BOARD + p) * 256 + ch0) * 2;
+        pv[k] = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off);
+        pw[k] = a.in2 ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off) : bf16x8{};
+        pb[k][0] = pb[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.in_bias) {
+            pb[k][0] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0);
+            pb[k][1] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0 + 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + 256 * k, bl = i >> 7, ps = (i >> 5) & 3;
+        bf16x8 v = pv[k];
+        if (a.in2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[k][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+        } else if (has_aff || a.relu || a.in_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e];
+                if (has_aff) f = fmaf(f, sc[e], sh[e]);
+                if (a.relu) f = fmaxf(f, 0.f);
+                if (a.in_bias) f += pb[k][e >> 2][e & 3];
+                v[e] = (__bf16)f;
+            }
+        }
+        if (b0 + bl >= a.B) v = bf16x8{};
+        *reinterpret_cast<bf16x8*>(cs + bl * kCornerStride + ps * 512 + pc * 16) = v;
+    }
+    __syncthreads();
+    // ---- wave w: output-channel tiles 4w .. 4w+3 (64 channels), rows = the 16 boards
+    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 4) * 1024 + lane * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int tap = ps < 2 ? ps : ps + 1;            // 0, 1, 3, 4
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int ks = kc * 4 + k4;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cs + r * kCornerStride + ps * 512 + ks * 64 + q * 16);
+                const char* wp = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wp + j * 1024), af, acc[j], 0, 0, 0);
+            }
+        }
+    // ---- epilogue: lane (r, q) = board b0 + r, channels cb .. cb+7 of each tile pair
+    const int bb = b0 + r;
+    if (bb >= a.B) return;
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        const int cb = chan_of(wave * 4 + j, 4 * q, 16);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = acc[j][i]; v[4 + i] = acc[j + 1][i]; }
+        const size_t orow = ((size_t)bb * KA_BOARD + 80) * 256 + cb, srow = (size_t)bb * 256 + cb;
+        if (a.bsum) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(a.bsum + srow + e);
+                t += f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+                *reinterpret_cast<f32x4*>(a.bsum + srow + e) = t;
+            }
+        }
+        if (a.sqpart) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(a.sqpart + srow + e);
+                t += f32x4{v[e] * v[e], v[e + 1] * v[e + 1], v[e + 2] * v[e + 2], v[e + 3] * v[e + 3]};
+                *reinterpret_cast<f32x4*>(a.sqpart + srow + e) = t;
+            }
+        }
+        bf16x8 o;
+        if (!a.ep_y) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        } else {
+            // da = dh * [bn(y) > 0] and its BatchNorm-backward terms (conv_epilogue's masked branch, term for term)
+            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) + orow * 2);
+            float esc[8], esh[8], emu[8], eis[8], t1[8], t2[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ep_scale + cb + 4 * h), c1 = *reinterpret_cast<const f32x4*>(a.ep_shift + cb + 4 * h);
+                const f32x4 c2 = *reinterpret_cast<const f32x4*>(a.ep_mean + cb + 4 * h), c3 = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { esc[4 * h + e] = c0[e]; esh[4 * h + e] = c1[e]; emu[4 * h + e] = c2[e]; eis[4 * h + e] = c3[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = (float)yv[e];
+                const __bf16 db = (__bf16)v[e];
+                const float d = (y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                t1[e] = d; t2[e] = d * ((y - emu[e]) * eis[e]);
+                o[e] = (__bf16)d;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                f32x4 s1 = *reinterpret_cast<const f32x4*>(a.ep_s1 + srow + e), s2 = *reinterpret_cast<const f32x4*>(a.ep_s2 + srow + e);
+                s1 += f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
+                s2 += f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
+                *reinterpret_cast<f32x4*>(a.ep_s1 + srow + e) = s1;
+                *reinterpret_cast<f32x4*>(a.ep_s2 + srow + e) = s2;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + orow * 2) = o;
+    }
+}
+static int launch_conv_corner(const ConvArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(conv3x3_corner_kernel, dim3((a.B + kCornerBoards - 1) / kCornerBoards), dim3(256), 0, st, a);
+    return ka_check_launch("conv3x3 (corner)");
 }
 
 template <typename T>
@@ -1076,17 +1039,23 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     constexpr int CPK = 4 * E::kPer16;
     KA_REQUIRE(a.B > 0 && a.Cin % CPK == 0 && a.Cout % 16 == 0,
                "conv3x3: need Cin %% %d == 0 and Cout %% 16 == 0 (got Cin=%d Cout=%d)", CPK, a.Cin, a.Cout);
+    bool want5 = false;
     if constexpr (sizeof(T) == 2) {
-        // the streaming form: tower shapes at training batch sizes (opt-in while it is being measured: KA_CONV_T=1)
-        const char* e = getenv("KA_CONV_T");
-        if (e && atoi(e) != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 && !a.in2) return launch_conv_stream(a, st);
         // the producer / consumer form.  KA_CONV_P: 0 off; 1 (default) the forward forms -- 8 % / 4 % faster alone, 1 % in
         // the step; 2: + the two-tensor data-gradient form with the plain epilogue (no faster alone, slower in the step: it
         // owns every register file, so the weight-gradient stream no longer runs beside it); 3: + the masked epilogue (spills)
         const char* ep = getenv("KA_CONV_P");
         const int pv = ep ? atoi(ep) : 1;
+        // training batches of the 256-channel tower: squares 0..79 as five row tiles here, square 80 of sixteen boards at a
+        // time in conv3x3_corner_kernel (KA_CONV_MT=6: all 81 squares as six row tiles, the round-1/2 form)
+        const char* em = getenv("KA_CONV_MT");
+        want5 = a.Cin == 256 && a.Cout == 256 && a.B >= 512 && !(em && atoi(em) == 6);
         if (pv != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 &&
-            (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) return launch_conv_pc(a, st);
+            (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) {
+            a.mt5 = want5;
+            if (int rc = launch_conv_pc(a, st)) return rc;
+            return want5 ? launch_conv_corner(a, st) : KA_OK;
+        }
     }
     // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
     int wm = 1;
@@ -1119,7 +1088,16 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     KA_REQUIRE(256 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
     if (wm == 1) {
-        if (ntw == 4) return launch_conv<T, 4, 1>(a, st);
+        if (ntw == 4) {
+            if constexpr (sizeof(T) == 2) {
+                if (want5) {
+                    a.mt5 = 1;
+                    if (int rc = launch_conv<T, 4, 1>(a, st)) return rc;
+                    return launch_conv_corner(a, st);
+                }
+            }
+            return launch_conv<T, 4, 1>(a, st);
+        }
         if (ntw == 2) return launch_conv<T, 2, 1>(a, st);
         return launch_conv<T, 1, 1>(a, st);
     }

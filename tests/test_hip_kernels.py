@@ -769,23 +769,51 @@ def test_grouped_fc_weight_gradients():
             assert torch.allclose(db.cpu(), dy.sum(0), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("transform", [False, True])
-def test_streaming_conv_is_bit_identical_to_the_default_kernel(monkeypatch, transform):
-    """The opt-in persistent form of the forward convolution (KA_CONV_T=1; the eval tower's MFMA loop with the next board
-    prefetched): same summation order and epilogue as conv3x3_kernel, so outputs and statistics agree bit for bit."""
-    dt, C, B = torch.bfloat16, 256, 771
-    g = torch.Generator().manual_seed(17)
-    x = torch.randn(B, C, 9, 9, generator=g)
-    w = torch.randn(C, C, 3, 3, generator=g) / 48
-    sc, sh = torch.rand(C, generator=g) + 0.5, 0.3 * torch.randn(C, generator=g)
-    gb = 0.5 * torch.randn(B, C, generator=g)
-    args = (sc.to(DEV), sh.to(DEV), gb.to(DEV), 1) if transform else ()
-    xin, wp = to_nhwc(x, dt), pack(w, dt, 0, C, C)
-    monkeypatch.setenv("KA_CONV_T", "0")
-    out0, bsum0, sq0 = run_conv(xin, wp, B, C, C, dt, *args)
-    monkeypatch.setenv("KA_CONV_T", "1")
-    out1, bsum1, sq1 = run_conv(xin, wp, B, C, C, dt, *args)
-    assert torch.equal(out0, out1) and torch.equal(bsum0, bsum1) and torch.equal(sq0, sq1)
+@pytest.mark.parametrize("B", [512, 515, 4096])
+def test_five_row_tiles_plus_corner_equal_six_row_tiles(monkeypatch, B):
+    """Training batches of the 256-channel tower compute squares 0..79 as five row tiles and square 80 of sixteen boards at a
+    time in conv3x3_corner_kernel (default); KA_CONV_MT=6 is the six-row-tile form.  Same products in the same order: every
+    output element bit for bit (all four launch kinds, both main kernels); the per-board sums add the corner's term last
+    instead of inside a lane's partial -- equal up to fp32 re-association."""
+    C = 256
+    g = torch.Generator(device=DEV).manual_seed(B + 1)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, x2, yprev = (rnd(B, 81, C).to(torch.bfloat16) for _ in range(3))
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, _lib.stream_ptr())
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    gb = rnd(B, C) * 0.1
+    k3 = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+
+    def run(kind):
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        out, dyo = nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16)
+        bsum, sq, e1, e2 = nan(B, C), nan(B, C), nan(B, C), nan(B, C)
+        st = _lib.stream_ptr()
+        if kind == 0: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st)
+        if kind == 1: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, gb, 1, bsum, sq, B, C, C, 1, st)
+        if kind == 2: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st)
+        if kind == 3: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st)
+        torch.cuda.synchronize()
+        return (out, dyo), (bsum, sq, e1, e2)
+
+    for pc in ("0", "3"):                                    # conv3x3_kernel / the producer-consumer kernel for every form
+        monkeypatch.setenv("KA_CONV_P", pc)
+        for kind in range(4):
+            monkeypatch.setenv("KA_CONV_MT", "6")
+            ref_o, ref_s = run(kind)
+            monkeypatch.delenv("KA_CONV_MT")
+            got_o, got_s = run(kind)
+            for a, b in zip(ref_o, got_o):
+                assert bool(((a == b) | (a.isnan() & b.isnan())).all()), (pc, kind)
+            assert not got_o[0].float().isnan().any()
+            for a, b in zip(ref_s, got_s):
+                if bool(a.isnan().all()):
+                    assert bool(b.isnan().all())
+                    continue
+                assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-6, (pc, kind)
 
 
 @pytest.mark.parametrize("B", [515, 1024, 4096])

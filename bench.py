@@ -583,9 +583,9 @@ def main() -> None:
                                     f"{kernel_source_id()}: not reported")
             ev_ms_step = 1e3 * res["events_elapsed"] / res["events_steps"]
             two_streams = os.environ.get("KA_WGRAD_OVERLAP", "0") != "0"
-            roof = {"bound": "mfma", "kernel": "conv3x3_pc_kernel / conv3x3_kernel (implicit-GEMM 3x3 conv; forward launches on the "
-                                               "producer-consumer form, data-gradient launches on conv3x3_kernel with fused "
-                                               "BatchNorm-backward passes" + (", concurrent with wgrad on a 2nd stream)" if two_streams else ")"),
+            roof = {"bound": "mfma", "kernel": "conv3x3_pc_kernel / conv3x3_kernel + conv3x3_corner_kernel (implicit-GEMM 3x3 conv: squares 0..79 as five row "
+                                               "tiles, square 80 of 16 boards as one more; forward launches on the producer-consumer form, "
+                                               "data-gradient launches on conv3x3_kernel with fused BatchNorm-backward passes" + (", concurrent with wgrad on a 2nd stream)" if two_streams else ")"),
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_note, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
                     "flop_per_launch": conv_flop,

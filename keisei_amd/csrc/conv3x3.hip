@@ -882,154 +882,153 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
 // 81 squares are five row tiles and one square.  As a sixth tile that square cost every (tap, k-step) of every wave two MFMAs
 // on 15 zero rows -- 16.7 % of the matrix work and of the activation-fragment reads for 1.2 % of the output (measured: the
 // tower kernels are 6-7 % faster without it, tools/_diag/job_r3_j.sh).  The tower kernels therefore compute squares 0..79
-// (MT = 5) and this kernel the corner: a workgroup takes SIXTEEN boards, whose corner squares are the 16 rows of ONE tile,
+// (MT = 5) and this kernel the corner: sixteen boards' corner squares are the 16 rows of ONE tile,
 // over K = 4 taps x 256 channels -- only the taps (-1,-1), (-1,0), (0,-1), (0,0) of square (8,8) lie on the board; the
 // other five multiplied zeros.  Same weight pack, same input transforms, same (chunk, tap, k-step) order: out[b, 80, :] is
 // bit-identical to the six-tile kernels'.  The per-board sums the tower kernel wrote (over 80 squares) receive the corner's
 // terms here (+=: one lane per (board, channel), stream-ordered behind the tower kernel; a fixed order of additions).
-constexpr int kCornerBoards = 16, kCornerStride = 4 * 512 + 16;      // 2064 B per board: 16 fragment lanes on 16 bank slots
+// The kernel is a chain of latencies (input squares from HBM, weight fragments from the L2, the sums it adds to), so each
+// is taken once: a 512-thread workgroup owns 32 boards (two row tiles) x 128 output channels -- 256 workgroups at B = 4096,
+// each pulling a 256 KB half of the four taps' weights out of the L2; every thread's eight input pieces are in flight together,
+// a wave's 64 weight fragments arrive 12 steps ahead, and the sums to be updated are requested before the MFMA loop.
+constexpr int kCornerBoards = 32, kCornerStride = 4 * 512 + 16;      // 2064 B per board: 16 fragment lanes on 16 bank slots
+constexpr int kCornerLds = kCornerBoards * kCornerStride;
 
-__global__ __launch_bounds__(256) void conv3x3_corner_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char cs[kCornerBoards * kCornerStride];
+__global__ __launch_bounds__(512) void conv3x3_corner_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char cs[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int b0 = blockIdx.x * kCornerBoards;
+    const int rt = wave & 1, nt0 = blockIdx.y * 8 + (wave >> 1) * 2;       // this wave: row tile rt, channel tiles nt0, nt0 + 1
+    const char* wl = static_cast<const char*>(a.wpack) + (size_t)nt0 * 1024 + lane * 16;
+    auto wfrag = [&](int step, int j) {                      // step = (chunk kc, tap slot ps, k-step k4): the tower kernels' order
+        const int kc = step >> 4, ps = (step >> 2) & 3, ks = kc * 4 + (step & 3), tap = ps < 2 ? ps : ps + 1;      // taps 0, 1, 3, 4
+        return *reinterpret_cast<const bf16x8*>(wl + (size_t)((tap * 8 + ks) * 16 + j) * 1024);
+    };
+    constexpr int kAhead = 12;                               // (16 ahead spilled at the 256 registers of two waves per SIMD)
+    bf16x8 wq[kAhead][2];
+#pragma unroll
+    for (int s2 = 0; s2 < kAhead; ++s2) { wq[s2][0] = wfrag(s2, 0); wq[s2][1] = wfrag(s2, 1); }
     // ---- stage [board][tap slot][256 channels]: squares 70, 71, 79, 80 = taps 0, 1, 3, 4 of square 80, transformed as the tower
     // kernels' staging transforms them (statement for statement)
     const bool has_aff = a.in_scale != nullptr;
-    const int pc = tid & 31, ch0 = pc * 8;                   // this thread's channel piece is the same for its 8 pieces
-    float sc[8], sh[8], k3[8];
+    const int pc = tid & 31, ch0 = pc * 8;                   // this thread's channel piece is the same for all its pieces
+    {
+        bf16x8 pv[8], pw[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; k3[e] = 0.f; }
-    if (has_aff) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0), s1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0 + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0), t1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = t0[e]; sh[4 + e] = t1[e]; }
-    }
-    if (a.in2) {
-        const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0), u1 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { k3[e] = u0[e]; k3[4 + e] = u1[e]; }
-    }
-    bf16x8 pv[8], pw[8];
-    f32x4 pb[8][2];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                            // every load of the 8 pieces in flight before the first is used
-        const int i = tid + 256 * k, bl = i >> 7, ps = (i >> 5) & 3, bb = min(b0 + bl, a.B - 1);
-        const int p = ps == 0 ? 70 : ps == 1 ? 71 : ps == 2 ? 79 : 80;
-        const size_t off = (((size_t)bb * KA_BOARD + p) * 256 + ch0) * 2;
-        pv[k] = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off);
-        pw[k] = a.in2 ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off) : bf16x8{};
-        pb[k][0] = pb[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.in_bias) {
-            pb[k][0] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0);
-            pb[k][1] = *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)bb * 256 + ch0 + 4);
+        for (int k = 0; k < 8; ++k) {                        // 32 boards x 4 squares x 32 pieces = 8 per thread, all in flight
+            const int i = tid + 512 * k, bl = i >> 7, ps = (i >> 5) & 3, bb = min(b0 + bl, a.B - 1);
+            const int p = ps == 0 ? 70 : ps == 1 ? 71 : ps == 2 ? 79 : 80;
+            const size_t off = (((size_t)bb * KA_BOARD + p) * 256 + ch0) * 2;
+            pv[k] = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off);
+            pw[k] = a.in2 ? *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off) : bf16x8{};
         }
-    }
+        float sc[8], sh[8], k3[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = tid + 256 * k, bl = i >> 7, ps = (i >> 5) & 3;
-        bf16x8 v = pv[k];
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; k3[e] = 0.f; }
+        if (has_aff) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0), s1 = *reinterpret_cast<const f32x4*>(a.in_scale + ch0 + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0), t1 = *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = t0[e]; sh[4 + e] = t1[e]; }
+        }
         if (a.in2) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0), u1 = *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[k][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
-        } else if (has_aff || a.relu || a.in_bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = (float)v[e];
-                if (has_aff) f = fmaf(f, sc[e], sh[e]);
-                if (a.relu) f = fmaxf(f, 0.f);
-                if (a.in_bias) f += pb[k][e >> 2][e & 3];
-                v[e] = (__bf16)f;
-            }
+            for (int e = 0; e < 4; ++e) { k3[e] = u0[e]; k3[4 + e] = u1[e]; }
         }
-        if (b0 + bl >= a.B) v = bf16x8{};
-        *reinterpret_cast<bf16x8*>(cs + bl * kCornerStride + ps * 512 + pc * 16) = v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = tid + 512 * k, bl = i >> 7, ps = (i >> 5) & 3;
+            bf16x8 v = pv[k];
+            if (a.in2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[k][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+            } else if (has_aff || a.relu || a.in_bias) {
+                f32x4 pb0 = {0.f, 0.f, 0.f, 0.f}, pb1 = pb0;
+                if (a.in_bias) {
+                    const size_t bo = (size_t)min(b0 + bl, a.B - 1) * 256 + ch0;
+                    pb0 = *reinterpret_cast<const f32x4*>(a.in_bias + bo); pb1 = *reinterpret_cast<const f32x4*>(a.in_bias + bo + 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[e];
+                    if (has_aff) f = fmaf(f, sc[e], sh[e]);
+                    if (a.relu) f = fmaxf(f, 0.f);
+                    if (a.in_bias) f += e < 4 ? pb0[e & 3] : pb1[e & 3];
+                    v[e] = (__bf16)f;
+                }
+            }
+            if (b0 + bl >= a.B) v = bf16x8{};
+            *reinterpret_cast<bf16x8*>(cs + bl * kCornerStride + ps * 512 + pc * 16) = v;
+        }
     }
     __syncthreads();
-    // ---- wave w: output-channel tiles 4w .. 4w+3 (64 channels), rows = the 16 boards
-    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 4) * 1024 + lane * 16;
-    f32x4 acc[4];
+    // ---- what the epilogue adds to / compares with is requested now and arrives under the MFMA loop
+    const int bb = b0 + 16 * rt + r;                         // lane (r, q): this board, channels cb[j] .. cb[j]+3 of tile j
+    const bool live = bb < a.B;
+    const int bbc = min(bb, a.B - 1);
+    int cb[2];
+    f32x4 pbs[2], psq[2], ps1[2], ps2[2], esc[2], esh[2], emu[2], eis[2];
+    bf16x4 yv[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int tap = ps < 2 ? ps : ps + 1;            // 0, 1, 3, 4
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int ks = kc * 4 + k4;
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cs + r * kCornerStride + ps * 512 + ks * 64 + q * 16);
-                const char* wp = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wp + j * 1024), af, acc[j], 0, 0, 0);
-            }
+    for (int j = 0; j < 2; ++j) {
+        cb[j] = chan_of(nt0 + j, 4 * q, 16);
+        const size_t srow = (size_t)bbc * 256 + cb[j];
+        pbs[j] = psq[j] = ps1[j] = ps2[j] = esc[j] = esh[j] = emu[j] = eis[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        yv[j] = bf16x4{};
+        if (a.bsum) pbs[j] = *reinterpret_cast<const f32x4*>(a.bsum + srow);
+        if (a.sqpart) psq[j] = *reinterpret_cast<const f32x4*>(a.sqpart + srow);
+        if (a.ep_y) {
+            ps1[j] = *reinterpret_cast<const f32x4*>(a.ep_s1 + srow); ps2[j] = *reinterpret_cast<const f32x4*>(a.ep_s2 + srow);
+            esc[j] = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]); esh[j] = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
+            emu[j] = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]); eis[j] = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
+            yv[j] = *reinterpret_cast<const bf16x4*>(static_cast<const char*>(a.ep_y) + (((size_t)bbc * KA_BOARD + 80) * 256 + cb[j]) * 2);
         }
-    // ---- epilogue: lane (r, q) = board b0 + r, channels cb .. cb+7 of each tile pair
-    const int bb = b0 + r;
-    if (bb >= a.B) return;
+    }
+    // ---- 32 k-steps: one activation fragment (this wave's 16 boards), two weight fragments 12 steps ahead, two MFMAs
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const char* arow = cs + (16 * rt + r) * kCornerStride + q * 16;
 #pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-        const int cb = chan_of(wave * 4 + j, 4 * q, 16);
-        float v[8];
+    for (int step = 0; step < 32; ++step) {
+        const bf16x8 w0 = wq[step % kAhead][0], w1 = wq[step % kAhead][1];
+        if (step + kAhead < 32) { wq[step % kAhead][0] = wfrag(step + kAhead, 0); wq[step % kAhead][1] = wfrag(step + kAhead, 1); }
+        const int ps = (step >> 2) & 3, ks = (step >> 4) * 4 + (step & 3);
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + ps * 512 + ks * 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af, acc[1], 0, 0, 0);
+    }
+    if (!live) return;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = acc[j][i]; v[4 + i] = acc[j + 1][i]; }
-        const size_t orow = ((size_t)bb * KA_BOARD + 80) * 256 + cb, srow = (size_t)bb * 256 + cb;
-        if (a.bsum) {
-#pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(a.bsum + srow + e);
-                t += f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
-                *reinterpret_cast<f32x4*>(a.bsum + srow + e) = t;
-            }
-        }
-        if (a.sqpart) {
-#pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(a.sqpart + srow + e);
-                t += f32x4{v[e] * v[e], v[e + 1] * v[e + 1], v[e + 2] * v[e + 2], v[e + 3] * v[e + 3]};
-                *reinterpret_cast<f32x4*>(a.sqpart + srow + e) = t;
-            }
-        }
-        bf16x8 o;
+    for (int j = 0; j < 2; ++j) {
+        const f32x4 v = acc[j];
+        const size_t orow = ((size_t)bb * KA_BOARD + 80) * 256 + cb[j], srow = (size_t)bb * 256 + cb[j];
+        if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + srow) = pbs[j] + v;
+        if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + srow) = psq[j] + f32x4{v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]};
+        bf16x4 o;
         if (!a.ep_y) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
         } else {
             // da = dh * [bn(y) > 0] and its BatchNorm-backward terms (conv_epilogue's masked branch, term for term)
-            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.ep_y) + orow * 2);
-            float esc[8], esh[8], emu[8], eis[8], t1[8], t2[8];
+            f32x4 t1, t2;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.ep_scale + cb + 4 * h), c1 = *reinterpret_cast<const f32x4*>(a.ep_shift + cb + 4 * h);
-                const f32x4 c2 = *reinterpret_cast<const f32x4*>(a.ep_mean + cb + 4 * h), c3 = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { esc[4 * h + e] = c0[e]; esh[4 * h + e] = c1[e]; emu[4 * h + e] = c2[e]; eis[4 * h + e] = c3[e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float y = (float)yv[e];
+            for (int e = 0; e < 4; ++e) {
+                const float y = (float)yv[j][e];
                 const __bf16 db = (__bf16)v[e];
-                const float d = (y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
-                t1[e] = d; t2[e] = d * ((y - emu[e]) * eis[e]);
+                const float d = (y * esc[j][e] + esh[j][e] > 0.f) ? (float)db : 0.f;
+                t1[e] = d; t2[e] = d * ((y - emu[j][e]) * eis[j][e]);
                 o[e] = (__bf16)d;
             }
-#pragma unroll
-            for (int e = 0; e < 8; e += 4) {
-                f32x4 s1 = *reinterpret_cast<const f32x4*>(a.ep_s1 + srow + e), s2 = *reinterpret_cast<const f32x4*>(a.ep_s2 + srow + e);
-                s1 += f32x4{t1[e], t1[e + 1], t1[e + 2], t1[e + 3]};
-                s2 += f32x4{t2[e], t2[e + 1], t2[e + 2], t2[e + 3]};
-                *reinterpret_cast<f32x4*>(a.ep_s1 + srow + e) = s1;
-                *reinterpret_cast<f32x4*>(a.ep_s2 + srow + e) = s2;
-            }
+            *reinterpret_cast<f32x4*>(a.ep_s1 + srow) = ps1[j] + t1;
+            *reinterpret_cast<f32x4*>(a.ep_s2 + srow) = ps2[j] + t2;
         }
-        *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + orow * 2) = o;
+        *reinterpret_cast<bf16x4*>(static_cast<char*>(a.out) + orow * 2) = o;
     }
 }
 static int launch_conv_corner(const ConvArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(conv3x3_corner_kernel, dim3((a.B + kCornerBoards - 1) / kCornerBoards), dim3(256), 0, st, a);
+    static std::atomic<unsigned long long> done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_corner_kernel), done, "conv3x3 (corner)")) return rc;
+    hipLaunchKernelGGL(conv3x3_corner_kernel, dim3((a.B + kCornerBoards - 1) / kCornerBoards, 2), dim3(512), kCornerLds, st, a);
     return ka_check_launch("conv3x3 (corner)");
 }
 

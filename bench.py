@@ -577,6 +577,9 @@ def main() -> None:
                     recs += [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_pc_kernel")]
                     n = sum(v["launches"] for v in recs)
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in recs) / n) if n else None
+                    corner = prof["kernels"].get("conv3x3_corner_kernel")      # (square 80: one launch behind every tower launch)
+                    if traffic is not None and corner:
+                        traffic += corner["hbm_bytes_per_launch"]
                     traffic_note = f"{pmc.name} (same kernel sources)"
                 else:
                     traffic_note = (f"{pmc.name} was collected on kernel sources {prof.get('kernel_source_sha16')}, this build is "

@@ -46,12 +46,12 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_source_id() -> str:
+def kernel_source_id(names=("common.h", "conv3x3.hip")) -> str:
     """sha256[:16] over the HIP sources the roofline kernel (conv3x3_kernel) is built from: ties a counter profile under
     profiles/ to the build of that kernel."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("common.h", "conv3x3.hip"):
+    for name in names:
         f = ROOT / "keisei_amd" / "csrc" / name
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
@@ -315,6 +315,16 @@ def run_transformer(args, device):
     lin = 2.0 * M * (64 * d + L * (3 * d * d + d * d + 8 * d * d)) + 2.0 * B * 81 * d * 11259
     attn = L * 4.0 * B * H * 81 * 81 * (d // H)
     flop_step = 3.0 * (lin + attn)
+    # the step's HBM bytes from the committed rocprofv3 PMC passes of this same command (tools/profile_round.sh), only when that
+    # profile was taken on this build of transformer.hip
+    hbm_step = None
+    tfp = sorted((ROOT / "profiles").glob("r*_transformer_hbm_traffic.json"))
+    if tfp and B == 4096 and args.dtype == "bf16":
+        prof = json.loads(tfp[-1].read_text())
+        if prof.get("transformer_source_sha16") == kernel_source_id(("common.h", "transformer.hip")) and prof.get("step_summary"):
+            byt = prof["step_summary"]["hbm_bytes_per_step"]
+            tbps = byt / (elapsed / args.steps) / 1e12
+            hbm_step = {"bytes_per_step": byt, "achieved_TBps": round(tbps, 3), "frac_of_8TBps": round(tbps / 8.0, 4), "source": tfp[-1].name}
     out = {"metric": "PPO samples/sec, transformer d256 h8 L6 on 50x9x9", "value": round(B * args.steps / elapsed, 1), "unit": "samples/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -325,7 +335,7 @@ def run_transformer(args, device):
                         "achieved": round(flop_step / (elapsed / args.steps) / 1e12, 1),
                         "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop_step / (elapsed / args.steps) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
-                        "traffic": None, "flop_per_step": flop_step},
+                        "traffic": None, "flop_per_step": flop_step, "hbm_step": hbm_step},
            "guard_flags": flags, "cpu_baseline": None}
     print(json.dumps(out), flush=True)
 

@@ -24,6 +24,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate p
 sys.path.insert(0, ".")
 import bench  # noqa: E402
 out["kernel_source_sha16"] = bench.kernel_source_id()
+out["transformer_source_sha16"] = bench.kernel_source_id(("common.h", "transformer.hip"))
 for k in sorted(set(fetch) | set(write)):
     f = 2.0 * 1024.0 * sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
     w = 1024.0 * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))

@@ -271,22 +271,29 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(NtArgs g) {
     }
 }
 
-// ------------------------------------------------------------------ NT GEMM, 256 x 256 x 64 tiles: the policy layer
+// ------------------------------------------------------------------ NT GEMM, 256 x 256 tiles: the policy layer
 // M, N and K all large (policy_fc: 4096 x 11 259 x 20 736 forward, and its two gradients): with 128 x 128 tiles every
 // workgroup pulls 256 operand rows per 64 k through the L2 for 32 MFMAs per wave -- 10.7 TB/s of L2 -> CU traffic at
 // 0.7 PFLOP/s, matrix pipe 30-34 % busy.  Here a 512-thread workgroup owns a 256 x 256 tile: 8 waves as 2 (m) x 4 (n), wave
 // tile 128 x 64 = 32 accumulator tiles (128 registers), 12 fragment reads per 32 MFMAs instead of 16, half the operand
-// bytes per FLOP through L2 and LDS, and a k-tile's MFMA phase twice as long for the same prefetch.  One workgroup per CU
-// (2 x 73.7 KB of LDS), register-staged double buffering as in gemm_nt_bf16_kernel; an XCD walks 4 (m) x 8 (n) super-tiles
-// (its 32 resident workgroups share 4 A and 8 B panels).  Bias-only epilogue, fp32 or bf16 output, ragged M / N edges;
-// K a multiple of 64.  Same products in the same k order as the 128 x 128 kernel: results are bit-identical.
+// bytes per FLOP through L2 and LDS.  One workgroup per CU; an XCD walks 4 (m) x 8 (n) super-tiles (its 32 resident
+// workgroups share 4 A and 8 B panels).  Operands reach the LDS by DMA, three 32-deep k-tiles ahead (below): matrix pipe
+// 45-47 % busy (37 % with one register-staged 64-deep tile in flight and a drain at every barrier).  Bias-only epilogue, fp32
+// or bf16 output, ragged M / N edges; K a multiple of 32.  Same products in the same k order as the 128 x 128 kernel:
+// results are bit-identical.
 constexpr int kGM = 256, kGN = 256;
-constexpr int kGLds = 2 * (kGM + kGN) * kLdsStride;
+constexpr int kGLds = 4 * (kGM + kGN) * 32 * 2;         // four stages of two unpadded [256][32] bf16 tiles: 128 KB
 
 __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(NtArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char big_smem[];
-    auto As = [&](int buf) { return big_smem + buf * ((kGM + kGN) * kLdsStride); };
-    auto Bs = [&](int buf) { return big_smem + buf * ((kGM + kGN) * kLdsStride) + kGM * kLdsStride; };
+    extern __shared__ __attribute__((aligned(1024))) char big_smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // Four LDS stages of one 32-deep k-tile each ([256 + 256 rows][32 k] bf16 = 32 KB, unpadded 64-byte rows), filled by LDS-DMA
+    // (global_load_lds_dwordx4: a wave instruction writes 64 lanes x 16 B = sixteen whole rows) three tiles ahead of the MFMAs,
+    // the fragments of the NEXT tile read under the MFMAs of this one, a counted vmcnt before each barrier (never 0 in the loop)
+    // and a raw s_barrier (a __syncthreads() would drain the DMA).
+    // Bank conflicts are avoided on the SOURCE side: LDS slot s (16 B) of row R holds global piece s ^ (((R >> 2) & 1) << 1), which
+    // puts the 16 lanes of every ds_read_b128 group on 16 different 16-byte bank slots.
+    constexpr int BK = 32, kRow = BK * 2, kTile = kGM * kRow, kStage = 2 * kTile, NST = 4;      // 64 B, 16 KB, 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;
     int bx, by;
@@ -299,31 +306,24 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(NtArgs g) {
         if (by >= g.map_gy || bx >= g.map_gx) return;        // padding of the last super-tiles (uniform exit, no barrier yet)
     }
     const int m0 = by * kGM, n0 = bx * kGN;
-    // staging role: 256 rows x 8 pieces (16 B) per operand tile = 2048 pieces, four per thread and operand
-    const int srow = tid >> 3, spc = tid & 7;
-    bf16x8 ra[4], rb[4];
-    // (32-bit byte offsets from the uniform operand bases, recomputed per k-tile from an opaque copy of the row index: kept
-    //  across the loop as eight 64-bit row pointers they cost 16 registers this kernel lacks; rows past the edge read the
-    //  operand's last row -- their products land in accumulators that are never stored)
-    auto load = [&](int k0) {
-        int sr = srow;
-        asm volatile("" : "+v"(sr));
+    // staging role: an operand tile is 16 pieces of 1 KB (16 rows); wave w issues pieces w and w + 8 of each operand.  Lane l of
+    // piece p: row 16 p + (l >> 2), LDS slot l & 3 <- global piece (l & 3) ^ (((row >> 2) & 1) << 1).  Rows past the edge read the
+    // operand's last row (their products land in accumulators that are never stored).
+    uint32_t ao[2], bo[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 16 * (wave + 8 * h) + (lane >> 2), pcs = (lane & 3) ^ (((row >> 2) & 1) << 1);
+        ao[h] = (uint32_t)(min(m0 + row, g.M - 1) * g.lda + pcs * 8) * 2u;
+        bo[h] = (uint32_t)(min(n0 + row, g.N - 1) * g.ldb + pcs * 8) * 2u;
+    }
+    auto dma = [&](int k0, int st) {
         const char* ak = reinterpret_cast<const char*>(g.A) + (size_t)k0 * 2;       // uniform
         const char* bk = reinterpret_cast<const char*>(g.B) + (size_t)k0 * 2;
+        char* base = big_smem + st * kStage;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const uint32_t ao = (uint32_t)(min(m0 + sr + 64 * h, g.M - 1) * g.lda + spc * 8) * 2u;
-            const uint32_t bo = (uint32_t)(min(n0 + sr + 64 * h, g.N - 1) * g.ldb + spc * 8) * 2u;
-            ra[h] = *reinterpret_cast<const bf16x8*>(ak + ao);
-            rb[h] = *reinterpret_cast<const bf16x8*>(bk + bo);
-        }
-    };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int row = srow + 64 * h;
-            *reinterpret_cast<bf16x8*>(As(buf) + row * kLdsStride + spc * 16) = ra[h];
-            *reinterpret_cast<bf16x8*>(Bs(buf) + row * kLdsStride + spc * 16) = rb[h];
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_global_load_lds(ak + ao[h], (lds_ptr)(base + (wave + 8 * h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(bk + bo[h], (lds_ptr)(base + kTile + (wave + 8 * h) * 1024), 16, 0, 0);
         }
     };
     f32x4 acc[8][4];
@@ -331,48 +331,60 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(NtArgs g) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto step = [&](int k0, int buf) {
-        const bool more = k0 + kBK < g.K;
-        if (more) load(k0 + kBK);
+    // fragment address of lane (r, q): row r (+ 16 i), piece q -> slot q ^ (((r >> 2) & 1) << 1)   (16 | row offsets: same swizzle)
+    const int foff = r * kRow + ((q ^ (((r >> 2) & 1) << 1)) << 4);
+    const int nk = g.K / BK;
+    struct Frags { bf16x8 a[8], b[4]; };
+    auto rd = [&](int st, Frags& f) {
+        const char* ab = big_smem + st * kStage + (wm * 128) * kRow + foff;
+        const char* bb = big_smem + st * kStage + kTile + (wn * 64) * kRow + foff;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // the four B fragments of the k-step, then the A fragments one row tile ahead of their four MFMAs (issue order
-            // pinned): 24 fragment registers instead of 48 -- with both k-steps' fragments hoisted the kernel spilled
-            const char* ab = As(buf) + (wm * 128 + r) * kLdsStride + kk * 64 + q * 16;
-            bf16x8 bfr[4];
+        for (int j = 0; j < 4; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(bb + j * 16 * kRow);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs(buf) + (wn * 64 + j * 16 + r) * kLdsStride + kk * 64 + q * 16);
-            bf16x8 a_cur = *reinterpret_cast<const bf16x8*>(ab);
-            // C^T tiles, as gemm_nt_bf16_kernel: a lane holds 4 consecutive columns n of one row m
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bf16x8 a_nxt = a_cur;
-                if (i < 7) a_nxt = *reinterpret_cast<const bf16x8*>(ab + (i + 1) * 16 * kLdsStride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], a_cur, acc[i][j], 0, 0, 0);
-                a_cur = a_nxt;
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        if (more) store(buf ^ 1);
-        __syncthreads();
+        for (int i = 0; i < 8; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(ab + i * 16 * kRow);
     };
-    load(0);
-    store(0);
-    __syncthreads();
-    int k0 = 0;
-    for (; k0 + kBK < g.K; k0 += 2 * kBK) {
-        step(k0, 0);
-        step(k0 + kBK, 1);
+    // Invariant at the top of iteration t: tiles <= t+1 have landed and are visible to every wave, tile t's fragments are in
+    // `cur`.  The iteration requests tile t+3, reads tile t+1's fragments under tile t's 32 MFMAs, then waits until at most the
+    // newest tile's DMA (4 per lane) is outstanding -- tile t+2 has landed -- and passes the barrier that publishes it.  A stage is
+    // written again (tile t+4 in iteration t+1) two barriers after its last read (iteration t-1).
+    auto step = [&](int t, const Frags& cur, Frags& nxt) {
+        if (t + 3 < nk) dma((t + 3) * BK, (t + 3) & (NST - 1));
+        if (t + 1 < nk) rd((t + 1) & (NST - 1), nxt);
+        // C^T tiles, as gemm_nt_bf16_kernel: a lane holds 4 consecutive columns n of one row m
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        // issue order: the 12 fragment reads of the next tile spread over this tile's MFMAs (one read, then three MFMAs; the rest)
+#pragma unroll
+        for (int z = 0; z < 10; ++z) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                       // (nothing of the next iteration is moved in front of the barrier)
+    };
+    // prologue: tiles 0, 1, 2 on their way; 0 and 1 landed and published, tile 0's fragments read
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nk) dma(t * BK, t);
+    if (nk >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags fa, fb;
+    rd(0, fa);
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        step(t, fa, fb);
+        step(t + 1, fb, fa);
     }
-    if (k0 < g.K) step(k0, 0);
+    if (t < nk) step(t, fa, fb);
     // epilogue: lane (r, q) of tile (i, j): row m = i*16 + r, columns n = j*16 + 4q .. +3
     const bool vec4 = (g.N & 3) == 0 && (g.ldc & 3) == 0;
 #pragma unroll

@@ -96,10 +96,10 @@ def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
     assert float((new[2].float().cpu() - want).abs().max()) <= 0.02 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("M,N,K", [(1100, 1300, 1024), (1024, 1027, 1088), (1281, 2048, 1024)])
+@pytest.mark.parametrize("M,N,K", [(1100, 1300, 1024), (1024, 1027, 1088), (1281, 2048, 1024), (2048, 1536, 4096)])
 def test_gemm_nt_big_tile_form_equals_the_tiled_kernel(monkeypatch, M, N, K):
     """M, N, K >= 1024 with a bias-only epilogue (the policy layer's three products) take gemm_nt_big_kernel (256 x 256 tiles, an XCD
-    walking 4 x 8 super-tiles); KA_TF_BIG=0 sends the call to gemm_nt_bf16_kernel, whose grid for these shapes is the 8 x 8
+    walking 4 x 8 super-tiles, operands by LDS-DMA three k-tiles ahead under counted waits); KA_TF_BIG=0 sends the call to gemm_nt_bf16_kernel, whose grid for these shapes is the 8 x 8
     super-tile map, and KA_TF_MAP2D=0 to its one-m-tile-per-XCD map.  Same products in the same k order: bit for bit, fp32
     and bf16 outputs, ragged M and N (N not a multiple of 4: the scalar store path), and against fp32 math."""
     g = torch.Generator().manual_seed(M + N + K)

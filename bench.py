@@ -86,7 +86,7 @@ def synth_dataset(total, seed, device):
     }
 
 
-def whole_update_rate(algo, adapter, T, N, device):
+def whole_update_rate(algo, adapter, T, N, device, stores=("host", "device")):
     """SURVEY 8(d) secondary metric and the 8(f1) row: T add() calls of N transitions with the step tensors on the
     device (as katago_loop.py:1523 passes them), then one update() through the public API -- batched GAE, advantage
     normalisation, the epochs_per_batch x ceil(TN/B) minibatch steps, the metric read-back.  Measured for both
@@ -96,7 +96,7 @@ def whole_update_rate(algo, adapter, T, N, device):
     A = 11259
     out = {"transitions": T * N, "epochs_per_batch": algo.params.epochs_per_batch,
            "includes": "GAE, advantage normalisation, epoch dataset hand-over, minibatch gathers, metric read-back"}
-    for store in ("host", "device"):
+    for store in stores:
         g = torch.Generator().manual_seed(99)
         os.environ["KA_ROLLOUT_BUFFER"] = store
         buf = KataGoRolloutBuffer(N, (50, 9, 9), A)
@@ -337,7 +337,7 @@ def run_transformer(args, device):
                         "frac": round(flop_step / (elapsed / args.steps) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
                         "traffic": None, "flop_per_step": flop_step, "hbm_step": hbm_step},
            "guard_flags": flags, "cpu_baseline": None}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def run_workload(args, dtype, steps, warmup, device, rank, world, dev_index, events_steps):
@@ -434,6 +434,8 @@ def main() -> None:
     ap.add_argument("--sl-epoch", action="store_true", help="also time one SLTrainer.train_epoch() over synthetic shards")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32-mode (parity numerics) run of the same workload")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block of the default line (whole update(), the 6x128 workload, the transformer workload)")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="initialise the process group (RCCL when the backend is nccl) even for one rank, wrap the model as the "
                          "N > 1 bench does, run ONE step with its collectives, print the collective counts and exit")
@@ -463,7 +465,7 @@ def main() -> None:
     if args.workload == "transformer":
         if world > 1:
             raise SystemExit("the transformer workload is a single-GPU bench line (BASELINE configs[4])")
-        run_transformer(args, device)
+        print(json.dumps(run_transformer(args, device)), flush=True)
         return
     if args.dist_dry_run:
         counts = {"syncbn": 0, "gradient": 0, "other": 0}
@@ -527,6 +529,9 @@ def main() -> None:
     whole = None
     if args.whole_update and rank == 0:
         whole = whole_update_rate(res["algo"], res["adapter"], T, N, device)
+    want_secondary = world == 1 and rank == 0 and args.workload == "40x256" and args.dtype == "bf16" and not args.no_secondary
+    if want_secondary and whole is None:
+        whole = whole_update_rate(res["algo"], res["adapter"], T, N, device, stores=("device",))
     sl = None
     if args.sl_epoch and rank == 0:
         from keisei_amd.training.model_registry import build_model
@@ -548,6 +553,46 @@ def main() -> None:
             fp32["conv3x3_avg_launch_ms"] = round(avg, 3)
             fp32["conv_frac_of_157TF"] = round(conv_flop / (avg * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)
         del r32
+
+    # SURVEY 8d "report both" + BASELINE configs[1] / configs[4], where the driver's default run sees them: a bounded leg each
+    # (<= 3 timed steps), after the timed region, one GPU, rank 0 -- the full-length versions are the --whole-update /
+    # --workload 6x128 / --workload transformer lines
+    secondary = None
+    if want_secondary:
+        secondary = {}
+        if whole is not None:
+            secondary["whole_update"] = {"samples_per_s": whole["samples_per_s"], "update_seconds": whole["device"]["update_seconds"],
+                                         "transitions": whole["transitions"], "epochs_per_batch": whole["epochs_per_batch"],
+                                         "store": "device", "includes": whole["includes"]}
+        for k in ("algo", "fs", "model", "adapter"):
+            res.pop(k, None)
+        torch.cuda.empty_cache()
+        sub = argparse.Namespace(**vars(args))
+        sub.workload, sub.batch = "6x128", 0
+        r6 = run_workload(sub, "bf16", 3, 2, device, rank, world, dev_index, 1)
+        B6 = r6["B"]
+        line6 = {"samples_per_s": round(B6 * 3 / r6["elapsed"], 1), "ms_per_step": round(1e3 * r6["elapsed"] / 3, 3), "steps": 3, "warmup": 2,
+                 "workload": f"se_resnet 6x128 KataGo-PPO minibatch step, minibatch {B6} (BASELINE configs[1])", "dtype": "bf16"}
+        if r6["events"] and r6["events"]["conv3x3"]:
+            ms6 = [a.elapsed_time(b) for a, b in r6["events"]["conv3x3"]]
+            f6 = 2.0 * B6 * 81 * 9 * 128 * 128
+            line6["roofline"] = {"bound": "mfma", "kernel": "tower conv3x3 launches (forward + data gradient)", "avg_launch_ms": round(sum(ms6) / len(ms6), 4),
+                                 "achieved": round(f6 / (sum(ms6) / len(ms6) * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(f6 / (sum(ms6) / len(ms6) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        sh6 = r6["shape"]
+        fl6 = train_flops_per_sample(sh6[0], sh6[1], sh6[3], sh6[1] // sh6[2], sh6[4], sh6[5], sh6[6])
+        line6["model_tflops_frac"] = round(line6["samples_per_s"] * fl6 / 1e12 / PEAK_BF16_TFLOPS, 4)
+        secondary["workload_6x128"] = line6
+        r6["algo"]._fused_end(r6["fs"])
+        del r6
+        torch.cuda.empty_cache()
+        sub = argparse.Namespace(**vars(args))
+        sub.steps, sub.warmup, sub.batch = 3, 2, 0
+        tl = run_transformer(sub, device)
+        secondary["transformer"] = {"samples_per_s": tl["value"], "ms_per_step": tl["ms_per_step"], "steps": 3, "warmup": 2,
+                                    "workload": tl["config"]["workload"], "dtype": tl["dtype"],
+                                    "roofline": {k: tl["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+        torch.cuda.empty_cache()
 
     n_ranks_seen = 1
     if world > 1:
@@ -643,8 +688,10 @@ def main() -> None:
         out.update(extra)
         if fp32 is not None:
             out["fp32_mode"] = fp32
-        if whole is not None:
+        if whole is not None and args.whole_update:
             out["whole_update"] = whole
+        if secondary is not None:
+            out["secondary"] = secondary
         if sl is not None:
             out["sl_epoch"] = sl
         # (N > 1: taken after the timed region and after the process group is gone -- the other ranks have exited)

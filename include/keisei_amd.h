@@ -321,8 +321,10 @@ int ka_tower_eval(const void* x_in, const float* pool_in, void* x_out, float* po
  * ka_shogi_env_reset: VecEnv::reset (vec_env.rs:617-645) -- or, with refresh != 0, derive key / check / masks from the
  *   board, hands and side the caller has written into `state` (test fixtures; ply and history start at 0).
  * ka_shogi_env_step: VecEnv::step (vec_env.rs:651-700, apply_moves :340-460).  Phase 1 checks every action against
- *   prev_mask / prev_mask_bits (the masks of the previous call); *err = n - i for the first refused env i, and then NO
- *   game moves (the reference raises before mutating).  Phase 2: make_move, check_termination (game.rs:355-387: move
+ *   prev_mask / prev_mask_bits (the masks of the previous call); `err` points at FOUR ints = two 64-bit words, 8-byte aligned:
+ *   word 0 (cleared by every call) = ((n - i) << 32) | (uint32) action for the first refused env i, and then NO game moves (the
+ *   reference raises before mutating); word 1 latches the first non-zero word 0 and is never cleared by the library: the
+ *   caller zeroes it when it has reported the refusal, so a flag read late survives any number of further steps.  Phase 2: make_move, check_termination (game.rs:355-387: move
  *   limit, fourfold repetition / perpetual check, 24-point impasse, no legal move), rewards for the mover
  *   (vec_env.rs:98-124), captured hand-type (255 none), TerminationReason, ply, material balance, episode counters
  *   stats[4] u64 {completed, drawn, truncated, total ply}; finished games write terminal_obs (other rows are left as they

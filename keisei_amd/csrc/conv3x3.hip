@@ -609,8 +609,13 @@ constexpr int kPcLds = kPcZero + kZeroSquares * kStImgStride;
 constexpr int kPcYStride = 256 * 2 + 16;                                  // the masked epilogue's y rows in LDS (16 B of padding: 2-way conflicts at most)
 constexpr int kPcLdsMasked = kPcLds + KA_BOARD * kPcYStride;
 
-template <bool TWO, bool MASKED, int NPW = 4, int MT = 6>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue; NPW staging waves; MT row tiles
+// STAG: MFMA waves 4-7 (the SIMD partners of waves 0-3) run half a unit behind waves 0-3, two barriers per unit: the epilogue and
+// the unit-start latencies of one wave then sit beside the matrix work of its partner instead of beside the partner's own
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  An image is read for three half-unit slots, so the staging waves load
+// the next unit's pieces in one slot and write them to LDS in the following one, the only slot in which that image is free.
+template <bool TWO, bool MASKED, int NPW = 4, int MT = 6, bool STAG = false>     // TWO: the two-tensor data-gradient input; MASKED: its ReLU + BatchNorm-backward epilogue; NPW staging waves; MT row tiles
 __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) {
+    static_assert(!(STAG && MASKED), "the staggered schedule is built for the register-only epilogue");
     constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
     constexpr int KP = (KA_BOARD * 16 + NP - 1) / NP, KY = (KA_BOARD * 32 + NP - 1) / NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -626,6 +631,55 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
         // ---------------- staging waves: piece i = pt + NP k of a unit = row i / 16, 16-byte piece i % 16 = pt % 16
         const int pt = tid - 512, pc = pt & 15;
         const bool has_aff = a.in_scale != nullptr;
+        // (the pieces of a unit live in registers across a barrier only in the staggered schedule: `stage` keeps its own,
+        //  local to one call -- as outer arrays they are kept in scratch across the unit loop's back-edge)
+        auto stage_load = [&](int u, bf16x8 (&pv)[KP], bf16x8 (&pw)[TWO ? KP : 1]) {
+            const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1, ch0 = kc * 128 + pc * 8;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k;
+                pv[k] = bf16x8{};
+                if (TWO) pw[TWO ? k : 0] = bf16x8{};
+                if (i < KA_BOARD * 16) {
+                    const size_t off = (((size_t)bb * KA_BOARD + (i >> 4)) * 256 + ch0) * 2;
+                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
+                    if (TWO) pw[TWO ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
+                }
+            }
+        };
+        auto stage_write = [&](int u, bf16x8 (&pv)[KP], bf16x8 (&pw)[TWO ? KP : 1]) {
+            const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1, ch0 = kc * 128 + pc * 8;
+            char* img = smem + (u & 1) * kPcImg;
+            float sc[8], sh[8], k3[8], pb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
+                k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
+                pb[e] = (!TWO && a.in_bias) ? a.in_bias[(size_t)bb * 256 + ch0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k;
+                if (i >= KA_BOARD * 16) continue;
+                bf16x8 v = pv[k];
+                if (TWO) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                    if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + (((size_t)bb * KA_BOARD + (i >> 4)) * 256 + ch0) * 2) = v;
+                } else if (has_aff || a.relu || a.in_bias) {
+                    // two channels per instruction (v_pk_fma_f32 / v_pk_add_f32): this arithmetic shares the SIMDs with the MFMA waves
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 f = {(float)v[e], (float)v[e + 1]};
+                        if (has_aff) f = __builtin_elementwise_fma(f, f32x2{sc[e], sc[e + 1]}, f32x2{sh[e], sh[e + 1]});
+                        if (a.relu) f = __builtin_elementwise_max(f, f32x2{0.f, 0.f});
+                        if (a.in_bias) f += f32x2{pb[e], pb[e + 1]};
+                        v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(img + lds_square(0, i >> 4) * kStImgStride + pc * 16) = v;
+            }
+        };
         auto stage = [&](int u) {
             const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1, ch0 = kc * 128 + pc * 8;
             char* img = smem + (u & 1) * kPcImg;
@@ -690,6 +744,19 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
         };
         stage(0);
         KA_LDS_BARRIER();
+        if constexpr (STAG) {
+            // slot 2v-2: the loads of unit v; slot 2v-1: its LDS writes (waves 4-7 read the image's previous unit until then)
+            for (int v = 1; v < nunits; ++v) {
+                bf16x8 pv[KP], pw[TWO ? KP : 1];
+                stage_load(v, pv, pw);
+                KA_LDS_BARRIER();
+                stage_write(v, pv, pw);
+                KA_LDS_BARRIER();
+            }
+            KA_LDS_BARRIER();
+            KA_LDS_BARRIER();
+            return;
+        }
         for (int u = 0; u < nunits; ++u) {
             if (u + 1 < nunits && !(a.tune_stagger & 2)) stage(u + 1);
             if (MASKED && (u & 1)) load_y((int)blockIdx.x + (u >> 1) * nwg);
@@ -721,6 +788,8 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
     wfrag(0, 0, w0); wfrag(0, 1, w1); wfrag(0, 2, w2);
     f32x4 acc[MT][2];
     KA_LDS_BARRIER();                                        // unit 0 is staged
+    const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (late) KA_LDS_BARRIER();                              // waves 4-7 start one slot (half a unit) behind waves 0-3
     for (int u = 0; u < nunits; ++u) {
         const int bb = (int)blockIdx.x + (u >> 1) * nwg, kc = u & 1;
         if (!kc) {
@@ -775,12 +844,13 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
             __builtin_amdgcn_sched_barrier(0); mm(w2, fa, fb, s0 + 3); __builtin_amdgcn_sched_barrier(0);
             if (ahead) wfrag(kc, s0 + 6, w2);
             __builtin_amdgcn_sched_barrier(0); mm(w3, fb, fa, s0 + 4); __builtin_amdgcn_sched_barrier(0);
+            if (STAG && tap == 4) KA_LDS_BARRIER();          // slot boundary: 20 k-steps before it, 16 and the epilogue behind it
         }
 #ifdef KA_PC_NO_W
 #undef wfrag
 #endif
         if (!MASKED && (u & 1) && !(a.tune_stagger & 1)) conv_epilogue<bf16_t, 2, MT>(a, acc, bb, wave * 2, 16, r, q);
-        KA_LDS_BARRIER();                                    // this image may be overwritten, the next one is complete
+        if (!(late && u == nunits - 1)) KA_LDS_BARRIER();    // this image may be overwritten, the next one is complete
         if (MASKED && kc) {
             // da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums (conv_epilogue's masked branch, term for term), y from LDS
             // (opaque copies of the lane coordinates: everything below is invariant across the boards, and hoisted above the
@@ -851,11 +921,11 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc_kernel(ConvArgs a) 
     }
 }
 
-template <bool TWO, bool MASKED, int NPW, int MT>
+template <bool TWO, bool MASKED, int NPW, int MT, bool STAG = false>
 static int launch_conv_pc_form(const ConvArgs& a, int grid, size_t lds, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<TWO, MASKED, NPW, MT>), done, what)) return rc;
-    hipLaunchKernelGGL((conv3x3_pc_kernel<TWO, MASKED, NPW, MT>), dim3(grid), dim3(512 + 64 * NPW), lds, st, a);
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc_kernel<TWO, MASKED, NPW, MT, STAG>), done, what)) return rc;
+    hipLaunchKernelGGL((conv3x3_pc_kernel<TWO, MASKED, NPW, MT, STAG>), dim3(grid), dim3(512 + 64 * NPW), lds, st, a);
     return ka_check_launch(what);
 }
 static int launch_conv_pc(ConvArgs a, hipStream_t st) {
@@ -865,8 +935,11 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     int grid = 256;
     if (const char* e = getenv("KA_CONV_P_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
     if (grid > a.B) grid = a.B;
+    int stag = 0;                                              // KA_CONV_P_STAG=1: waves 4-7 half a unit behind waves 0-3 (five-row-tile forms)
+    if (const char* e = getenv("KA_CONV_P_STAG")) stag = atoi(e);
 #define KA_PC_FORM(TWO_, MASKED_, NPW_, LDS_, WHAT_)                                                         \
-    (a.mt5 ? launch_conv_pc_form<TWO_, MASKED_, NPW_, 5>(a, grid, LDS_, st, WHAT_ ", 5 row tiles")            \
+    (a.mt5 ? ((stag && !MASKED_) ? launch_conv_pc_form<TWO_, false, NPW_, 5, true>(a, grid, LDS_, st, WHAT_ ", 5 row tiles, staggered") \
+                                 : launch_conv_pc_form<TWO_, MASKED_, NPW_, 5>(a, grid, LDS_, st, WHAT_ ", 5 row tiles"))            \
            : launch_conv_pc_form<TWO_, MASKED_, NPW_, kMTW>(a, grid, LDS_, st, WHAT_))
     if (a.in2 && a.ep_y) return KA_PC_FORM(true, true, 4, kPcLdsMasked, "conv3x3 (pc, masked)");
     if (a.in2) return KA_PC_FORM(true, false, 4, kPcLds, "conv3x3 (pc, two-tensor)");

@@ -57,7 +57,7 @@ __host__ __device__ constexpr unsigned dirs_of(int pc) {
 
 struct EnvArgs {
     uint8_t* state; unsigned long long* keys; uint8_t* checks;
-    const long long* actions; const int* err;
+    const long long* actions; unsigned long long* err;     // err[0]: this step's refusal, err[1]: the latch (see ka_shogi_env_step)
     float* obs; uint8_t* mask; uint32_t* mask_bits;
     float* rewards; uint8_t* terminated; uint8_t* truncated; float* terminal_obs; uint8_t* current_players;
     uint8_t* captured; uint8_t* term_reason; uint16_t* ply_out; int* material; unsigned long long* stats;
@@ -200,7 +200,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // an action of this step was refused: nothing moves in ANY game (vec_env.rs:651-690).  The outputs of this step are then
     // written again from the unchanged positions (zero rewards, no flags), so that the buffers the caller flips to hold the
     // positions to move and their masks -- the next step validates against them -- also when the caller reads the flag late.
-    const bool hold = a.mode == 1 && *a.err != 0;
+    const bool hold = a.mode == 1 && a.err[0] != 0;
+    // the refusal is latched in a second word that no launch clears: a caller that reads the flag late still sees the FIRST
+    // refused step (and the action it named) after any number of further steps
+    if (hold && env == 0 && lane == 0 && a.err[1] == 0) a.err[1] = a.err[0];
     uint8_t* st = a.state + (size_t)env * kStateBytes;
     unsigned long long* keys = a.keys + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
     uint8_t* checks = a.checks + (size_t)env * (a.max_ply > 0 ? a.max_ply : 1);
@@ -549,15 +552,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 }
 
 // an action is accepted when it is inside the action space and set in the mask handed out last (vec_env.rs:651-690);
-// err = n - (index of the first refused env), 0 when every action stands
-__global__ void shogi_validate_kernel(const long long* actions, const uint8_t* mask, const uint32_t* bits, int n, int kA, int* err) {
+// err = ((n - index of the first refused env) << 32) | the refused action (clamped to 32 bits), 0 when every action stands
+__global__ void shogi_validate_kernel(const long long* actions, const uint8_t* mask, const uint32_t* bits, int n, int kA, unsigned long long* err) {
     const int kWords = (kA + 31) >> 5;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long act = actions[i];
     bool ok = act >= 0 && act < kA;
     if (ok) ok = mask ? mask[(size_t)i * kA + act] != 0 : (bits[(size_t)i * kWords + (act >> 5)] >> (act & 31)) & 1;
-    if (!ok) atomicMax(err, n - i);
+    if (!ok) {
+        const long long c = act < -2147483647LL - 1 ? -2147483647LL - 1 : (act > 2147483647LL ? 2147483647LL : act);
+        atomicMax(err, ((unsigned long long)(n - i) << 32) | (unsigned int)(int)c);
+    }
 }
 
 }  // namespace
@@ -596,12 +602,12 @@ extern "C" int ka_shogi_env_step(void* state, void* keys, void* checks, const lo
     KA_REQUIRE((mask || mask_bits) && (prev_mask || prev_mask_bits), "shogi_env_step: needs the bool or the packed masks");
     KA_REQUIRE((obs_mode == 0 || obs_mode == 1) && (action_mode == 0 || action_mode == 1), "shogi_env_step: modes are 0 (default) or 1 (katago / spatial)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) { ka_set_error("shogi_env_step: memset failed"); return KA_ERR_HIP; }
+    if (hipMemsetAsync(err, 0, sizeof(unsigned long long), st) != hipSuccess) { ka_set_error("shogi_env_step: memset failed"); return KA_ERR_HIP; }
     hipLaunchKernelGGL(shogi_validate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, actions,
-                       static_cast<const uint8_t*>(prev_mask), static_cast<const uint32_t*>(prev_mask_bits), n, action_space(action_mode), err);
+                       static_cast<const uint8_t*>(prev_mask), static_cast<const uint32_t*>(prev_mask_bits), n, action_space(action_mode), reinterpret_cast<unsigned long long*>(err));
     EnvArgs a{};
     a.state = static_cast<uint8_t*>(state); a.keys = static_cast<unsigned long long*>(keys); a.checks = static_cast<uint8_t*>(checks);
-    a.actions = actions; a.err = err;
+    a.actions = actions; a.err = reinterpret_cast<unsigned long long*>(err);
     a.obs = obs; a.mask = static_cast<uint8_t*>(mask); a.mask_bits = static_cast<uint32_t*>(mask_bits);
     a.rewards = rewards; a.terminated = static_cast<uint8_t*>(terminated); a.truncated = static_cast<uint8_t*>(truncated);
     a.terminal_obs = terminal_obs; a.current_players = static_cast<uint8_t*>(current_players);

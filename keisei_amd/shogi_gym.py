@@ -189,7 +189,7 @@ class VecEnv:
         self._ply = two(n, dtype=torch.int16)                 # u16 payload (max_ply <= 65535); viewed as uint16 on the host
         self._material = two(n, dtype=torch.int32)
         self._stats = z(4, dtype=torch.int64)
-        self._err = z(1, dtype=torch.int32)
+        self._err = z(2, dtype=torch.int64)                   # [this step's refusal, the latch raise_if_refused reads and clears]
         self._actions = z(n, dtype=torch.int64)
         # as in the reference's constructor (vec_env.rs:574-612): the games stand at the start position, the mask buffer
         # is still all-false -- a step() before reset() is refused ("action index ... is not legal")
@@ -204,6 +204,7 @@ class VecEnv:
         self._armed = True
         with torch.cuda.device(self.device):
             self._cur = 0
+            self._err.zero_()                                 # (a refusal nobody asked about ends with the games it belonged to)
             _lib.call("ka_shogi_env_reset", self._state, self._keys, self._checks, self._n, self._max_ply, self._omode,
                       self._amode, self._obs[0], self._mask[0], self._bits[0], self._players[0], 0, _lib.stream_ptr())
         return ResetResult(self._out(self._obs[0]), self._out(self._mask[0]),
@@ -248,13 +249,18 @@ class VecEnv:
 
     def raise_if_refused(self, actions: Optional[torch.Tensor] = None) -> None:
         """The reference refuses a step before anything moves (vec_env.rs:660-690); so does the kernel, and this reads
-        its flag (one 4-byte copy).  With check_actions=False call it whenever convenient: a refused step moved no game,
-        and its result holds the unchanged positions again (zero rewards, no flags)."""
-        e = int(self._err.item())
-        if e == 0:
+        its latch (one 8-byte copy).  With check_actions=False call it whenever convenient: a refused step moved no game,
+        its result holds the unchanged positions again (zero rewards, no flags), and the latch keeps the FIRST refusal --
+        env index and action, stored by the kernel -- through any number of later steps until it is reported here."""
+        word = int(self._err[1].item())
+        if word == 0:
             return
-        i = self._n - e
-        a = int((actions if actions is not None else self._actions)[i].item())
+        self._err[1].zero_()
+        i = self._n - (word >> 32)
+        a = word & 0xFFFFFFFF
+        a = a - (1 << 32) if a >= (1 << 31) else a
+        if actions is not None and abs(a) >= (1 << 31) - 1:   # clamped by the kernel: the caller's own tensor has the exact index
+            a = int(actions[i].item())
         if a < 0:
             raise ValueError(f"env {i}: negative action index {a}")
         raise RuntimeError(f"env {i}: action index {a} is not legal")

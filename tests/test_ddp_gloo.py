@@ -25,7 +25,7 @@ def _free_port() -> int:
 def _worker(rank: int, world: int, port: int, outdir: str) -> None:
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from keisei_amd.training.katago_ppo import KataGoPPOAlgorithm, KataGoPPOParams, KataGoRolloutBuffer
     from keisei_amd.training.model_registry import build_model
     from keisei_amd.training.value_adapter import MultiHeadValueAdapter
@@ -66,6 +66,22 @@ def test_two_rank_ddp_update_keeps_ranks_in_sync():
         if "running_" in k or "num_batches" in k:
             continue
         assert torch.allclose(v, b["sd"][k], rtol=0, atol=1e-7), k
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_ddp_update_keeps_ranks_in_sync():
+    """The rank count of BASELINE configs[3] (keisei-ddp.toml: 8 GPUs), rehearsed on CPU over gloo: eight ranks with their own
+    rollouts, one update() each, identical learned weights everywhere afterwards."""
+    world = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        outs = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+    assert len({o["metrics"]["policy_loss"] for o in outs}) == world          # different data on every rank
+    for o in outs[1:]:
+        for k, v in outs[0]["sd"].items():
+            if "running_" in k or "num_batches" in k:
+                continue
+            assert torch.allclose(v, o["sd"][k], rtol=0, atol=1e-7), k
 
 
 def test_distributed_context_without_torchrun(monkeypatch):

@@ -56,3 +56,38 @@ def test_bench_gpus_2_starts_itself():
     assert d["config"]["parallelism"] == "dp2+syncbn" and d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]   # both ranks' samples
     assert all(v == v for v in d["train_metrics"].values())
+
+
+def test_default_line_carries_the_secondary_measurements():
+    """The driver runs `python bench.py` with no workload flag: SURVEY 8d's "report both" (whole update() beside the minibatch step)
+    and BASELINE configs[1] / configs[4] ride on that line as bounded legs (`secondary`), next to the headline's own keys."""
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-fp32")
+    assert d["metric"].startswith("PPO samples/sec, se_resnet 40x256") and d["roofline"]["launches_timed"] > 0
+    sec = d["secondary"]
+    assert set(sec) == {"whole_update", "workload_6x128", "transformer"}
+    assert sec["whole_update"]["samples_per_s"] > 0 and sec["whole_update"]["store"] == "device"
+    assert sec["whole_update"]["transitions"] == 128 * 128
+    for k in ("workload_6x128", "transformer"):
+        assert sec[k]["samples_per_s"] > 0 and sec[k]["steps"] == 3 and "workload" in sec[k]
+        r = sec[k]["roofline"]
+        assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_bench_gpus_6_rehearsal_over_gloo():
+    """The launcher at the largest rank count this pool lets one card carry (six processes may use a GPU at once; the eight-rank
+    wiring of BASELINE configs[3] is rehearsed on CPU by tests/test_ddp_gloo.py::test_eight_rank_ddp_update_keeps_ranks_in_sync):
+    `bench.py --gpus 6` over gloo on the one GPU, every rank seen, dp6 + SyncBatchNorm, the value the sum of the ranks."""
+    saved = {k: os.environ.get(k) for k in ("KA_BENCH_BACKEND",)}
+    os.environ["KA_BENCH_BACKEND"] = "gloo"
+    try:
+        d = run_bench("--gpus", "6", "--workload", "2x32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert d["n_gpus"] == 6 and d["n_ranks_seen"] == 6 and d["backend"] == "gloo"
+    assert d["config"]["parallelism"] == "dp6+syncbn" and d["config"]["global_batch"] == 6 * d["config"]["per_gpu_batch"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    assert all(v == v for v in d["train_metrics"].values())

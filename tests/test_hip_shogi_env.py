@@ -455,6 +455,36 @@ def test_a_refused_step_without_host_checks_leaves_every_buffer_consistent():
     assert np.array_equal(r3.rewards.cpu().numpy(), o3["rewards"]) and np.array_equal(r3.current_players.cpu().numpy(), o3["current_players"])
 
 
+def test_a_refusal_read_late_survives_later_steps():
+    """check_actions=False: the refusal is latched by the kernel (include/keisei_amd.h, ka_shogi_env_step: word 1 of `err`), so an
+    illegal step followed by legal ones is still reported -- with the env index and the action of the FIRST refused step, also
+    when the actions arrived as a device tensor -- and reporting clears the latch."""
+    n = 5
+    dev = _env(n, 60, output="torch", check_actions=False)
+    ref = OracleVecEnv(n, 60)
+    dev.reset(); _, mask = ref.reset()
+    rng = np.random.default_rng(11)
+    pick = lambda m: np.array([rng.choice(np.flatnonzero(row)) for row in m], dtype=np.int64)
+    bad = pick(mask)
+    bad[2] = int(np.flatnonzero(~mask[2])[-1])
+    bad[4] = int(np.flatnonzero(~mask[4])[0])                            # a second offender: the lower env index is reported
+    dev.step(torch.from_numpy(bad).cuda())                               # refused, nothing raised
+    for _ in range(3):                                                   # legal steps from the unchanged positions
+        acts = pick(mask)
+        r = dev.step(torch.from_numpy(acts).cuda()); o = ref.step(acts)
+        mask = o["legal_masks"]
+        assert np.array_equal(r.legal_masks.cpu().numpy(), mask)
+    later = pick(mask); later[1] = int(np.flatnonzero(~mask[1])[0])
+    dev.step(torch.from_numpy(later).cuda())                             # a second refused step does not displace the first
+    with pytest.raises(RuntimeError, match=rf"env 2: action index {bad[2]} is not legal"):
+        dev.raise_if_refused()
+    dev.raise_if_refused()                                               # reported once: the latch is clear again
+    neg = pick(mask); neg[0] = -7
+    dev.step(torch.from_numpy(neg).cuda())
+    with pytest.raises(ValueError, match=r"env 0: negative action index -7"):
+        dev.raise_if_refused()
+
+
 def test_full_size_invariants_on_the_device():
     """4096 games x 300 steps with on-device sampling (no oracle at this size): 40 pieces in every game, never an empty
     mask, planes agree with the stored boards, finished games restart at the start position, counters add up."""

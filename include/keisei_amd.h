@@ -35,6 +35,10 @@ extern "C" {
 int ka_version(void);
 const char* ka_target_arch(void);          /* "gfx950" */
 const char* ka_last_error(void);           /* message of the last failing call on this thread */
+/* Run-time switches (KA_CONV_*, KA_WGRAD_*, KA_TF_*, ...; csrc/common.h KA_OPTIONS) are read from the environment ONCE, by the
+ * first launch that asks, into the table the launchers index (no getenv() on the enqueue path).  A process that changes one
+ * afterwards calls ka_options_reload() (returns the number of switches set). */
+int ka_options_reload(void);
 
 /* ---- 3x3 convolution (implicit GEMM on MFMA) ----------------------------------------------------
  * Replaces nn.Conv2d(Cin, Cout, 3, padding=1, bias=False): input_conv / conv1 / conv2

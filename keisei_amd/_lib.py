@@ -109,6 +109,7 @@ _SIGS = {
     "ka_tf_attention_bwd": "pppp iii f q i p",
     "ka_tf_attention_bwd_o": "ppppp iii f q i p",
     "ka_version": "",
+    "ka_options_reload": "",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "d": ctypes.c_double, "q": ctypes.c_longlong}   # q also carries 64-bit seeds
 
@@ -145,6 +146,12 @@ def _load() -> ctypes.CDLL:
     lib.ka_target_arch.argtypes = []
     _lib = lib
     return lib
+
+
+def reload_options() -> int:
+    """The library reads its KA_* switches from the environment once (first launch).  A process that changes one afterwards
+    -- tests, A/B tools flipping a kernel form in place -- calls this to have them read again; returns how many are set."""
+    return int(_load().ka_options_reload())
 
 
 def library_path() -> Path:

@@ -1078,7 +1078,7 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
     KA_REQUIRE(y && scale && shift && out, "block_tail_fwd: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nt = 0;
-    const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
+    const int nsq = ka_opt_set(KA_OPT_BOARD_PAIRS) ? 0 : board16_plan(C, dtype, &nt);
     if (nsq > 0 && nsq <= 11 && B > 0) {
         const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
         const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
@@ -1103,7 +1103,7 @@ extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, 
     KA_REQUIRE(x && pool, "pool_fwd: null tensor");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nt = 0;
-    const int nsq = getenv("KA_BOARD_PAIRS") ? 0 : board16_plan(C, dtype, &nt);
+    const int nsq = ka_opt_set(KA_OPT_BOARD_PAIRS) ? 0 : board16_plan(C, dtype, &nt);
     if (nsq > 0 && nsq <= 11 && B > 0) {
         const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
         const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
@@ -1246,7 +1246,7 @@ extern "C" int ka_block_dx(const void* dxc, const void* dout, const void* out, c
     KA_REQUIRE(x && xpool && dpool && dx && ((dout == nullptr) == (out == nullptr)), "block_dx: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nt = 0;
-    if (B > 0 && !getenv("KA_BOARD_PAIRS") && board16_plan(C, dtype, &nt) > 0) {
+    if (B > 0 && !ka_opt_set(KA_OPT_BOARD_PAIRS) && board16_plan(C, dtype, &nt) > 0) {
         if (nt == 512) {
             KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_dx16_kernel<T, 512>), dim3(B), dim3(512), (size_t)5 * C * sizeof(float), st, (const T*)dxc,
                                                     (const T*)dout, (const T*)out, (const T*)x, xpool, dpool, (T*)dx, C));

@@ -25,3 +25,37 @@ int ka_check_launch(const char* what) {
 extern "C" const char* ka_last_error(void) { return g_err; }
 extern "C" int ka_version(void) { return 1; }
 extern "C" const char* ka_target_arch(void) { return "gfx950"; }
+
+// ---- run-time switches: the environment is read once (common.h, KA_OPTIONS) -------------------------------------------------
+#include <atomic>
+#include <stdlib.h>
+static const char* const g_opt_names[KA_OPT_COUNT] = {
+#define KA_OPT_NAME(n) "KA_" #n,
+    KA_OPTIONS(KA_OPT_NAME)
+#undef KA_OPT_NAME
+};
+static KaOptVal g_opt_tables[2][KA_OPT_COUNT];               // the table in use and the one a reload fills
+static std::atomic<const KaOptVal*> g_opts{nullptr};
+static std::atomic<int> g_opt_flip{0};
+static const KaOptVal* ka_opts_load() {
+    KaOptVal* t = g_opt_tables[g_opt_flip.fetch_add(1) & 1];
+    for (int i = 0; i < KA_OPT_COUNT; ++i) {
+        const char* e = getenv(g_opt_names[i]);
+        t[i].set = e != nullptr;
+        t[i].val = e ? atoi(e) : 0;
+    }
+    g_opts.store(t, std::memory_order_release);
+    return t;
+}
+const KaOptVal* ka_opts() {
+    const KaOptVal* t = g_opts.load(std::memory_order_acquire);
+    return t ? t : ka_opts_load();
+}
+// re-read every KA_* switch from the environment (a process that changes one after its first launch: tests, A/B tools);
+// returns the number of switches set.  Not meant to race with launches of other threads.
+extern "C" int ka_options_reload(void) {
+    const KaOptVal* t = ka_opts_load();
+    int n = 0;
+    for (int i = 0; i < KA_OPT_COUNT; ++i) n += t[i].set;
+    return n;
+}

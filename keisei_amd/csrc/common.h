@@ -57,6 +57,25 @@ inline const char* ka_diag_env(const char* name) {
 #endif
 }
 
+// ---- run-time switches (launch plan) ----------------------------------------------------------------------------------------
+// Every KA_* switch the library honours is read from the environment ONCE -- at the first launch that asks, or again when
+// the caller says so (ka_options_reload: tests and A/B tools that flip a switch inside one process) -- into a table the
+// launchers index: no getenv() on the enqueue path.  bench.py records the switches set in its environment.
+#define KA_OPTIONS(X)                                                                                                      \
+    X(CONV_P) X(CONV_MT) X(CONV_PC2) X(CONV_P_STAG) X(CONV_P_PRIO) X(CONV_P_WGS) X(CONV_P_NPW) X(CONV_WM) X(CONV_KC)       \
+    X(CONV_NTW) X(CONV_STAGGER) X(CONV_PRIO) X(WGRAD_TN) X(WGRAD_WGS) X(BOARD_PAIRS) X(TF_LDS_EPI) X(TF_K256) X(TF_BIG)    \
+    X(TF_MAP2D) X(TF_ATTN_LDS) X(TF_ATTN_ONE)
+enum KaOpt {
+#define KA_OPT_ENUM(n) KA_OPT_##n,
+    KA_OPTIONS(KA_OPT_ENUM)
+#undef KA_OPT_ENUM
+    KA_OPT_COUNT
+};
+struct KaOptVal { int set, val; };
+const KaOptVal* ka_opts();                                   // capi.hip
+inline bool ka_opt_set(KaOpt o) { return ka_opts()[o].set != 0; }
+inline int ka_opt(KaOpt o, int dflt) { const KaOptVal v = ka_opts()[o]; return v.set ? v.val : dflt; }
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950.

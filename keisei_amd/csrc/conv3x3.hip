@@ -931,12 +931,11 @@ static int launch_conv_pc_form(const ConvArgs& a, int grid, size_t lds, hipStrea
 static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     a.tune_stagger = 0; a.tune_prio = 0;                       // diagnostics: KA_CONV_P_ABL 1 no epilogue, 2 no staging after the first unit
     if (const char* e = ka_diag_env("KA_CONV_P_ABL")) a.tune_stagger = atoi(e);
-    if (const char* e = getenv("KA_CONV_P_PRIO")) a.tune_prio = atoi(e);
+    a.tune_prio = ka_opt(KA_OPT_CONV_P_PRIO, 0);
     int grid = 256;
-    if (const char* e = getenv("KA_CONV_P_WGS")) { const int v = atoi(e); if (v > 0) grid = v; }
+    if (const int v = ka_opt(KA_OPT_CONV_P_WGS, 0); v > 0) grid = v;
     if (grid > a.B) grid = a.B;
-    int stag = 0;                                              // KA_CONV_P_STAG=1: waves 4-7 half a unit behind waves 0-3 (five-row-tile forms)
-    if (const char* e = getenv("KA_CONV_P_STAG")) stag = atoi(e);
+    const int stag = ka_opt(KA_OPT_CONV_P_STAG, 0);            // KA_CONV_P_STAG=1: waves 4-7 half a unit behind waves 0-3 (five-row-tile forms)
 #define KA_PC_FORM(TWO_, MASKED_, NPW_, LDS_, WHAT_)                                                         \
     (a.mt5 ? ((stag && !MASKED_) ? launch_conv_pc_form<TWO_, false, NPW_, 5, true>(a, grid, LDS_, st, WHAT_ ", 5 row tiles, staggered") \
                                  : launch_conv_pc_form<TWO_, MASKED_, NPW_, 5>(a, grid, LDS_, st, WHAT_ ", 5 row tiles"))            \
@@ -945,10 +944,249 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
     if (a.in2) return KA_PC_FORM(true, false, 4, kPcLds, "conv3x3 (pc, two-tensor)");
     // two staging waves where the input carries a transform (its arithmetic shares the SIMDs with the MFMA waves: measured
     // 0.369-0.374 against 0.380-0.386 ms with four), four for the plain input (0.339 against 0.349); KA_CONV_P_NPW forces one
-    if (const char* e = getenv("KA_CONV_P_NPW"); e ? atoi(e) == 2 : (a.in_scale || a.relu || a.in_bias))
+    if (ka_opt_set(KA_OPT_CONV_P_NPW) ? ka_opt(KA_OPT_CONV_P_NPW, 4) == 2 : (a.in_scale || a.relu || a.in_bias))
         return KA_PC_FORM(false, false, 2, kPcLds, "conv3x3 (pc, 2 staging waves)");
     return KA_PC_FORM(false, false, 4, kPcLds, "conv3x3 (pc)");
 #undef KA_PC_FORM
+}
+
+// The masked data-gradient epilogue for a wave that has few registers to spare (conv3x3_pc2_kernel: the other board's accumulators
+// and the weight ring stay live): da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums, conv_epilogue's masked branch term
+// for term, but one MFMA tile -- four channels per lane, 8-byte pieces -- at a time, the y pieces of the second tile requested
+// before the first is worked on.  Five row tiles: every row is a square of the board.
+__device__ __forceinline__ void conv_epilogue_masked_lean(const ConvArgs& a, f32x4 (&acc)[5][2], int bb, int nt0, int r, int q) {
+    const int cb[2] = {chan_of(nt0, 4 * q, 16), chan_of(nt0 + 1, 4 * q, 16)};
+    // one uniform base per tensor and 32-bit lane offsets (Cout = 256: a row is 512 B, a row tile 8 KB)
+    const char* yb = static_cast<const char*>(a.ep_y) + (size_t)bb * (KA_BOARD * 512);
+    char* ob = static_cast<char*>(a.out) + (size_t)bb * (KA_BOARD * 512);
+    const int lo[2] = {r * 512 + cb[0] * 2, r * 512 + cb[1] * 2};
+    bf16x4 yv[2][5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) yv[0][mt] = *reinterpret_cast<const bf16x4*>(yb + lo[0] + mt * 8192);
+    if (a.bsum) {                                            // per-board sums of the raw accumulators (conv_epilogue, same order)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s0[i] += acc[mt][j][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
+            if (r == 0) *reinterpret_cast<f32x4*>(a.bsum + bb * 256 + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) yv[1][mt] = *reinterpret_cast<const bf16x4*>(yb + lo[1] + mt * 8192);
+        }
+        const f32x4 esc = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]), esh = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
+        const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]), eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
+        float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (float)yv[j][mt][e];
+                const __bf16 db = (__bf16)acc[mt][j][e];
+                const float d = (y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
+                o[e] = (__bf16)d;
+            }
+            *reinterpret_cast<bf16x4*>(ob + lo[j] + mt * 8192) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
+        if (r == 0) {
+            *reinterpret_cast<f32x4*>(a.ep_s1 + bb * 256 + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+            *reinterpret_cast<f32x4*>(a.ep_s2 + bb * 256 + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+        }
+    }
+}
+
+// ---------------------------------------------------------------- two boards per weight fragment (bf16, Cin = Cout = 256)
+// What paces conv3x3_pc_kernel is not the matrix pipe but the weight stream: every (board, chunk) unit pulls its 590 KB of
+// fragments out of the L2 again -- 4.8 GB per launch at B = 4096, i.e. 15 TB/s through a path that delivers about 70 GB/s per
+// CU (TA busy 68 %, TCP pending-stall 38 % of the kernel's cycles at a matrix pipe 61 % busy: profiles/r04_conv_vmem_path_counters.json).
+// Here a unit is TWO boards x a 64-channel chunk: an MFMA wave owns ten row tiles (squares 0..79 of both boards) x two channel
+// tiles, so a weight fragment feeds 20 MFMAs instead of 10 and the stream per board is halved; the four 64-channel images
+// (two boards x two buffers) take the LDS the two 128-channel images took.  Activation fragments are read one k-step ahead into
+// the registers of the tile just multiplied (one set, no second buffer); every LDS offset of the 18 k-steps of a unit is an
+// immediate.  Same weight packs, staging transforms and epilogue as conv3x3_pc_kernel; the k-steps of an output element are
+// summed in the order (64-channel chunk, tap, k-step) instead of (128-channel chunk, tap, k-step): results equal those of the
+// other kernels up to fp32 re-association.
+constexpr int kP2Stride = 64 * 2 + 32;                                  // bytes per square of a 64-channel image: 16 fragment lanes on 16 bank slots
+constexpr int kP2Img = kImgSquares1 * kP2Stride;                        // 28 960 B
+constexpr int kP2Lds = 4 * kP2Img;                                      // [buffer][board]
+constexpr int kP2Base = (kPW + 1) * kP2Stride;                          // the most negative tap offset, folded into the row base
+
+template <bool TWO, bool MASKED, int NPW>
+__global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a) {
+    constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
+    constexpr int kHalf = KA_BOARD * 8, kPieces = 2 * kHalf;            // 16-byte pieces of a unit: 2 boards x 81 squares x 8
+    constexpr int KP = (kPieces + NP - 1) / NP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int nwg = gridDim.x, npairs_all = (a.B + 1) >> 1;
+    if ((int)blockIdx.x >= npairs_all) return;
+    for (int i = tid; i < kP2Lds / 16; i += NT_) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+    const int npairs = (npairs_all - (int)blockIdx.x + nwg - 1) / nwg, nunits = 4 * npairs;
+    if (!MASKED) a.ep_y = nullptr;                           // (compile-time: conv_epilogue's masked branch is not compiled in)
+    __syncthreads();
+
+    if (wave >= 8) {
+        // ---------------- staging waves: piece i = pt + NP k of a unit = board i / 648, square (i % 648) / 8, 16-byte piece i % 8
+        const int pt = tid - 512, pc = pt & 7;
+        const bool has_aff = a.in_scale != nullptr;
+        auto stage = [&](int u) {
+            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), ch0 = (u & 3) * 64 + pc * 8;
+            char* img = smem + (u & 1) * (2 * kP2Img);
+            bf16x8 pv[KP], pw[TWO ? KP : 1];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k, j = i >= kHalf ? 1 : 0, sq = (i - j * kHalf) >> 3;
+                pv[k] = bf16x8{};
+                if (TWO) pw[TWO ? k : 0] = bf16x8{};
+                if (i < kPieces && b0 + j < a.B) {
+                    const size_t off = (((size_t)(b0 + j) * KA_BOARD + sq) * 256 + ch0) * 2;
+                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
+                    if (TWO) pw[TWO ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
+                }
+            }
+            float sc[8], sh[8], k3[8], pb[2][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
+                k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
+                pb[0][e] = (!TWO && a.in_bias) ? a.in_bias[(size_t)b0 * 256 + ch0 + e] : 0.f;
+                pb[1][e] = (!TWO && a.in_bias && b0 + 1 < a.B) ? a.in_bias[(size_t)(b0 + 1) * 256 + ch0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = pt + NP * k, j = i >= kHalf ? 1 : 0, sq = (i - j * kHalf) >> 3;
+                if (i >= kPieces) continue;
+                bf16x8 v = pv[k];
+                if (b0 + j < a.B) {
+                    if (TWO) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                        if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + (((size_t)(b0 + j) * KA_BOARD + sq) * 256 + ch0) * 2) = v;
+                    } else if (has_aff || a.relu || a.in_bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            f32x2 f = {(float)v[e], (float)v[e + 1]};
+                            if (has_aff) f = __builtin_elementwise_fma(f, f32x2{sc[e], sc[e + 1]}, f32x2{sh[e], sh[e + 1]});
+                            if (a.relu) f = __builtin_elementwise_max(f, f32x2{0.f, 0.f});
+                            if (a.in_bias) f += j ? f32x2{pb[1][e], pb[1][e + 1]} : f32x2{pb[0][e], pb[0][e + 1]};
+                            v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
+                        }
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(img + j * kP2Img + lds_square(0, sq) * kP2Stride + pc * 16) = v;
+            }
+        };
+        stage(0);
+        KA_LDS_BARRIER();
+        for (int u = 0; u < nunits; ++u) {
+            if (u + 1 < nunits) stage(u + 1);
+            KA_LDS_BARRIER();
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves: ten row tiles (five per board) x two channel tiles; the weight ring (three slots, two k-steps
+    // ahead: a k-step is 20 MFMAs per wave) runs on across the units
+    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
+    // weight fragments of step s of 64-channel chunk c4: s = tap * 2 + k-step; steps 18, 19 are the first two of the next unit's chunk
+    auto wfrag = [&](int c4, int s, bf16x8 (&f)[2]) {
+        if (s >= 18) { s -= 18; c4 = (c4 + 1) & 3; }
+        const int tap = s >> 1, ks = c4 * 2 + (s & 1);
+        const char* p = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
+        f[0] = *reinterpret_cast<const bf16x8*>(p);
+        f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+    };
+    int rowbase[5];                                          // LDS byte offset of (row tile t, lane) in image [0][0], minus kP2Base
+#pragma unroll
+    for (int t = 0; t < 5; ++t) rowbase[t] = lds_square(0, t * 16 + r) * kP2Stride + q * 16 - kP2Base;
+    bf16x8 wr[3][2];
+    wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
+    f32x4 acc[10][2];
+    KA_LDS_BARRIER();                                        // unit 0 is staged
+    for (int u = 0; u < nunits; ++u) {
+        const int c4 = u & 3;
+        if (!c4) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        const char* img = smem + (u & 1) * (2 * kP2Img);
+        // activation fragments: each refilled right after the two MFMAs that read it.  NF = 10 registers sets: with the same tile's
+        // fragment of the next k-step (a whole k-step of MFMAs ahead); NF = 5 (the masked form, whose epilogue needs the
+        // registers): with the fragment five tiles further on (the other board's tile of this k-step, then this board's tile
+        // of the next k-step) -- 1-2 % slower
+        constexpr int NF = MASKED ? 5 : 10;
+        bf16x8 fa[NF];
+#pragma unroll
+        for (int t = 0; t < NF; ++t)
+            fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t % 5] + (t / 5) * kP2Img + kP2Base + (-kPW - 1) * kP2Stride);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
+            if (!(MASKED && c4 == 3 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int tap = s >> 1, sn = s + 1, tapn = sn >> 1;
+            const int toff = kP2Base + ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kP2Stride + (s & 1) * 64;
+            const int toffn = kP2Base + ((tapn / 3 - 1) * kPW + (tapn % 3 - 1)) * kP2Stride + (sn & 1) * 64;
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][0], fa[t % NF], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][1], fa[t % NF], acc[t][1], 0, 0, 0);
+                if (NF == 10) {
+                    if (s < 17) fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t % 5] + (t / 5) * kP2Img + toffn);
+                } else if (t < 5) fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t] + kP2Img + toff);
+                else if (s < 17) fa[t - 5] = *reinterpret_cast<const bf16x8*>(img + rowbase[t - 5] + toffn);
+            }
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if ((NF == 5 && t < 5) || s < 17) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c4 == 3) {
+            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg);
+            if constexpr (MASKED) {
+                // (opaque copies of the lane coordinates: the epilogue's addresses are invariant across the pairs, and hoisted
+                //  above the MFMA loop they spill it)
+                int rl = r, ql = q;
+                asm volatile("" : "+v"(rl), "+v"(ql));
+                conv_epilogue_masked_lean(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[0]), b0, wave * 2, rl, ql);
+                __builtin_amdgcn_sched_barrier(0);
+                if (b0 + 1 < a.B) conv_epilogue_masked_lean(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, rl, ql);
+                wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
+            } else {
+                conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[0]), b0, wave * 2, 16, r, q);
+                if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, 16, r, q);
+            }
+        }
+        KA_LDS_BARRIER();                                    // these images may be overwritten, the next pair is complete
+    }
+}
+
+template <bool TWO, bool MASKED, int NPW>
+static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* what) {
+    static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW>), done, what)) return rc;
+    const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
+    return ka_check_launch(what);
+}
+static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
+    if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4>(a, st, "conv3x3 (two boards per unit, two-tensor, masked)");
+    if (a.in2) return launch_conv_pc2_form<true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
+    return launch_conv_pc2_form<false, false, 4>(a, st, "conv3x3 (two boards per unit)");
 }
 
 // ---------------------------------------------------------------- square 80 of sixteen boards as one row tile
@@ -1116,12 +1354,18 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         // the producer / consumer form.  KA_CONV_P: 0 off; 1 (default) the forward forms -- 8 % / 4 % faster alone, 1 % in
         // the step; 2: + the two-tensor data-gradient form with the plain epilogue (no faster alone, slower in the step: it
         // owns every register file, so the weight-gradient stream no longer runs beside it); 3: + the masked epilogue (spills)
-        const char* ep = getenv("KA_CONV_P");
-        const int pv = ep ? atoi(ep) : 1;
+        const int pv = ka_opt(KA_OPT_CONV_P, 1);
         // training batches of the 256-channel tower: squares 0..79 as five row tiles here, square 80 of sixteen boards at a
         // time in conv3x3_corner_kernel (KA_CONV_MT=6: all 81 squares as six row tiles, the round-1/2 form)
-        const char* em = getenv("KA_CONV_MT");
-        want5 = a.Cin == 256 && a.Cout == 256 && a.B >= 512 && !(em && atoi(em) == 6);
+        want5 = a.Cin == 256 && a.Cout == 256 && a.B >= 512 && ka_opt(KA_OPT_CONV_MT, 5) != 6;
+        // two boards per weight fragment (conv3x3_pc2_kernel).  KA_CONV_PC2: 0 off; 1 the forward forms; 2 (default) + the two-tensor
+        // data gradient with the register-only epilogue; 3 + the masked epilogue (measured slower than conv3x3_kernel's in the step)
+        const int p2 = ka_opt(KA_OPT_CONV_PC2, 2);
+        if (p2 != 0 && want5 && pv != 0 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3)) {
+            a.mt5 = 1;
+            if (int rc = launch_conv_pc2(a, st)) return rc;
+            return launch_conv_corner(a, st);
+        }
         if (pv != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 &&
             (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) {
             a.mt5 = want5;
@@ -1131,7 +1375,7 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     }
     // boards per workgroup: 1 = 256-thread workgroups, two independent ones per CU when the tile allows it
     int wm = 1;
-    if (const char* e = getenv("KA_CONV_WM")) { const int v = atoi(e); if (v == 1 || v == 2) wm = v; }   // experiments
+    if (const int v = ka_opt(KA_OPT_CONV_WM, 0); v == 1 || v == 2) wm = v;   // experiments
     const int img_squares = wm == 2 ? kLdsSquares : kImgSquares1;
     // LDS chunk: the largest divisor of Cin (in k-steps) whose 16-byte pieces tile the 256 staging threads of a board
     // and whose image fits: squares x (KC*size + 32) <= 150 KiB
@@ -1153,10 +1397,10 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
     while (ntw > 1 && (long long)((a.B + wm - 1) / wm) * ((a.Cout + 64 * ntw - 1) / (64 * ntw)) < 256) ntw >>= 1;
     a.tune_prio = 1;          // static priority for the second wave of every SIMD: it reaches its epilogue first
     // tuning overrides (experiments only): channels per LDS chunk, n-tiles per wave
-    if (const char* e = getenv("KA_CONV_KC")) { const int v = atoi(e); if (v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v; }
-    if (const char* e = getenv("KA_CONV_NTW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ntw = v; }
-    if (const char* e = getenv("KA_CONV_STAGGER")) a.tune_stagger = atoi(e);
-    if (const char* e = getenv("KA_CONV_PRIO")) a.tune_prio = atoi(e);
+    if (const int v = ka_opt(KA_OPT_CONV_KC, 0); v > 0 && a.Cin % v == 0 && v % CPK == 0 && v <= kc) kc = v;
+    if (const int v = ka_opt(KA_OPT_CONV_NTW, 0); v == 1 || v == 2 || v == 4) ntw = v;
+    a.tune_stagger = ka_opt(KA_OPT_CONV_STAGGER, a.tune_stagger);
+    a.tune_prio = ka_opt(KA_OPT_CONV_PRIO, a.tune_prio);
     KA_REQUIRE(256 % (kc * E::kSize / 16) == 0, "conv3x3: chunk of %d channels does not tile the workgroup", kc);
     a.KC = kc;
     if (wm == 1) {

@@ -1887,10 +1887,9 @@ static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* b
     if (nsplit > 1) { len = ((K + kBK - 1) / kBK + nsplit - 1) / nsplit * kBK; nsplit = (K + len - 1) / len; }
     NtArgs g{static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(B), C, bias, residual, relu_act, M, N, K, lda, ldb, ldc,
              c_bf16, relu, len, 1, drop_p, seed};
-    if (const char* e = getenv("KA_TF_LDS_EPI")) g.lds_epilogue = atoi(e);
+    g.lds_epilogue = ka_opt(KA_OPT_TF_LDS_EPI, g.lds_epilogue);
     // K = 256 (d_model of BASELINE config 5), bf16 output, whole 16-column runs: the activation-stationary form (KA_TF_K256=0: off)
-    const char* ek = getenv("KA_TF_K256");
-    const bool k256 = !(ek && atoi(ek) == 0);
+    const bool k256 = ka_opt(KA_OPT_TF_K256, 1) != 0;
     if (k256 && K == kKsK && nsplit == 1 && c_bf16 && N % kKsCols == 0 && N <= 4096 && ldc % 8 == 0 && lda >= K && ldb >= K) {
         const size_t lds = kKsLds + (size_t)N * sizeof(float);
         const int full = M / kKsRows, tail = M % kKsRows ? 1 : 0;
@@ -1919,8 +1918,7 @@ static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* b
     static std::atomic<unsigned long long> done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel), done, "tf_gemm_nt")) return rc;
     // all three extents large, nothing but a bias in the epilogue: the 256 x 256 tile form (KA_TF_BIG=0: off)
-    const char* eb = getenv("KA_TF_BIG");
-    if (!(eb && atoi(eb) == 0) && nsplit == 1 && M >= 1024 && N >= 1024 && K >= 1024 && K % kBK == 0 && !residual && !relu_act &&
+    if (ka_opt(KA_OPT_TF_BIG, 1) != 0 && nsplit == 1 && M >= 1024 && N >= 1024 && K >= 1024 && K % kBK == 0 && !residual && !relu_act &&
         !relu && drop_p == 0.f && (size_t)M * lda < (1ull << 31) && (size_t)N * ldb < (1ull << 31)) {      // (32-bit operand byte offsets)
         g.map_gx = (N + kGN - 1) / kGN; g.map_gy = (M + kGM - 1) / kGM;
         const int supers = ((g.map_gx + 7) / 8) * ((g.map_gy + 3) / 4);
@@ -1931,8 +1929,7 @@ static int tf_gemm_nt_impl(const void* A, const void* B, void* C, const float* b
     }
     const int gx = (N + kBN - 1) / kBN, gy = (M + kBM - 1) / kBM;
     dim3 grid(gx, gy, nsplit);
-    const char* e2 = getenv("KA_TF_MAP2D");                  // (0: the one-m-tile-per-XCD map for every shape)
-    if (gx > 8 && gy >= 8 && !(e2 && atoi(e2) == 0)) {
+    if (gx > 8 && gy >= 8 && ka_opt(KA_OPT_TF_MAP2D, 1) != 0) {      // (0: the one-m-tile-per-XCD map for every shape)
         g.map_gx = gx; g.map_gy = gy;
         const int supers = ((gx + 7) / 8) * ((gy + 7) / 8);
         grid = dim3(((supers + 7) / 8) * 8 * 64, 1, nsplit);
@@ -2163,7 +2160,7 @@ extern "C" int ka_tf_attention_fwd(const void* qkv, void* out, float* lse, int B
     AttnArgs a{qkv, out, lse, nullptr, nullptr, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool reg_form = dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
-                          !getenv("KA_TF_ATTN_LDS");
+                          !ka_opt_set(KA_OPT_TF_ATTN_LDS);
     if (reg_form) {           // operands in registers, four (board, head) pairs per workgroup
         const int grid = (B * H + 3) / 4;
         if (dh <= 16) hipLaunchKernelGGL(attention_fwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
@@ -2189,7 +2186,7 @@ extern "C" int ka_tf_attention_bwd_o(const void* qkv, const void* out, const voi
                                      int dh, float drop_p, unsigned long long seed, int dtype, void* stream) {
     KA_REQUIRE(qkv && out && dout && lse && dqkv && B > 0 && H > 0 && dh > 0 && dh <= 64, "tf_attention_bwd_o: bad arguments (dh <= 64)");
     if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
-        !getenv("KA_TF_ATTN_LDS") && !getenv("KA_TF_ATTN_ONE")) {
+        !ka_opt_set(KA_OPT_TF_ATTN_LDS) && !ka_opt_set(KA_OPT_TF_ATTN_ONE)) {
         AttnArgs a{qkv, const_cast<void*>(out), const_cast<float*>(lse), dout, dqkv, B, H, dh, H * dh, 1.0f / sqrtf((float)dh), drop_p, seed};
         hipStream_t st = static_cast<hipStream_t>(stream);
         const int grid = (B * H + 3) / 4;
@@ -2211,7 +2208,7 @@ extern "C" int ka_tf_attention_bwd(const void* qkv, const void* dout, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = attn_np(dh) / 16;
     if (dtype == KA_DTYPE_BF16 && dh <= 32 && dh % 8 == 0 && (H * dh) % 8 == 0 && (long long)B * H * kSP * kSP < (1LL << 32) &&
-        !getenv("KA_TF_ATTN_LDS")) {
+        !ka_opt_set(KA_OPT_TF_ATTN_LDS)) {
         const int grid = (B * H + 3) / 4;
         if (dh <= 16) hipLaunchKernelGGL(attention_bwd_reg_kernel<1>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);
         else          hipLaunchKernelGGL(attention_bwd_reg_kernel<2>, dim3(grid), dim3(256), 4 * kAtWaveLds, st, a);

@@ -379,7 +379,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 // the default; KA_WGRAD_TN=64 selects the other.  Both give the same split count.
 static int wgrad_tn(bool fused_input) {
     (void)fused_input;
-    if (const char* e = getenv("KA_WGRAD_TN")) { if (atoi(e) == 64) return 64; }
+    if (ka_opt(KA_OPT_WGRAD_TN, 128) == 64) return 64;
     return 128;
 }
 
@@ -389,7 +389,7 @@ static int wgrad_splits_for(int B, int Cin, int Cout, int target_wgs) {
     const int tc = kTC;
     const int tn = 128;            // the 64-wide variant has twice the tiles and twice the workgroups per CU: same count
     const int tiles = ((Cout + tn - 1) / tn) * ((Cin + tc - 1) / tc);
-    if (const char* e = getenv("KA_WGRAD_WGS")) { const int v = atoi(e); if (v > 0) target_wgs = v; }   // experiments
+    if (const int v = ka_opt(KA_OPT_WGRAD_WGS, 0); v > 0) target_wgs = v;   // experiments
     int s = (target_wgs > 0 ? target_wgs : 256) / tiles;
     if (s < 1) s = 1;
     if (s > B) s = B;

@@ -60,3 +60,22 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture
+def ka_env(monkeypatch):
+    """Set / unset a KA_* switch of the library inside one test: the library caches its switches (ka_options_reload)."""
+    from keisei_amd import _lib
+
+    class _Env:
+        def set(self, name, value):
+            monkeypatch.setenv(name, str(value))
+            _lib.reload_options()
+
+        def unset(self, name):
+            monkeypatch.delenv(name, raising=False)
+            _lib.reload_options()
+
+    yield _Env()
+    monkeypatch.undo()
+    _lib.reload_options()

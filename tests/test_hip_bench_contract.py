@@ -73,21 +73,22 @@ def test_default_line_carries_the_secondary_measurements():
         assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
-def test_bench_gpus_6_rehearsal_over_gloo():
-    """The launcher at the largest rank count this pool lets one card carry (six processes may use a GPU at once; the eight-rank
-    wiring of BASELINE configs[3] is rehearsed on CPU by tests/test_ddp_gloo.py::test_eight_rank_ddp_update_keeps_ranks_in_sync):
-    `bench.py --gpus 6` over gloo on the one GPU, every rank seen, dp6 + SyncBatchNorm, the value the sum of the ranks."""
+def test_bench_gpus_4_rehearsal_over_gloo():
+    """The launcher at the largest rank count this pool lets one card carry beside the test process itself (six processes may
+    have a GPU open at once; the eight-rank wiring of BASELINE configs[3] is rehearsed on CPU by
+    tests/test_ddp_gloo.py::test_eight_rank_ddp_update_keeps_ranks_in_sync): `bench.py --gpus 4` over gloo on the one GPU, every
+    rank seen, dp4 + SyncBatchNorm, the value the sum of the ranks."""
     saved = {k: os.environ.get(k) for k in ("KA_BENCH_BACKEND",)}
     os.environ["KA_BENCH_BACKEND"] = "gloo"
     try:
-        d = run_bench("--gpus", "6", "--workload", "2x32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+        d = run_bench("--gpus", "4", "--workload", "2x32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     finally:
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert d["n_gpus"] == 6 and d["n_ranks_seen"] == 6 and d["backend"] == "gloo"
-    assert d["config"]["parallelism"] == "dp6+syncbn" and d["config"]["global_batch"] == 6 * d["config"]["per_gpu_batch"]
+    assert d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["backend"] == "gloo"
+    assert d["config"]["parallelism"] == "dp4+syncbn" and d["config"]["global_batch"] == 4 * d["config"]["per_gpu_batch"]
     assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
     assert all(v == v for v in d["train_metrics"].values())

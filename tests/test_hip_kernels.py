@@ -770,7 +770,7 @@ def test_grouped_fc_weight_gradients():
 
 
 @pytest.mark.parametrize("B", [512, 515, 4096])
-def test_five_row_tiles_plus_corner_equal_six_row_tiles(monkeypatch, B):
+def test_five_row_tiles_plus_corner_equal_six_row_tiles(ka_env, B):
     """Training batches of the 256-channel tower compute squares 0..79 as five row tiles and square 80 of sixteen boards at a
     time in conv3x3_corner_kernel (default); KA_CONV_MT=6 is the six-row-tile form.  Same products in the same order: every
     output element bit for bit (all four launch kinds, both main kernels); the per-board sums add the corner's term last
@@ -799,12 +799,13 @@ def test_five_row_tiles_plus_corner_equal_six_row_tiles(monkeypatch, B):
         torch.cuda.synchronize()
         return (out, dyo), (bsum, sq, e1, e2)
 
+    ka_env.set("KA_CONV_PC2", "0")                           # (the two-board form sums in another order: its own test below)
     for pc in ("0", "3"):                                    # conv3x3_kernel / the producer-consumer kernel for every form
-        monkeypatch.setenv("KA_CONV_P", pc)
+        ka_env.set("KA_CONV_P", pc)
         for kind in range(4):
-            monkeypatch.setenv("KA_CONV_MT", "6")
+            ka_env.set("KA_CONV_MT", "6")
             ref_o, ref_s = run(kind)
-            monkeypatch.delenv("KA_CONV_MT")
+            ka_env.unset("KA_CONV_MT")
             got_o, got_s = run(kind)
             for a, b in zip(ref_o, got_o):
                 assert bool(((a == b) | (a.isnan() & b.isnan())).all()), (pc, kind)
@@ -817,7 +818,7 @@ def test_five_row_tiles_plus_corner_equal_six_row_tiles(monkeypatch, B):
 
 
 @pytest.mark.parametrize("B", [515, 1024, 4096])
-def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(monkeypatch, B):
+def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(ka_env, B):
     """conv3x3_pc_kernel (staging waves + MFMA waves, the default for the forward forms at training batch sizes): the same
     summation order, weight packs and epilogues as conv3x3_kernel -- all four launch kinds agree bit for bit, including a
     board count that does not divide the 256 persistent workgroups and the headline minibatch (4096: 16 boards per
@@ -847,10 +848,72 @@ def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(monkeypatch, 
         return out, dyo, bsum, sq, e1, e2
 
     same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    ka_env.set("KA_CONV_PC2", "0")                           # (the two-board form sums in another order: its own test below)
     for kind in range(4):
-        monkeypatch.setenv("KA_CONV_P", "0")
+        ka_env.set("KA_CONV_P", "0")
         ref = run(kind)
-        monkeypatch.setenv("KA_CONV_P", "3")                  # every form through the producer / consumer kernel
+        ka_env.set("KA_CONV_P", "3")                  # every form through the producer / consumer kernel
         got = run(kind)
         assert all(same(a.float(), b.float()) for a, b in zip(ref, got)), kind
         assert not ref[0].float().isnan().any()
+
+
+@pytest.mark.parametrize("B", [515, 1024, 4096])
+def test_two_board_conv_equals_the_one_board_forms_up_to_reassociation(ka_env, B):
+    """conv3x3_pc2_kernel (two boards per weight fragment: the default for the forward forms and the plain-epilogue data gradient at
+    training batch sizes) sums the k-steps of an output element in the order (64-channel chunk, tap, k-step) where the other
+    kernels use (128-channel chunk, tap, k-step): the fp32 accumulators agree up to re-association, so the bf16 outputs are
+    equal or -- rarely -- one ulp apart; the written-back dy (the staging transform) is bit-identical; per-board sums agree to
+    1e-5.  All four launch kinds, a board count that leaves the last pair half empty (515), and both forms against an fp32
+    convolution of the same bf16 operands (the yardstick conv3x3_kernel itself is held to)."""
+    C = 256
+    g = torch.Generator(device=DEV).manual_seed(B + 7)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, x2, yprev = (rnd(B, 81, C).to(torch.bfloat16) for _ in range(3))
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, _lib.stream_ptr())
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    gb = rnd(B, C) * 0.1
+    k3 = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+
+    def run(kind):
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        out, dyo = nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16)
+        bsum, sq, e1, e2 = nan(B, C), nan(B, C), nan(B, C), nan(B, C)
+        st = _lib.stream_ptr()
+        if kind == 0: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st)
+        if kind == 1: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, gb, 1, bsum, sq, B, C, C, 1, st)
+        if kind == 2: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st)
+        if kind == 3: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st)
+        torch.cuda.synchronize()
+        return (out, dyo), (bsum, sq, e1, e2)
+
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    for kind in range(4):
+        ka_env.set("KA_CONV_PC2", "0")
+        (o0, d0), s0 = run(kind)
+        ka_env.set("KA_CONV_PC2", "3")                       # every form through the two-board kernel
+        (o1, d1), s1 = run(kind)
+        a, b = o0.float(), o1.float()
+        assert not bool(a.isnan().any()) and not bool(b.isnan().any()), kind
+        diff = (a - b).abs()
+        assert bool((diff <= 2.0 ** -7 * torch.maximum(a.abs(), b.abs()) + 2e-5).all()), kind      # one bf16 ulp (absolute floor near zero)
+        assert float((diff != 0).float().mean()) < 0.01, kind                                       # measured: 1e-4 .. 3e-4 of the elements
+        assert same(d0.float(), d1.float()), kind
+        for u, v in zip(s0, s1):
+            if bool(u.isnan().all()):
+                assert bool(v.isnan().all()), kind
+                continue
+            tol = 2e-3 if kind == 2 else 1e-5                # (masked sums add the one-ulp output differences of up to 81 squares)
+            assert float((u - v).abs().max()) <= tol * float(u.abs().max()) + 1e-6, kind
+    n = 64
+    xf = x[:n].float().reshape(n, 9, 9, C).permute(0, 3, 1, 2)
+    ref32 = torch.nn.functional.conv2d(xf, w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1).reshape(n, 81, C)
+    errs = []
+    for form in ("0", "3"):
+        ka_env.set("KA_CONV_PC2", form)
+        (out, _), _ = run(0)
+        errs.append(float((out[:n].float() - ref32).abs().max()) / float(ref32.abs().max()))
+    assert max(errs) < 6e-3 and abs(errs[0] - errs[1]) < 1e-3, errs       # both at the bf16 output rounding (3.9e-3)

@@ -67,7 +67,7 @@ def test_gemm_tn_bf16(M, N, K, ldb, split):
 
 
 @pytest.mark.parametrize("M,N", [(81, 256), (300, 1024), (4096, 768), (1000, 272), (129, 64)])
-def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
+def test_gemm_nt_k256_form_equals_the_tiled_kernel(ka_env, M, N):
     """K = 256 with a bf16 output takes the activation-stationary kernel (gemm_nt_k256_kernel); KA_TF_K256=0 sends the same call to
     gemm_nt_bf16_kernel.  Same products in the same k order, same epilogue statements: every epilogue form bit for bit
     (bias + ReLU + dropout, bias + dropout + residual, the masked input-gradient form), ragged row counts, partial last chunk."""
@@ -88,7 +88,7 @@ def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
         torch.cuda.synchronize()
         return outs
     new = run()
-    monkeypatch.setenv("KA_TF_K256", "0")
+    ka_env.set("KA_TF_K256", "0")
     old = run()
     for k, (x, y) in enumerate(zip(new, old)):
         assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y), k
@@ -97,7 +97,7 @@ def test_gemm_nt_k256_form_equals_the_tiled_kernel(monkeypatch, M, N):
 
 
 @pytest.mark.parametrize("M,N,K", [(1100, 1300, 1024), (1024, 1027, 1088), (1281, 2048, 1024), (2048, 1536, 4096)])
-def test_gemm_nt_big_tile_form_equals_the_tiled_kernel(monkeypatch, M, N, K):
+def test_gemm_nt_big_tile_form_equals_the_tiled_kernel(ka_env, M, N, K):
     """M, N, K >= 1024 with a bias-only epilogue (the policy layer's three products) take gemm_nt_big_kernel (256 x 256 tiles, an XCD
     walking 4 x 8 super-tiles, operands by LDS-DMA three k-tiles ahead under counted waits); KA_TF_BIG=0 sends the call to gemm_nt_bf16_kernel, whose grid for these shapes is the 8 x 8
     super-tile map, and KA_TF_MAP2D=0 to its one-m-tile-per-XCD map.  Same products in the same k order: bit for bit, fp32
@@ -116,9 +116,9 @@ def test_gemm_nt_big_tile_form_equals_the_tiled_kernel(monkeypatch, M, N, K):
         torch.cuda.synchronize()
         return o32, o16[:, :N].clone()
     big = run()
-    monkeypatch.setenv("KA_TF_BIG", "0")
+    ka_env.set("KA_TF_BIG", "0")
     tiled = run()
-    monkeypatch.setenv("KA_TF_MAP2D", "0")
+    ka_env.set("KA_TF_MAP2D", "0")
     plain = run()
     for x, y, z in zip(big, tiled, plain):
         assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y) and torch.equal(y, z)
@@ -249,7 +249,7 @@ def test_attention_forward_backward(dt, H, dh):
 
 
 @pytest.mark.parametrize("H,dh,p", [(8, 32, 0.1), (4, 8, 0.3), (3, 16, 0.0)])
-def test_register_attention_equals_the_lds_form(monkeypatch, H, dh, p):
+def test_register_attention_equals_the_lds_form(ka_env, H, dh, p):
     """bf16, head dimension <= 32: the register-resident kernels (the default) against the LDS-tile kernels
     (KA_TF_ATTN_LDS=1) on the same seed -- same dropout mask in both score orientations of the backward, same softmax."""
     B, d, seed = 5, H * dh, 987654321
@@ -259,9 +259,9 @@ def test_register_attention_equals_the_lds_form(monkeypatch, H, dh, p):
     res = {}
     for form in ("1", ""):
         if form:
-            monkeypatch.setenv("KA_TF_ATTN_LDS", form)
+            ka_env.set("KA_TF_ATTN_LDS", form)
         else:
-            monkeypatch.delenv("KA_TF_ATTN_LDS")
+            ka_env.unset("KA_TF_ATTN_LDS")
         out = torch.full((B * 81, d), float("nan"), dtype=torch.bfloat16, device=DEV); lse = torch.empty(B, H, 81, device=DEV)
         _lib.call("ka_tf_attention_fwd", qkv, out, lse, B, H, dh, p, seed, _lib.DTYPE_BF16, st())
         dq = torch.full((B * 81, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)

@@ -1,0 +1,69 @@
+"""round 4: conv3x3_pc2_kernel (two boards per weight fragment, KA_CONV_PC2) against conv3x3_pc_kernel -- outputs equal up to fp32
+re-association (bf16 outputs: at most one ulp apart, on few elements), the written-back dy bit-identical, sums to 1e-5; and
+stand-alone times, forms 0 (plain input), 1 (transform input), 3 (two-tensor input)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from keisei_amd import _lib
+DEV = "cuda"; C = 256
+def run_all(B, time_n=0):
+    g = torch.Generator(device=DEV).manual_seed(B)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, x2 = (rnd(B, 81, C).to(torch.bfloat16) for _ in range(2))
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, _lib.stream_ptr())
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    gb = rnd(B, C) * 0.1
+    k3 = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    yprev = rnd(B, 81, C).to(torch.bfloat16)
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+    e1, e2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    def launch(kind, out, dyo, bsum, sq):
+        st = _lib.stream_ptr()
+        if kind == 0: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st)
+        if kind == 1: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, gb, 1, bsum, sq, B, C, C, 1, st)
+        if kind == 3: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, None, None, None, None, None, None, None, B, C, C, 1, st)
+        if kind == 2: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st); sq.copy_(e1 + 0.37 * e2)
+    def run(kind):
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        out, dyo = nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16)
+        bsum, sq = nan(B, C), nan(B, C)
+        launch(kind, out, dyo, bsum, sq)
+        torch.cuda.synchronize()
+        ms = 0.0
+        if time_n:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(time_n): launch(kind, out, dyo, bsum, sq)
+            b.record(); torch.cuda.synchronize(); ms = a.elapsed_time(b) / time_n
+        return (out, dyo, bsum, sq), ms
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    os.environ["KA_CONV_P"] = "2"
+    for rep in range(3 if time_n else 1):
+        for kind in (0, 1, 3, 2):
+            os.environ["KA_CONV_PC2"] = "0"; _lib.reload_options(); ref, t0 = run(kind)
+            os.environ["KA_CONV_PC2"] = "3"; _lib.reload_options(); got, t1 = run(kind)
+            o0, o1 = ref[0].float(), got[0].float()
+            assert not bool(o0.isnan().any()) and not bool(o1.isnan().any()), (B, kind, int(o1.isnan().sum()))
+            d = (o0 - o1).abs()
+            ulp_ok = bool((d <= 2.0 ** -7 * torch.maximum(o0.abs(), o1.abs()) + 2e-5).all())
+            frac = float((d != 0).float().mean())
+            ok_dy = same(ref[1].float(), got[1].float())
+            sums_ok = True
+            for a_, b_ in ((ref[2], got[2]), (ref[3], got[3])):
+                if bool(a_.isnan().all()):
+                    sums_ok &= bool(b_.isnan().all()); continue
+                sums_ok &= float((a_ - b_).abs().max()) <= (2e-3 if kind == 2 else 1e-5) * float(a_.abs().max()) + 1e-6
+            print(f"B={B} kind={kind} one-ulp={ulp_ok} differing={frac:.4f} dy-identical={ok_dy} sums={sums_ok} | pc {t0 * 1e3:.1f} us pc2 {t1 * 1e3:.1f} us", flush=True)
+            assert ulp_ok and frac < 0.03 and ok_dy and sums_ok
+    if B <= 1024:                                            # both against an fp32 convolution of the same bf16 operands
+        xf = x[:64].float().reshape(64, 9, 9, C).permute(0, 3, 1, 2)
+        ref32 = torch.nn.functional.conv2d(xf, w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1).reshape(64, 81, C)
+        for tag, v in (("0", "pc"), ("2", "pc2")):
+            os.environ["KA_CONV_PC2"] = tag; _lib.reload_options()
+            (out, _, _, _), _ = run(0)
+            e = float((out[:64].float() - ref32).abs().max()) / float(ref32.abs().max())
+            print(f"B={B} {v}: max error vs fp32 conv of the bf16 operands {e:.2e} (bf16 output rounding: 3.9e-3)", flush=True)
+            assert e < 6e-3
+run_all(515); run_all(1024); run_all(4096, time_n=30)

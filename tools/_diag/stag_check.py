@@ -37,8 +37,8 @@ def run_all(B, time_n=0):
     os.environ["KA_CONV_P"] = "2"
     for rep in range(3 if time_n else 1):
         for kind in (0, 1, 3):
-            os.environ["KA_CONV_P_STAG"] = "0"; ref, t0 = run(kind)
-            os.environ["KA_CONV_P_STAG"] = "1"; got, t1 = run(kind)
+            os.environ["KA_CONV_P_STAG"] = "0"; _lib.reload_options(); ref, t0 = run(kind)
+            os.environ["KA_CONV_P_STAG"] = "1"; _lib.reload_options(); got, t1 = run(kind)
             ok = all(same(a.float(), b.float()) for a, b in zip(ref, got)) and not bool(ref[0].float().isnan().any())
             print(f"B={B} kind={kind} identical={ok} plain {t0 * 1e3:.1f} us staggered {t1 * 1e3:.1f} us", flush=True)
             assert ok

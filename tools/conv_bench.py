@@ -26,10 +26,10 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 if which == "tune":
-    os.environ["KA_CONV_KC"] = "128"; os.environ["KA_CONV_NTW"] = "4"; os.environ["KA_CONV_WM"] = "2"
+    os.environ["KA_CONV_KC"] = "128"; os.environ["KA_CONV_NTW"] = "4"; os.environ["KA_CONV_WM"] = "2"; _lib.reload_options()
     for rep in range(2):
         for stg, prio in [(0, 0), (1, 0), (2, 0), (3, 0), (5, 0), (0, 1), (2, 1), (3, 1)]:
-            os.environ["KA_CONV_STAGGER"] = str(stg); os.environ["KA_CONV_PRIO"] = str(prio)
+            os.environ["KA_CONV_STAGGER"] = str(stg); os.environ["KA_CONV_PRIO"] = str(prio); _lib.reload_options()
             ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr()), n=20)
             print(f"stagger={stg} prio={prio}: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s", flush=True)
 elif which == "conv":
@@ -38,7 +38,7 @@ elif which == "conv":
     dyo = torch.empty_like(x); e1 = torch.empty(rows, C, device=dev); e2 = torch.empty(rows, C, device=dev)
     mu = 0.1 * torch.randn(C, device=dev); istd = torch.rand(C, device=dev) + 0.5
     for kc, wm in ([(128, 1)] if os.environ.get("CB_QUICK") else [(128, 1), (64, 1), (128, 2)]):
-        os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_WM"] = str(wm)
+        os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_WM"] = str(wm); _lib.reload_options()
         for name, fn in (
             ("plain (conv1 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())),
             ("bn+relu+bias input (conv2 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, code, _lib.stream_ptr())),
@@ -51,7 +51,7 @@ elif which == "conv":
 else:
     dy = torch.randn(B, 81, C, device=dev).to(dt)
     for tn in ("128", "64"):
-        os.environ["KA_WGRAD_TN"] = tn
+        os.environ["KA_WGRAD_TN"] = tn; _lib.reload_options()
         for twg in (0, 192):
             ns = _lib.query("ka_wgrad_splits", B, C, C, twg)
             slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)

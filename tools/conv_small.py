@@ -20,6 +20,6 @@ for B in (64, 128, 256, 512):
     x = torch.randn(B, 81, C, device=dev).to(dt); out = torch.empty_like(x); g = torch.randn(B, C, device=dev)
     bsum = torch.empty(B, C, device=dev)
     for ntw in ("4", "2", "1"):
-        os.environ["KA_CONV_NTW"] = ntw
+        os.environ["KA_CONV_NTW"] = ntw; _lib.reload_options()
         ms = timeit(lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, None, B, C, C, code, _lib.stream_ptr()))
         print(f"B={B} NTW={ntw}: {ms * 1e3:.1f} us", flush=True)

@@ -12,7 +12,7 @@ _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, code, _lib.stream_ptr())
 out = torch.empty_like(x); rows = _lib.query("ka_conv3x3_sqpart_rows", B)
 bsum = torch.empty(B, C, device=dev); sq = torch.empty(rows, C, device=dev)
 for kc, ntw, wm in [(128, 4, 2), (64, 4, 2)]:
-    os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = "1"
+    os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_NTW"] = str(ntw); os.environ["KA_CONV_WM"] = "1"; _lib.reload_options()
     nwg = B
     import time
     t0 = time.time()

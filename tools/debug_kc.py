@@ -6,6 +6,7 @@ import numpy as np, torch
 from conftest import Golden
 from keisei_amd.training.models.se_resnet import SEResNetModel, SEResNetParams
 from keisei_amd.hip.seresnet import SEResNetEngine
+from keisei_amd import _lib
 from oracle import keisei_oracle as orc
 g = Golden("g2_model_mid")
 tag, shape = "s3x256.", orc.NetShape(3, 256)
@@ -18,7 +19,7 @@ obs = g[tag + "obs"].cuda()
 eng = SEResNetEngine(m)
 B = obs.shape[0]
 def run(kc):
-    if kc: os.environ["KA_CONV_KC"] = str(kc)
+    if kc: os.environ["KA_CONV_KC"] = str(kc); _lib.reload_options()
     else: os.environ.pop("KA_CONV_KC", None)
     logits, v, s, sv = eng.forward(obs, True, True, torch.float32)
     grads = eng.backward(sv, g[tag + "cot.policy"].cuda() / B, g[tag + "cot.value"].cuda(), g[tag + "cot.score"].cuda())

@@ -27,6 +27,6 @@ for N in (1024, 768, 256):
     }
     for name, fn in forms.items():
         os.environ.pop("KA_TF_K256", None); t_new = timeit(fn)
-        os.environ["KA_TF_K256"] = "0"; t_old = timeit(fn); os.environ.pop("KA_TF_K256")
+        os.environ["KA_TF_K256"] = "0"; _lib.reload_options(); t_old = timeit(fn); os.environ.pop("KA_TF_K256"); _lib.reload_options()
         byts = (M * K + M * N * (1 + ("residual" in name) + ("masked" in name))) * 2
         print(f"N={N:5d} {name:28s} k256 {t_new:7.1f} us ({byts / t_new / 1e6:5.2f} TB/s, {2.0 * M * N * K / t_new / 1e6:6.0f} TF)   tiled {t_old:7.1f} us", flush=True)

@@ -30,6 +30,7 @@ struct WgradArgs {
     const float* in_bias;    // [B,Cin]
     float* slab;             // [nsplit][9][Cout][Cin]
     int B, Cin, Cout, relu, boards_per_split, ntn, ntiles, nsplit;
+    int stagger;             // waves 4-7 stage the next board AFTER their MFMAs instead of before them (see board_iter)
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             if (b + AHEAD < bend) load_board(b + AHEAD, ys, xs);
         }
     };
+    const bool late = NBUF >= 2 && TN == 128 && a.stagger && __builtin_amdgcn_readfirstlane(wave) >= 4;
     // one board; ys/xs = the register set of board b+1 (compile-time choice: the loop below is unrolled by two)
     auto board_iter = [&](int b, vec16 (&ys)[NY], vec16 (&xs)[NX]) {
         if (NBUF == 1) {
@@ -216,8 +218,14 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             __syncthreads();
             if (b + 1 < bend) load_board(b + 1, ys, xs);      // in flight during the MFMA phase
         } else {
+            // The two waves of a SIMD (w and w + 4) run the same program between the same barriers: in lockstep they both
+            // stage (LDS writes, the input transform, the next loads) and then both queue for the matrix pipe.  With `late`
+            // waves 4-7 multiply first and stage afterwards, so one partner's staging sits beside the other's MFMAs
+            // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Either order is legal inside one barrier interval: the
+            // tile written (board b+1) is read from the next iteration on, the tiles read (boards b, b-1) were complete at
+            // the last barrier.
             const int cur = (b - bbeg) % NBUF;
-            stage_next(b, ys, xs);
+            if (!late) stage_next(b, ys, xs);
             ytile = smem + cur * TILE_BYTES; xtile = ytile + KROWS * SY;
         }
         const bool skip = !c_ok || ntn_valid == 0;    // wave-uniform
@@ -316,7 +324,10 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
             }
         }
         }
-        if (NBUF >= 2) __syncthreads();
+        if (NBUF >= 2) {
+            if (late) stage_next(b, ys, xs);
+            __syncthreads();
+        }
     };
     if (NSETS == 2) {
         for (int b = bbeg; b < bend; b += 2) {           // board b+1 is odd within the range -> set 1, b+2 even -> set 0
@@ -341,6 +352,244 @@ __global__ __launch_bounds__(TN * 4, TN == 64 ? 2 : 1) void wgrad_kernel(WgradAr
                     if (n < a.Cout && c < a.Cin)
                         a.slab[(((size_t)split * 9 + tap) * a.Cout + n) * a.Cin + c] = acc[tap][t][i];
                 }
+    }
+}
+
+// ---------------------------------------------------------------- bf16, 128-wide tile: the lean form
+// wgrad_kernel<bf16_t, 128> issues 2.7 vector instructions per MFMA (profiles/r03_mfma_sq_counters.json): with the matrix
+// instruction holding the SIMD's vector issue for half of its 16 cycles, two such waves per SIMD are issue-bound at a matrix pipe
+// 53 % busy.  Where they come from: every k-step opens with a dependent chain of ~40 of them (flat row -> board / square ->
+// haloed tile index, two divisions by 9) in front of its first LDS read, every board re-derives its staging addresses
+// (~200), and the slab store branches per element.  Same tiles, ring, k-slot permutation, MFMA order and split-K map here
+// (bit-identical slabs), but
+//   * the flat row of a k-step is walked by the SCALAR unit (board offset and first row of the step), a lane adds its row
+//     slot, wraps once, and takes the haloed-tile offset of its square from an 82-entry LDS table;
+//   * the row offsets of step s+1 are computed behind the reads of step s (they do not depend on staged data), so a step
+//     starts with its LDS reads;
+//   * staging addresses are lane constants; the slab leaves without per-element branches when the tile is whole.
+template <bool FUSED>
+__global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
+    constexpr int NTHR = 512, SY = 128 * 2 + 32, SX = kTC * 2 + 32, KROWS = 82, PW = 17, XSQ = 11 * PW;
+    constexpr int YB = KROWS * SY, TILE = YB + XSQ * SX, XTAB = 3 * TILE;      // [3 tiles][dY rows | haloed X squares] | square table
+    constexpr int kTapBias = (PW + 1) * SX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (provably wave-uniform: the k-step walk below stays on the scalar unit)
+    const int r = lane & 15, q = lane >> 4;
+    const int nh = wave & 1, cq = wave >> 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;       // (the XCD-aware tile / split map of wgrad_kernel)
+    const int tile = slot % a.ntiles;
+    const int split = xcd + 8 * (slot / a.ntiles);
+    if (split >= a.nsplit) return;
+    const int tn = tile % a.ntn, tc = tile / a.ntn;
+    const int n0 = tn * 128, c0 = tc * kTC;
+    const int bbeg = split * a.boards_per_split;
+    const int bend = min(a.B, bbeg + a.boards_per_split), nb = bend - bbeg;
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 3 * TILE / 16; i += NTHR) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+    if (tid < KROWS) {                                       // byte offset of square p in the haloed X tile; entry 81: a square of the halo-free
+        const int p = tid < KA_BOARD ? tid : 0;              // board whose dY row is the zero pad row
+        reinterpret_cast<int*>(smem + XTAB)[tid] = YB + ((p / 9 + 1) * PW + (p % 9) + 1) * SX;
+    }
+
+    // ---- staging roles: lane constants
+    const int yj = tid & 15, xj = tid & 7;
+    const bool ycol_ok = n0 + yj * 8 < a.Cout, xcol_ok = c0 + xj * 8 < a.Cin;
+    int ldsY[3], gY[3], ldsX[2], gX[2];
+    bool okY[3], okX[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = (tid >> 4) + 32 * i;
+        okY[i] = row < KA_BOARD && ycol_ok;
+        ldsY[i] = row * SY + yj * 16;
+        gY[i] = (row * a.Cout + n0 + yj * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 64 * i, rr = row < KA_BOARD ? row : 0;
+        okX[i] = row < KA_BOARD && xcol_ok;
+        ldsX[i] = YB + ((rr / 9 + 1) * PW + (rr % 9) + 1) * SX + xj * 16;
+        gX[i] = (row * a.Cin + c0 + xj * 8) * 2;
+    }
+    float sc[FUSED ? 8 : 1], sh[FUSED ? 8 : 1], rb[FUSED ? 8 : 1];
+    const bool has_aff = FUSED && a.in_scale != nullptr;
+    if (has_aff && xcol_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[c0 + xj * 8 + e]; sh[e] = a.in_shift[c0 + xj * 8 + e]; }
+    }
+    bf16x8 ry[3], rx[2];
+    auto load_board = [&](int b) {
+        const char* yb = static_cast<const char*>(a.dy) + (size_t)b * KA_BOARD * a.Cout * 2;
+        const char* xb = static_cast<const char*>(a.x) + (size_t)b * KA_BOARD * a.Cin * 2;
+        if (FUSED && a.in_bias && xcol_ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rb[e] = a.in_bias[(size_t)b * a.Cin + c0 + xj * 8 + e];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ry[i] = okY[i] ? *reinterpret_cast<const bf16x8*>(yb + gY[i]) : bf16x8{};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rx[i] = okX[i] ? *reinterpret_cast<const bf16x8*>(xb + gX[i]) : bf16x8{};
+    };
+    auto store_board = [&](int toff) {                       // into the tile at byte offset toff of the ring
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if ((tid >> 4) + 32 * i < KA_BOARD) *reinterpret_cast<bf16x8*>(smem + toff + ldsY[i]) = ry[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if ((tid >> 3) + 64 * i >= KA_BOARD) continue;
+            bf16x8 v = rx[i];
+            if (FUSED && xcol_ok && (has_aff || a.relu || a.in_bias)) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+                if (has_aff) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+                if (a.in_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += rb[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)f[e];
+            }
+            *reinterpret_cast<bf16x8*>(smem + toff + ldsX[i]) = v;
+        }
+    };
+
+    const int ntn_valid = min(4, max(0, (a.Cout - n0 - nh * 64 + 15) / 16));
+    const bool skip = !(c0 + cq * 16 < a.Cin) || ntn_valid == 0;      // wave-uniform
+    const bool late = a.stagger && __builtin_amdgcn_readfirstlane(wave) >= 4;
+
+    // ---- the flat row walk.  Scalar: kb = first flat row of the next k-step, as (byte offset of its board's tile in the ring,
+    // row inside that board).  Lane: its two rows of the step are kb + rsub and kb + rsub + 16 (the k-slot permutation of
+    // wgrad_kernel), each in this board or -- past row 80 -- at the start of the next one; rows past the range read the zero
+    // pad row 81 of a tile (only the last step has them).
+    const int rsub = 4 * q + (r >> 2), kend = KA_BOARD * nb;
+    int s_toff = 0, s_p = 0, s_k = 0;                         // scalar state of the NEXT step to prepare
+    int yo[2], xo[2];                                         // LDS byte offsets of the prepared step: dY rows, X squares
+    const int coly = (nh * 64 + 4 * (r & 3)) * 2, colx = (cq * 16 + 4 * (r & 3)) * 2;
+    auto prepare = [&]() {                                    // offsets of step s_k / 32, then advance the scalar state by one step
+        const int toff_next = s_toff + TILE == 3 * TILE ? 0 : s_toff + TILE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int p = s_p + rsub + 16 * h;
+            const bool wrap = p >= KA_BOARD;
+            p = wrap ? p - KA_BOARD : p;
+            int tf = wrap ? toff_next : s_toff;
+            if (s_k + 32 > kend) {                            // (uniform: the last step of the range)
+                const bool pad = s_k + rsub + 16 * h >= kend;
+                p = pad ? KA_BOARD : p;
+                tf = pad ? s_toff : tf;
+            }
+            yo[h] = tf + p * SY + coly;
+            xo[h] = tf + *reinterpret_cast<const int*>(smem + XTAB + p * 4) + colx - kTapBias;    // (every tap offset then is a non-negative immediate)
+        }
+        s_k += 32; s_p += 32;
+        if (s_p >= KA_BOARD) { s_p -= KA_BOARD; s_toff = toff_next; }
+    };
+
+    if (nb > 0) load_board(bbeg);
+    // (every barrier of this kernel orders LDS traffic only: __syncthreads() would also drain the vector-memory counter, i.e. wait
+    //  at each board for the prefetch loads of the board after next -- a full HBM round trip for the waves that issue them last)
+    KA_LDS_BARRIER();                                         // zero fill and the square table complete
+    if (nb > 0) {
+        store_board(0);
+        if (nb > 1) load_board(bbeg + 1);
+    }
+    prepare();                                                // step 0 (reads the table: behind the barrier above)
+    KA_LDS_BARRIER();
+    int ks = 0;
+#pragma unroll 1
+    for (int jl = 0; jl < nb; ++jl) {
+        const int nxt = ((jl + 1) % 3) * TILE;
+        auto stage_next = [&]() {
+            if (jl + 1 < nb) {
+                store_board(nxt);
+                if (jl + 2 < nb) load_board(bbeg + jl + 2);
+            }
+        };
+        if (!late) stage_next();
+        const int ks_hi = jl + 1 == nb ? (KA_BOARD * nb + 31) / 32 : (KA_BOARD * (jl + 1)) / 32;
+        if (!skip) {
+#pragma unroll 1
+            for (; ks < ks_hi; ++ks) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + yo[0] + t * 32));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + yo[1] + t * 32));
+                    af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const int x0 = xo[0], x1 = xo[1];
+                auto load_b = [&](int tap) {
+                    const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * SX + kTapBias;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + x0 + toff));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + x1 + toff));
+                    return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                // B fragments (the tap-shifted X rows) are fetched TWO taps ahead: one tap is four MFMAs, 64-128 cycles of the
+                // shared pipe, about one LDS round trip under the load of eight waves
+                bf16x8 bcur = load_b(0), bnx = load_b(1);
+                prepare();                                    // the next step's offsets, behind this step's first reads
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    bf16x8 bn2 = bnx;
+                    if (tap < 7) bn2 = load_b(tap + 2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bcur, acc[tap][t], 0, 0, 0);
+                    bcur = bnx; bnx = bn2;
+                }
+                // issue order: [8 A reads + 4 B reads] then 7 x { 2 B reads two taps ahead, 4 MFMAs of this tap }, 8 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                for (int tap = 0; tap < 7; ++tap) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+        } else {
+            ks = ks_hi;
+        }
+        if (late) stage_next();
+        KA_LDS_BARRIER();
+    }
+
+    // ---- partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
+    if (!skip) {
+        const int c = c0 + cq * 16 + r;
+        float* sl = a.slab + (size_t)split * 9 * a.Cout * a.Cin;
+        const bool whole = n0 + nh * 64 + 64 <= a.Cout && c0 + cq * 16 + 16 <= a.Cin;     // wave-uniform
+        if (whole) {
+            float* base = sl + (size_t)(n0 + nh * 64 + q * 4) * a.Cin + c;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        base[((size_t)tap * a.Cout + t * 16 + i) * a.Cin] = acc[tap][t][i];
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = n0 + (nh * 4 + t) * 16 + q * 4 + i;
+                        if (n < a.Cout && c < a.Cin) sl[((size_t)tap * a.Cout + n) * a.Cin + c] = acc[tap][t][i];
+                    }
+        }
     }
 }
 
@@ -400,6 +649,15 @@ static int wgrad_splits_for(int B, int Cin, int Cout, int target_wgs) {
 // number of partial slabs the caller must provide room for ([splits][9][Cout][Cin] floats)
 extern "C" int ka_wgrad_splits(int B, int Cin, int Cout, int target_wgs) { return wgrad_splits_for(B, Cin, Cout, target_wgs); }
 
+template <bool FUSED>
+static int launch_wgrad_flat(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    const size_t lds = 3 * (82 * (128 * 2 + 32) + 11 * 17 * (kTC * 2 + 32)) + 82 * 4;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&wgrad_flat_kernel<FUSED>), attr_done, "wgrad (lean)")) return rc;
+    hipLaunchKernelGGL((wgrad_flat_kernel<FUSED>), grid, dim3(512), lds, st, a);
+    return ka_check_launch("wgrad (lean)");
+}
+
 template <typename T, int TN, bool FUSED>
 static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int NBUF = (sizeof(T) == 2 && TN == 128) ? 3 : (sizeof(T) == 2 ? 2 : 1);   // as in the kernel
@@ -421,12 +679,14 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     const int nsplit = wgrad_splits_for(B, Cin, Cout, target_wgs);
     const int bps = (B + nsplit - 1) / nsplit;
     const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + kTC - 1) / kTC);
-    WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit};
+    WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit, ka_opt(KA_OPT_WGRAD_STAG, 1)};
     dim3 grid(8 * ntiles * ((nsplit + 7) / 8));
     int rc;
     const bool fused = in_scale || in_bias || relu;
 #define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
-    if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
+    if (dtype == KA_DTYPE_BF16 && tn == 128 && ka_opt(KA_OPT_WGRAD_LEAN, 1) != 0)
+        rc = fused ? launch_wgrad_flat<true>(a, grid, st) : launch_wgrad_flat<false>(a, grid, st);
+    else if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
     else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);
 #undef KA_WG
     else { ka_set_error("wgrad: unknown dtype %d", dtype); return KA_ERR_ARG; }

@@ -30,6 +30,7 @@
 // Reference semantics replaced: nn.Conv2d(C, C, 3, padding=1, bias=False) at
 // keisei/training/models/se_resnet.py:50,52,110 and its autograd backward.
 #include <stdlib.h>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -1023,8 +1024,113 @@ constexpr int kP2Img = kImgSquares1 * kP2Stride;                        // 28 96
 constexpr int kP2Lds = 4 * kP2Img;                                      // [buffer][board]
 constexpr int kP2Base = (kPW + 1) * kP2Stride;                          // the most negative tap offset, folded into the row base
 
-template <bool TWO, bool MASKED, int NPW>
+// ---- border tiles (SKIP).  A tap that steps off the board multiplies the zero halo: 104 of the 729 (square, tap) products of a
+// board.  With squares taken in index order no row tile is all halo for any tap; with two boards per unit the rows can be dealt so
+// that three tiles are: TOP = squares (0, 0..7) of both boards (zero for the three taps with dy = -1), RIGHT = (0..7, 8) (dx = +1),
+// LEFT = (1..8, 0) (dx = -1).  The fourth border tile holds (8, 1..7) and one interior square (4, 4) of each board -- square
+// (8, 8) stays with conv3x3_corner_kernel -- and the 48 other interior squares of a board are its three interior tiles.  Nine of
+// the 90 (tile, tap) pairs of a k-step pair are skipped: 10 % of the MFMAs and of the activation-fragment reads.
+// Bank conflicts: a 16-lane ds_read_b128 group is conflict-free when the squares of lanes r in {0..3, 12..15} have distinct LDS
+// indices mod 8, and those of lanes 4..11 too (a square is 160 B = 10 sixteen-byte slots, and 17 = 1 mod 8 squares per padded
+// row): index mod 8 = (x + y + 2) mod 8, so each half tile takes squares with eight different (x + y) mod 8 -- an edge is
+// such a set, (8, 1..7) + (4, 4) is, and the 48 interior squares split into six (every residue occurs exactly six times).
+// Lanes {0..3, 12..15} of a border tile belong to the pair's first board, lanes 4..11 to the second.
+struct P2Perm { unsigned char sq[10][16]; };
+constexpr P2Perm make_p2perm() {
+    P2Perm P{};
+    const int E[8] = {0, 1, 2, 3, 12, 13, 14, 15}, O[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+    for (int k = 0; k < 8; ++k) {
+        const int edge[4] = {k, 9 * k + 8, 9 * (k + 1), k < 7 ? 72 + (k + 1) : 40};
+        for (int t = 0; t < 4; ++t) { P.sq[t][E[k]] = (unsigned char)edge[t]; P.sq[t][O[k]] = (unsigned char)edge[t]; }
+    }
+    int byres[8][6] = {}, cnt[8] = {};
+    for (int y = 1; y <= 7; ++y)
+        for (int x = 1; x <= 7; ++x) {
+            if (y == 4 && x == 4) continue;
+            const int rho = (x + y) & 7;
+            byres[rho][cnt[rho]++] = 9 * y + x;
+        }
+    for (int b = 0; b < 2; ++b)
+        for (int tt = 0; tt < 3; ++tt)
+            for (int k = 0; k < 8; ++k) {
+                P.sq[4 + 3 * b + tt][E[k]] = (unsigned char)byres[k][2 * tt];
+                P.sq[4 + 3 * b + tt][O[k]] = (unsigned char)byres[k][2 * tt + 1];
+            }
+    return P;
+}
+__device__ const P2Perm kP2Perm = make_p2perm();
+__host__ __device__ constexpr bool p2_skip(int t, int tap) {
+    return (t == 0 && tap / 3 == 0) || (t == 1 && tap % 3 == 2) || (t == 2 && tap % 3 == 0);
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) -- every index a constant expression, so
+// arrays indexed by table entries stay in registers
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// the (k-step, tile) pairs of a unit in issue order, without the skipped ones
+struct P2Seq { unsigned char s[180], t[180]; int n; };
+constexpr P2Seq make_p2seq(bool skip) {
+    P2Seq Q{};
+    Q.n = 0;
+    for (int s = 0; s < 18; ++s)
+        for (int t = 0; t < 10; ++t)
+            if (!(skip && p2_skip(t, s >> 1))) { Q.s[Q.n] = (unsigned char)s; Q.t[Q.n] = (unsigned char)t; ++Q.n; }
+    return Q;
+}
+
+// register-only epilogue of a pair in the border-tile layout: lane (r, q) holds, for tile t, square sqv[t] of board
+// b0 + (t < 4 ? lanes 4..11 : t >= 7) and for channel tile j the 4 channels cb[j]..+3 (both tiles: 8 consecutive channels)
+__device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x4 (&acc)[10][2], const unsigned (&sqp)[3], int b0, bool has_b1,
+                                                   int nt0, int r, int q) {       // sqp: the lane's ten squares, one byte each
+    const int cb[2] = {chan_of(nt0, 4 * q, 16), chan_of(nt0 + 1, 4 * q, 16)};
+    const bool isO = r >= 4 && r < 12;
+    if (a.bsum || a.sqpart) {
+        // one (channel tile, board) at a time: eight running sums live beside the eighty accumulators
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    if (t >= 4 && (t >= 7) != (b == 1)) continue;            // an interior tile of the other board
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[t][j][i];
+                        if (t < 4) v = (isO == (b == 1)) ? v : 0.f;          // border tile: this lane's row belongs to one board
+                        s[i] += v; ss[i] += v * v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s[i] = row_sum16(s[i]); ss[i] = row_sum16(ss[i]); }
+                if (r == 0 && (b == 0 || has_b1)) {
+                    if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + (size_t)(b0 + b) * 256 + cb[j]) = f32x4{s[0], s[1], s[2], s[3]};
+                    if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + (size_t)(b0 + b) * 256 + cb[j]) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+                }
+                __builtin_amdgcn_sched_barrier(0);           // (one block of sums at a time: interleaved they spill the MFMA loop)
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const int bd = t < 4 ? (isO ? 1 : 0) : (t < 7 ? 0 : 1);
+        if (bd && !has_b1) continue;
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = (__bf16)acc[t][0][i]; o[4 + i] = (__bf16)acc[t][1][i]; }
+        const int sq = (int)((sqp[t >> 2] >> (8 * (t & 3))) & 0xffu);
+        // (one uniform base per pair and a 32-bit lane offset)
+        *reinterpret_cast<bf16x8*>(static_cast<char*>(a.out) + (size_t)b0 * (KA_BOARD * 512) + ((bd * KA_BOARD + sq) * 256 + cb[0]) * 2) = o;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool TWO, bool MASKED, int NPW, bool SKIP = false>
 __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a) {
+    static_assert(!(SKIP && MASKED), "the border-tile layout is built for the register-only epilogue");
     constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
     constexpr int kHalf = KA_BOARD * 8, kPieces = 2 * kHalf;            // 16-byte pieces of a unit: 2 boards x 81 squares x 8
     constexpr int KP = (kPieces + NP - 1) / NP;
@@ -1038,54 +1144,82 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
     __syncthreads();
 
     if (wave >= 8) {
-        // ---------------- staging waves: piece i = pt + NP k of a unit = board i / 648, square (i % 648) / 8, 16-byte piece i % 8
-        const int pt = tid - 512, pc = pt & 7;
+        // ---------------- staging waves: piece i = pt + NP k of a unit = row i / 8 of the pair's 2 x 81 rows, 16-byte piece i % 8.
+        // Everything a piece needs besides its data is a lane constant (its LDS slot, its byte offset inside the pair) or scalar
+        // (the pair, the chunk): the tensors are addressed through buffer descriptors sized to the batch, so the rows of a missing
+        // second board read as zeros and are never written, without a branch.  The vector instructions of these waves share the
+        // SIMDs with the MFMA waves one for one.
+        const int pt = tid - 512, pc = pt & 7, swave = __builtin_amdgcn_readfirstlane(wave) - 8;
         const bool has_aff = a.in_scale != nullptr;
+        const unsigned nbytes = (unsigned)a.B * (KA_BOARD * 512);
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.in2 : a.in), 0, nbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(TWO && a.in_out ? a.in_out : const_cast<void*>(a.in), 0,
+                                                                              TWO && a.in_out ? nbytes : 0u, 0x00020000);
+        const int voff0 = (pt >> 3) * 512 + pc * 16;
+        int ldso[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int row = min((pt + NP * k) >> 3, 2 * KA_BOARD - 1), j = row >= KA_BOARD ? 1 : 0;
+            ldso[k] = j * kP2Img + lds_square(0, row - j * KA_BOARD) * kP2Stride + pc * 16;
+        }
+        // round k of this wave has pieces at all?  (NP = 256: the sixth round is sixteen lanes of the first staging wave)
+        auto live = [&](int k) { return (swave * 64 + NP * k) < kPieces; };
         auto stage = [&](int u) {
-            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), ch0 = (u & 3) * 64 + pc * 8;
+            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3, ch0 = c4 * 64 + pc * 8;
+            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * 512) + c4 * 128);
             char* img = smem + (u & 1) * (2 * kP2Img);
             bf16x8 pv[KP], pw[TWO ? KP : 1];
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = pt + NP * k, j = i >= kHalf ? 1 : 0, sq = (i - j * kHalf) >> 3;
-                pv[k] = bf16x8{};
-                if (TWO) pw[TWO ? k : 0] = bf16x8{};
-                if (i < kPieces && b0 + j < a.B) {
-                    const size_t off = (((size_t)(b0 + j) * KA_BOARD + sq) * 256 + ch0) * 2;
-                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in) + off));
-                    if (TWO) pw[TWO ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(static_cast<const char*>(a.in2) + off));
-                }
+                if (!live(k)) continue;
+                const int vo = pt + NP * k < kPieces ? voff0 + k * (NP / 8) * 512 : (int)0x7fffffff;      // (past the pair: out of range)
+                pv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, vo, soff, 2));
+                if (TWO) pw[TWO ? k : 0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in2, vo, soff, 2));
             }
             float sc[8], sh[8], k3[8], pb[2][8];
+            {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f}, o = {1.f, 1.f, 1.f, 1.f};
+                const f32x4 s0 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + ch0) : o, s1 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + ch0 + 4) : o;
+                const f32x4 t0 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0) : z, t1 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4) : z;
+                const f32x4 u0 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0) : z, u1 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4) : z;
+                const bool bias = !TWO && a.in_bias;
+                const f32x4 p00 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * 256 + ch0) : z;
+                const f32x4 p01 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * 256 + ch0 + 4) : z;
+                const bool b1 = bias && b0 + 1 < a.B;
+                const f32x4 p10 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * 256 + ch0) : z;
+                const f32x4 p11 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * 256 + ch0 + 4) : z;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sc[e] = has_aff ? a.in_scale[ch0 + e] : 1.f; sh[e] = has_aff ? a.in_shift[ch0 + e] : 0.f;
-                k3[e] = TWO ? a.in_k3[ch0 + e] : 0.f;
-                pb[0][e] = (!TWO && a.in_bias) ? a.in_bias[(size_t)b0 * 256 + ch0 + e] : 0.f;
-                pb[1][e] = (!TWO && a.in_bias && b0 + 1 < a.B) ? a.in_bias[(size_t)(b0 + 1) * 256 + ch0 + e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = t0[e]; sh[4 + e] = t1[e]; k3[e] = u0[e]; k3[4 + e] = u1[e];
+                    pb[0][e] = p00[e]; pb[0][4 + e] = p01[e]; pb[1][e] = p10[e]; pb[1][4 + e] = p11[e];
+                }
             }
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = pt + NP * k, j = i >= kHalf ? 1 : 0, sq = (i - j * kHalf) >> 3;
+                if (!live(k)) continue;
+                const int i = pt + NP * k;
                 if (i >= kPieces) continue;
+                const int j = i >= kHalf ? 1 : 0;
                 bf16x8 v = pv[k];
-                if (b0 + j < a.B) {
-                    if (TWO) {
+                if (TWO) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
-                        if (a.in_out) *reinterpret_cast<bf16x8*>(static_cast<char*>(a.in_out) + (((size_t)(b0 + j) * KA_BOARD + sq) * 256 + ch0) * 2) = v;
-                    } else if (has_aff || a.relu || a.in_bias) {
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                    if (b0 + j >= a.B) v = bf16x8{};          // (a missing board stays all zeros: the transform of zeros is the shift)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r_out,
+                                                           voff0 + k * (NP / 8) * 512, soff, 0);
+                } else if (has_aff || a.relu || a.in_bias) {
 #pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            f32x2 f = {(float)v[e], (float)v[e + 1]};
-                            if (has_aff) f = __builtin_elementwise_fma(f, f32x2{sc[e], sc[e + 1]}, f32x2{sh[e], sh[e + 1]});
-                            if (a.relu) f = __builtin_elementwise_max(f, f32x2{0.f, 0.f});
-                            if (a.in_bias) f += j ? f32x2{pb[1][e], pb[1][e + 1]} : f32x2{pb[0][e], pb[0][e + 1]};
-                            v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
-                        }
+                    for (int e = 0; e < 8; e += 2) {
+                        f32x2 f = {(float)v[e], (float)v[e + 1]};
+                        if (has_aff) f = __builtin_elementwise_fma(f, f32x2{sc[e], sc[e + 1]}, f32x2{sh[e], sh[e + 1]});
+                        if (a.relu) f = __builtin_elementwise_max(f, f32x2{0.f, 0.f});
+                        if (a.in_bias) f += j ? f32x2{pb[1][e], pb[1][e + 1]} : f32x2{pb[0][e], pb[0][e + 1]};
+                        v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
                     }
+                    if (b0 + j >= a.B) v = bf16x8{};
                 }
-                *reinterpret_cast<bf16x8*>(img + j * kP2Img + lds_square(0, sq) * kP2Stride + pc * 16) = v;
+                *reinterpret_cast<bf16x8*>(img + ldso[k]) = v;
             }
         };
         stage(0);
@@ -1099,18 +1233,39 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
 
     // ---------------- MFMA waves: ten row tiles (five per board) x two channel tiles; the weight ring (three slots, two k-steps
     // ahead: a k-step is 20 MFMAs per wave) runs on across the units
-    const char* wl = static_cast<const char*>(a.wpack) + (size_t)(wave * 2) * 1024 + lane * 16;
-    // weight fragments of step s of 64-channel chunk c4: s = tap * 2 + k-step; steps 18, 19 are the first two of the next unit's chunk
+    // weight fragments of step s of 64-channel chunk c4: s = tap * 2 + k-step; steps 18, 19 are the first two of the next unit's chunk.
+    // The address is a scalar base (the wave's channel tiles, the step) plus the lane's 32-bit offset: the step walk stays on the
+    // scalar unit -- as 64-bit lane pointers it cost two vector adds and two registers per load pair
+    // (buffer loads: descriptor of the whole pack in four scalar registers, the lane's 32-bit offset, the step as the scalar offset)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpack), 0, 9 * 8 * 16 * 1024, 0x00020000);
+    const int wlane = __builtin_amdgcn_readfirstlane(wave) * 2048 + lane * 16;
     auto wfrag = [&](int c4, int s, bf16x8 (&f)[2]) {
         if (s >= 18) { s -= 18; c4 = (c4 + 1) & 3; }
         const int tap = s >> 1, ks = c4 * 2 + (s & 1);
-        const char* p = wl + (size_t)((tap * 8 + ks) * 16) * 1024;
-        f[0] = *reinterpret_cast<const bf16x8*>(p);
-        f[1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+        // (readfirstlane: the unit counter is wave-uniform, but it lives under the wave-role branch and is not provably so)
+        const int so = __builtin_amdgcn_readfirstlane(((tap * 8 + ks) * 16) * 1024);
+        f[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        f[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
     };
-    int rowbase[5];                                          // LDS byte offset of (row tile t, lane) in image [0][0], minus kP2Base
+    // LDS byte offset of (row tile t, lane) in the first buffer, minus kP2Base.  Index order: tile t of board 0 (board 1: + kP2Img);
+    // SKIP: ten entries, the lane's (board, square) of every tile of the border-tile layout
+    constexpr int NRB = SKIP ? 10 : 5;
+    int rowbase[NRB];
+    unsigned sqp[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 5; ++t) rowbase[t] = lds_square(0, t * 16 + r) * kP2Stride + q * 16 - kP2Base;
+    for (int t = 0; t < NRB; ++t) {
+        if (SKIP) {
+            const int sq = kP2Perm.sq[t][r];
+            sqp[t >> 2] |= (unsigned)sq << (8 * (t & 3));
+            const int bd = t < 4 ? ((r >= 4 && r < 12) ? 1 : 0) : (t < 7 ? 0 : 1);
+            rowbase[t] = bd * kP2Img + lds_square(0, sq) * kP2Stride + q * 16 - kP2Base;
+        } else {
+            rowbase[t] = lds_square(0, t * 16 + r) * kP2Stride + q * 16 - kP2Base;
+        }
+    }
+    // (rowbase follows the buffer: + 2 kP2Img for the odd units, toggled in place at every unit's end -- a second set of ten offsets
+    //  for the other buffer does not fit the register budget)
+    auto frag_off = [&](int t) { return SKIP ? rowbase[SKIP ? t : 0] : rowbase[t % 5] + (t / 5) * kP2Img; };
     bf16x8 wr[3][2];
     wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
     f32x4 acc[10][2];
@@ -1121,40 +1276,36 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
 #pragma unroll
             for (int t = 0; t < 10; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
-        const char* img = smem + (u & 1) * (2 * kP2Img);
-        // activation fragments: each refilled right after the two MFMAs that read it.  NF = 10 registers sets: with the same tile's
-        // fragment of the next k-step (a whole k-step of MFMAs ahead); NF = 5 (the masked form, whose epilogue needs the
-        // registers): with the fragment five tiles further on (the other board's tile of this k-step, then this board's tile
-        // of the next k-step) -- 1-2 % slower
-        constexpr int NF = MASKED ? 5 : 10;
-        bf16x8 fa[NF];
-#pragma unroll
-        for (int t = 0; t < NF; ++t)
-            fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t % 5] + (t / 5) * kP2Img + kP2Base + (-kPW - 1) * kP2Stride);
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-            // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
-            if (!(MASKED && c4 == 3 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int tap = s >> 1, sn = s + 1, tapn = sn >> 1;
-            const int toff = kP2Base + ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kP2Stride + (s & 1) * 64;
-            const int toffn = kP2Base + ((tapn / 3 - 1) * kPW + (tapn % 3 - 1)) * kP2Stride + (sn & 1) * 64;
-#pragma unroll
-            for (int t = 0; t < 10; ++t) {
-                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][0], fa[t % NF], acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][1], fa[t % NF], acc[t][1], 0, 0, 0);
-                if (NF == 10) {
-                    if (s < 17) fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t % 5] + (t / 5) * kP2Img + toffn);
-                } else if (t < 5) fa[t] = *reinterpret_cast<const bf16x8*>(img + rowbase[t] + kP2Img + toff);
-                else if (s < 17) fa[t - 5] = *reinterpret_cast<const bf16x8*>(img + rowbase[t - 5] + toffn);
+        const char* img = smem;
+        // activation fragments: a ring of R, walked over the unit's (k-step, tile) pairs in issue order; each slot is refilled right
+        // after the two MFMAs that read it with the fragment R pairs further on (R = 8: 16 MFMAs of this wave, 256-512 cycles
+        // of the shared pipe, ahead of its use)
+        constexpr P2Seq Q = make_p2seq(SKIP);
+        constexpr int R = MASKED ? 5 : 8;
+        bf16x8 fa[R];
+        auto frag_at = [&](auto n_) {
+            constexpr int n = decltype(n_)::value, s = Q.s[n], t = Q.t[n], tap = s >> 1;
+            constexpr int toff = kP2Base + ((tap / 3 - 1) * kPW + (tap % 3 - 1)) * kP2Stride + (s & 1) * 64;
+            fa[n % R] = *reinterpret_cast<const bf16x8*>(img + frag_off(t) + toff);
+        };
+        static_for<R>(frag_at);
+        static_for<Q.n>([&](auto n_) {
+            constexpr int n = decltype(n_)::value, s = Q.s[n], t = Q.t[n];
+            if constexpr (n == 0 || Q.s[n > 0 ? n - 1 : 0] != s) {
+                __builtin_amdgcn_sched_barrier(0);
+                // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
+                if (!(MASKED && c4 == 3 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int t = 0; t < 10; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if ((NF == 5 && t < 5) || s < 17) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][0], fa[n % R], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][1], fa[n % R], acc[t][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if constexpr (n + R < Q.n) {
+                frag_at(std::integral_constant<int, n + R>{});
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        __builtin_amdgcn_sched_barrier(0);
         if (c4 == 3) {
             const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg);
             if constexpr (MASKED) {
@@ -1166,27 +1317,37 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 if (b0 + 1 < a.B) conv_epilogue_masked_lean(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, rl, ql);
                 wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
+            } else if constexpr (SKIP) {
+                conv_epilogue_pair(a, acc, sqp, b0, b0 + 1 < a.B, wave * 2, r, q);
             } else {
                 conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[0]), b0, wave * 2, 16, r, q);
                 if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, 16, r, q);
             }
         }
+#pragma unroll
+        for (int t = 0; t < NRB; ++t) rowbase[t] += (u & 1) ? -2 * kP2Img : 2 * kP2Img;
         KA_LDS_BARRIER();                                    // these images may be overwritten, the next pair is complete
     }
 }
 
-template <bool TWO, bool MASKED, int NPW>
+template <bool TWO, bool MASKED, int NPW, bool SKIP = false>
 static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW>), done, what)) return rc;
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP>), done, what)) return rc;
     const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
-    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
     return ka_check_launch(what);
 }
 static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
+    // border tiles (KA_CONV_PC2_SKIP=1): rows dealt so that three tiles are all halo for three taps each -- 10 % fewer MFMAs and
+    // fragment reads, bit-compatible, and SLOWER as built (316 vs 288 us forward, profiles/NOTES_r04.md): ten lane offsets instead of
+    // five push the MFMA loop past its 168 registers, and the spill reloads sit on the weight ring's vector-memory counter
+    const bool skip = ka_opt(KA_OPT_CONV_PC2_SKIP, 0) != 0;
     if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4>(a, st, "conv3x3 (two boards per unit, two-tensor, masked)");
-    if (a.in2) return launch_conv_pc2_form<true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
-    return launch_conv_pc2_form<false, false, 4>(a, st, "conv3x3 (two boards per unit)");
+    if (a.in2) return skip ? launch_conv_pc2_form<true, false, 4, true>(a, st, "conv3x3 (two boards per unit, two-tensor, border tiles)")
+                           : launch_conv_pc2_form<true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
+    return skip ? launch_conv_pc2_form<false, false, 4, true>(a, st, "conv3x3 (two boards per unit, border tiles)")
+                : launch_conv_pc2_form<false, false, 4>(a, st, "conv3x3 (two boards per unit)");
 }
 
 // ---------------------------------------------------------------- square 80 of sixteen boards as one row tile

@@ -20,7 +20,9 @@ SOURCES = ["capi.hip", "conv3x3.hip", "wgrad.hip", "board.hip", "gemm.hip", "los
 ARCH = "gfx950"
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unknown-pragmas", "-Wno-sometimes-uninitialized"]
-PER_FILE = {"gae.hip": ["-ffp-contract=off"]}
+# conv3x3.hip: no SLP vectorisation -- v_pk_fma_f32 / v_pk_add_f32 beside MFMAs cost more than the scalar pair they replace
+# (MI355X_MICROARCH.md, filler prices) and the packed temporaries spilled the masked epilogue (profiles/NOTES_r04.md)
+PER_FILE = {"gae.hip": ["-ffp-contract=off"], "conv3x3.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -951,60 +951,85 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
 #undef KA_PC_FORM
 }
 
-// The masked data-gradient epilogue for a wave that has few registers to spare (conv3x3_pc2_kernel: the other board's accumulators
-// and the weight ring stay live): da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums, conv_epilogue's masked branch term
-// for term, but one MFMA tile -- four channels per lane, 8-byte pieces -- at a time, the y pieces of the second tile requested
-// before the first is worked on.  Five row tiles: every row is a square of the board.
-__device__ __forceinline__ void conv_epilogue_masked_lean(const ConvArgs& a, f32x4 (&acc)[5][2], int bb, int nt0, int r, int q) {
+// The masked data-gradient epilogue of a PAIR (conv3x3_pc2_kernel, index-order tiles: 0..4 the first board, 5..9 the second):
+// da = dh * [bn(y) > 0] and the BatchNorm-backward partial sums (conv_epilogue's masked branch), one MFMA tile -- four channels per
+// lane, 8-byte pieces -- at a time because the other board's accumulators stay live, and organised around what it costs: exposed
+// latency and vector instructions that run while the matrix pipe idles (measured: the instruction count is what matters; the
+// file is built with -fno-slp-vectorize, packed fp32 arithmetic beside MFMAs and its register pressure cost this epilogue 13 %):
+//   * four stages (board, channel tile), the y pieces of stage s+1 requested before stage s is worked on, the first ones before
+//     the per-board sums; the per-channel coefficients of a channel tile are loaded once for both boards;
+//   * the second sum is taken as sum(d * y) and centred afterwards: S2 = (sum(d y) - mean * sum(d)) * invstd -- one fma per
+//     element where (y - mean) * invstd * d took three instructions (equal up to fp32 rounding);
+//   * bf16 <-> fp32 by shifts and masks on the packed words: the masked value d is the bf16 it is stored as.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32x4 (&acc)[10][2], int b0, bool has_b1, int nt0, int r, int q) {
     const int cb[2] = {chan_of(nt0, 4 * q, 16), chan_of(nt0 + 1, 4 * q, 16)};
-    // one uniform base per tensor and 32-bit lane offsets (Cout = 256: a row is 512 B, a row tile 8 KB)
-    const char* yb = static_cast<const char*>(a.ep_y) + (size_t)bb * (KA_BOARD * 512);
-    char* ob = static_cast<char*>(a.out) + (size_t)bb * (KA_BOARD * 512);
+    const char* yb = static_cast<const char*>(a.ep_y) + (size_t)b0 * (KA_BOARD * 512);
+    char* ob = static_cast<char*>(a.out) + (size_t)b0 * (KA_BOARD * 512);
     const int lo[2] = {r * 512 + cb[0] * 2, r * 512 + cb[1] * 2};
-    bf16x4 yv[2][5];
+    u32x2 yA[5], yB[5];
+    auto yload = [&](int b, int j, u32x2 (&y)[5]) {
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt) yv[0][mt] = *reinterpret_cast<const bf16x4*>(yb + lo[0] + mt * 8192);
+        for (int mt = 0; mt < 5; ++mt) y[mt] = *reinterpret_cast<const u32x2*>(yb + b * (KA_BOARD * 512) + lo[j] + mt * 8192);
+    };
+    f32x4 cA[2], cB[2];                                      // scale, shift of the channel tile's four channels
+    yload(0, 0, yA);
+    cA[0] = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[0]); cA[1] = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[0]);
     if (a.bsum) {                                            // per-board sums of the raw accumulators (conv_epilogue, same order)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float s0[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int mt = 0; mt < 5; ++mt)
+            for (int j = 0; j < 2; ++j) {
+                float s0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s0[i] += acc[mt][j][i];
+                for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
-            if (r == 0) *reinterpret_cast<f32x4*>(a.bsum + bb * 256 + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
-        }
+                    for (int i = 0; i < 4; ++i) s0[i] += acc[5 * b + mt][j][i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
+                if (r == 0 && (b == 0 || has_b1)) *reinterpret_cast<f32x4*>(a.bsum + (b0 + b) * 256 + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+            }
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j == 0) {
-#pragma unroll
-            for (int mt = 0; mt < 5; ++mt) yv[1][mt] = *reinterpret_cast<const bf16x4*>(yb + lo[1] + mt * 8192);
-        }
-        const f32x4 esc = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]), esh = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
+    yload(0, 1, yB);
+    cB[0] = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[1]); cB[1] = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[1]);
+    auto process = [&](int b, int j, const u32x2 (&y)[5], const f32x4 (&c)[2]) {
         const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]), eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
         float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
-            bf16x4 o;
+            u32x2 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float y = (float)yv[j][mt][e];
-                const __bf16 db = (__bf16)acc[mt][j][e];
-                const float d = (y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
-                t1[e] += d; t2[e] += d * ((y - emu[e]) * eis[e]);
-                o[e] = (__bf16)d;
+            for (int h = 0; h < 2; ++h) {
+                const unsigned yw = y[mt][h];
+                const float y0 = __uint_as_float(yw << 16), y1 = __uint_as_float(yw & 0xffff0000u);
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 dbp = {(__bf16)acc[5 * b + mt][j][2 * h], (__bf16)acc[5 * b + mt][j][2 * h + 1]};
+                const unsigned dw = __builtin_bit_cast(unsigned, dbp);
+                const float d0 = (y0 * c[0][2 * h] + c[1][2 * h] > 0.f) ? __uint_as_float(dw << 16) : 0.f;
+                const float d1 = (y1 * c[0][2 * h + 1] + c[1][2 * h + 1] > 0.f) ? __uint_as_float(dw & 0xffff0000u) : 0.f;
+                t1[2 * h] += d0; t1[2 * h + 1] += d1;
+                t2[2 * h] = fmaf(d0, y0, t2[2 * h]); t2[2 * h + 1] = fmaf(d1, y1, t2[2 * h + 1]);
+                o[h] = (__float_as_uint(d0) >> 16) | __float_as_uint(d1);
             }
-            *reinterpret_cast<bf16x4*>(ob + lo[j] + mt * 8192) = o;
+            *reinterpret_cast<u32x2*>(ob + b * (KA_BOARD * 512) + lo[j] + mt * 8192) = o;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { t1[e] = row_sum16(t1[e]); t2[e] = row_sum16(t2[e]); }
-        if (r == 0) {
-            *reinterpret_cast<f32x4*>(a.ep_s1 + bb * 256 + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
-            *reinterpret_cast<f32x4*>(a.ep_s2 + bb * 256 + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+        for (int e = 0; e < 4; ++e) {
+            t1[e] = row_sum16(t1[e]);
+            t2[e] = (row_sum16(t2[e]) - emu[e] * t1[e]) * eis[e];
         }
+        if (r == 0) {
+            *reinterpret_cast<f32x4*>(a.ep_s1 + (b0 + b) * 256 + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+            *reinterpret_cast<f32x4*>(a.ep_s2 + (b0 + b) * 256 + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+        }
+    };
+    process(0, 0, yA, cA);
+    if (has_b1) yload(1, 0, yA);
+    process(0, 1, yB, cB);
+    if (has_b1) {
+        yload(1, 1, yB);
+        process(1, 0, yA, cA);
+        process(1, 1, yB, cB);
     }
 }
 
@@ -1128,7 +1153,11 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x4 (&ac
     }
 }
 
-template <bool TWO, bool MASKED, int NPW, bool SKIP = false>
+// STAG: MFMA waves 4-7 (the SIMD partners of waves 0-3) run half a unit (nine k-steps) behind waves 0-3, two barriers per unit, so
+// that one partner's epilogue and unit-start latencies sit beside the other's MFMAs; an image pair is then read for three
+// half-unit slots, and the staging waves load the next unit in one slot and write it in the following one (the schedule of
+// conv3x3_pc_kernel<..., STAG>, which did not pay there: that kernel waits for its weight stream, this one for the matrix pipe).
+template <bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
 __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a) {
     static_assert(!(SKIP && MASKED), "the border-tile layout is built for the register-only epilogue");
     constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
@@ -1165,11 +1194,10 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
         }
         // round k of this wave has pieces at all?  (NP = 256: the sixth round is sixteen lanes of the first staging wave)
         auto live = [&](int k) { return (swave * 64 + NP * k) < kPieces; };
-        auto stage = [&](int u) {
-            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3, ch0 = c4 * 64 + pc * 8;
+        bf16x8 pv[KP], pw[TWO ? KP : 1];
+        auto stage_load = [&](int u) {
+            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3;
             const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * 512) + c4 * 128);
-            char* img = smem + (u & 1) * (2 * kP2Img);
-            bf16x8 pv[KP], pw[TWO ? KP : 1];
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 if (!live(k)) continue;
@@ -1177,6 +1205,11 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 pv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, vo, soff, 2));
                 if (TWO) pw[TWO ? k : 0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in2, vo, soff, 2));
             }
+        };
+        auto stage_write = [&](int u) {
+            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3, ch0 = c4 * 64 + pc * 8;
+            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * 512) + c4 * 128);
+            char* img = smem + (u & 1) * (2 * kP2Img);
             float sc[8], sh[8], k3[8], pb[2][8];
             {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f}, o = {1.f, 1.f, 1.f, 1.f};
@@ -1222,8 +1255,21 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 *reinterpret_cast<bf16x8*>(img + ldso[k]) = v;
             }
         };
+        auto stage = [&](int u) { stage_load(u); stage_write(u); };
         stage(0);
         KA_LDS_BARRIER();
+        if constexpr (STAG) {
+            // slot 2v-2: the loads of unit v; slot 2v-1: its LDS writes (waves 4-7 read that buffer's previous unit until then)
+            for (int v = 1; v < nunits; ++v) {
+                stage_load(v);
+                KA_LDS_BARRIER();
+                stage_write(v);
+                KA_LDS_BARRIER();
+            }
+            KA_LDS_BARRIER();
+            KA_LDS_BARRIER();
+            return;
+        }
         for (int u = 0; u < nunits; ++u) {
             if (u + 1 < nunits) stage(u + 1);
             KA_LDS_BARRIER();
@@ -1270,6 +1316,8 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
     wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
     f32x4 acc[10][2];
     KA_LDS_BARRIER();                                        // unit 0 is staged
+    const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (late) KA_LDS_BARRIER();                              // waves 4-7 start one slot (half a unit) behind waves 0-3
     for (int u = 0; u < nunits; ++u) {
         const int c4 = u & 3;
         if (!c4) {
@@ -1293,6 +1341,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
             constexpr int n = decltype(n_)::value, s = Q.s[n], t = Q.t[n];
             if constexpr (n == 0 || Q.s[n > 0 ? n - 1 : 0] != s) {
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STAG && s == 9) KA_LDS_BARRIER();      // slot boundary: nine k-steps before it, nine and the epilogue behind it
                 // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
                 if (!(MASKED && c4 == 3 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1313,9 +1362,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 //  above the MFMA loop they spill it)
                 int rl = r, ql = q;
                 asm volatile("" : "+v"(rl), "+v"(ql));
-                conv_epilogue_masked_lean(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[0]), b0, wave * 2, rl, ql);
-                __builtin_amdgcn_sched_barrier(0);
-                if (b0 + 1 < a.B) conv_epilogue_masked_lean(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, rl, ql);
+                conv_epilogue_masked_pair(a, acc, b0, b0 + 1 < a.B, wave * 2, rl, ql);
                 wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
             } else if constexpr (SKIP) {
                 conv_epilogue_pair(a, acc, sqp, b0, b0 + 1 < a.B, wave * 2, r, q);
@@ -1326,16 +1373,16 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
         }
 #pragma unroll
         for (int t = 0; t < NRB; ++t) rowbase[t] += (u & 1) ? -2 * kP2Img : 2 * kP2Img;
-        KA_LDS_BARRIER();                                    // these images may be overwritten, the next pair is complete
+        if (!(late && u == nunits - 1)) KA_LDS_BARRIER();    // these images may be overwritten, the next pair is complete
     }
 }
 
-template <bool TWO, bool MASKED, int NPW, bool SKIP = false>
+template <bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
 static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP>), done, what)) return rc;
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP, STAG>), done, what)) return rc;
     const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
-    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
     return ka_check_launch(what);
 }
 static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
@@ -1343,6 +1390,12 @@ static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
     // fragment reads, bit-compatible, and SLOWER as built (316 vs 288 us forward, profiles/NOTES_r04.md): ten lane offsets instead of
     // five push the MFMA loop past its 168 registers, and the spill reloads sit on the weight ring's vector-memory counter
     const bool skip = ka_opt(KA_OPT_CONV_PC2_SKIP, 0) != 0;
+    const bool stag = ka_opt(KA_OPT_CONV_PC2_STAG, 0) != 0;    // waves 4-7 half a unit behind waves 0-3
+    if (stag && !skip) {
+        if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, masked, staggered)");
+        if (a.in2) return launch_conv_pc2_form<true, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, staggered)");
+        return launch_conv_pc2_form<false, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, staggered)");
+    }
     if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4>(a, st, "conv3x3 (two boards per unit, two-tensor, masked)");
     if (a.in2) return skip ? launch_conv_pc2_form<true, false, 4, true>(a, st, "conv3x3 (two boards per unit, two-tensor, border tiles)")
                            : launch_conv_pc2_form<true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
@@ -1520,8 +1573,8 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         // time in conv3x3_corner_kernel (KA_CONV_MT=6: all 81 squares as six row tiles, the round-1/2 form)
         want5 = a.Cin == 256 && a.Cout == 256 && a.B >= 512 && ka_opt(KA_OPT_CONV_MT, 5) != 6;
         // two boards per weight fragment (conv3x3_pc2_kernel).  KA_CONV_PC2: 0 off; 1 the forward forms; 2 (default) + the two-tensor
-        // data gradient with the register-only epilogue; 3 + the masked epilogue (measured slower than conv3x3_kernel's in the step)
-        const int p2 = ka_opt(KA_OPT_CONV_PC2, 2);
+        // data gradient with the register-only epilogue; 3 (default) + the masked epilogue
+        const int p2 = ka_opt(KA_OPT_CONV_PC2, 3);
         if (p2 != 0 && want5 && pv != 0 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3)) {
             a.mt5 = 1;
             if (int rc = launch_conv_pc2(a, st)) return rc;

@@ -962,15 +962,19 @@ static int launch_conv_pc(ConvArgs a, hipStream_t st) {
 //     element where (y - mean) * invstd * d took three instructions (equal up to fp32 rounding);
 //   * bf16 <-> fp32 by shifts and masks on the packed words: the masked value d is the bf16 it is stored as.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32x4 (&acc)[10][2], int b0, bool has_b1, int nt0, int r, int q) {
-    const int cb[2] = {chan_of(nt0, 4 * q, 16), chan_of(nt0 + 1, 4 * q, 16)};
-    const char* yb = static_cast<const char*>(a.ep_y) + (size_t)b0 * (KA_BOARD * 512);
-    char* ob = static_cast<char*>(a.out) + (size_t)b0 * (KA_BOARD * 512);
-    const int lo[2] = {r * 512 + cb[0] * 2, r * 512 + cb[1] * 2};
-    u32x2 yA[5], yB[5];
-    auto yload = [&](int b, int j, u32x2 (&y)[5]) {
+template <int C, int MT>
+__device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32x4 (&acc)[2 * MT][2], int b0, bool has_b1, int nt0, int r, int q) {
+    constexpr int ROWB = C * 2, NT = C / 16;                  // bytes per square, 16-channel tiles
+    const int cb[2] = {chan_of(nt0, 4 * q, NT), chan_of(nt0 + 1, 4 * q, NT)};
+    const char* yb = static_cast<const char*>(a.ep_y) + (size_t)b0 * (KA_BOARD * ROWB);
+    char* ob = static_cast<char*>(a.out) + (size_t)b0 * (KA_BOARD * ROWB);
+    const int lo[2] = {r * ROWB + cb[0] * 2, r * ROWB + cb[1] * 2};
+    // (MT = 6: the sixth row tile holds square 80 in lane row 0, fifteen padding rows behind it)
+    auto live = [&](int mt) { return MT == 5 || mt < 5 || r == 0; };
+    u32x2 yA[MT], yB[MT];
+    auto yload = [&](int b, int j, u32x2 (&y)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) y[mt] = *reinterpret_cast<const u32x2*>(yb + b * (KA_BOARD * 512) + lo[j] + mt * 8192);
+        for (int mt = 0; mt < MT; ++mt) y[mt] = live(mt) ? *reinterpret_cast<const u32x2*>(yb + b * (KA_BOARD * ROWB) + lo[j] + mt * 16 * ROWB) : u32x2{0u, 0u};
     };
     f32x4 cA[2], cB[2];                                      // scale, shift of the channel tile's four channels
     yload(0, 0, yA);
@@ -982,36 +986,36 @@ __device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32
             for (int j = 0; j < 2; ++j) {
                 float s0[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) s0[i] += acc[5 * b + mt][j][i];
+                    for (int i = 0; i < 4; ++i) s0[i] += live(mt) ? acc[MT * b + mt][j][i] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s0[i] = row_sum16(s0[i]);
-                if (r == 0 && (b == 0 || has_b1)) *reinterpret_cast<f32x4*>(a.bsum + (b0 + b) * 256 + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+                if (r == 0 && (b == 0 || has_b1)) *reinterpret_cast<f32x4*>(a.bsum + (b0 + b) * C + cb[j]) = f32x4{s0[0], s0[1], s0[2], s0[3]};
             }
     }
     yload(0, 1, yB);
     cB[0] = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[1]); cB[1] = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[1]);
-    auto process = [&](int b, int j, const u32x2 (&y)[5], const f32x4 (&c)[2]) {
+    auto process = [&](int b, int j, const u32x2 (&y)[MT], const f32x4 (&c)[2]) {
         const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]), eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
         float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             u32x2 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const unsigned yw = y[mt][h];
                 const float y0 = __uint_as_float(yw << 16), y1 = __uint_as_float(yw & 0xffff0000u);
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                const bf16x2 dbp = {(__bf16)acc[5 * b + mt][j][2 * h], (__bf16)acc[5 * b + mt][j][2 * h + 1]};
+                const bf16x2 dbp = {(__bf16)acc[MT * b + mt][j][2 * h], (__bf16)acc[MT * b + mt][j][2 * h + 1]};
                 const unsigned dw = __builtin_bit_cast(unsigned, dbp);
-                const float d0 = (y0 * c[0][2 * h] + c[1][2 * h] > 0.f) ? __uint_as_float(dw << 16) : 0.f;
-                const float d1 = (y1 * c[0][2 * h + 1] + c[1][2 * h + 1] > 0.f) ? __uint_as_float(dw & 0xffff0000u) : 0.f;
+                const float d0 = (live(mt) && y0 * c[0][2 * h] + c[1][2 * h] > 0.f) ? __uint_as_float(dw << 16) : 0.f;
+                const float d1 = (live(mt) && y1 * c[0][2 * h + 1] + c[1][2 * h + 1] > 0.f) ? __uint_as_float(dw & 0xffff0000u) : 0.f;
                 t1[2 * h] += d0; t1[2 * h + 1] += d1;
                 t2[2 * h] = fmaf(d0, y0, t2[2 * h]); t2[2 * h + 1] = fmaf(d1, y1, t2[2 * h + 1]);
                 o[h] = (__float_as_uint(d0) >> 16) | __float_as_uint(d1);
             }
-            *reinterpret_cast<u32x2*>(ob + b * (KA_BOARD * 512) + lo[j] + mt * 8192) = o;
+            if (live(mt)) *reinterpret_cast<u32x2*>(ob + b * (KA_BOARD * ROWB) + lo[j] + mt * 16 * ROWB) = o;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1019,8 +1023,8 @@ __device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32
             t2[e] = (row_sum16(t2[e]) - emu[e] * t1[e]) * eis[e];
         }
         if (r == 0) {
-            *reinterpret_cast<f32x4*>(a.ep_s1 + (b0 + b) * 256 + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
-            *reinterpret_cast<f32x4*>(a.ep_s2 + (b0 + b) * 256 + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
+            *reinterpret_cast<f32x4*>(a.ep_s1 + (b0 + b) * C + cb[j]) = f32x4{t1[0], t1[1], t1[2], t1[3]};
+            *reinterpret_cast<f32x4*>(a.ep_s2 + (b0 + b) * C + cb[j]) = f32x4{t2[0], t2[1], t2[2], t2[3]};
         }
     };
     process(0, 0, yA, cA);
@@ -1096,12 +1100,12 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // the (k-step, tile) pairs of a unit in issue order, without the skipped ones
-struct P2Seq { unsigned char s[180], t[180]; int n; };
-constexpr P2Seq make_p2seq(bool skip) {
+struct P2Seq { unsigned char s[216], t[216]; int n; };
+constexpr P2Seq make_p2seq(bool skip, int ntiles) {
     P2Seq Q{};
     Q.n = 0;
     for (int s = 0; s < 18; ++s)
-        for (int t = 0; t < 10; ++t)
+        for (int t = 0; t < ntiles; ++t)
             if (!(skip && p2_skip(t, s >> 1))) { Q.s[Q.n] = (unsigned char)s; Q.t[Q.n] = (unsigned char)t; ++Q.n; }
     return Q;
 }
@@ -1157,10 +1161,14 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x4 (&ac
 // that one partner's epilogue and unit-start latencies sit beside the other's MFMAs; an image pair is then read for three
 // half-unit slots, and the staging waves load the next unit in one slot and write it in the following one (the schedule of
 // conv3x3_pc_kernel<..., STAG>, which did not pay there: that kernel waits for its weight stream, this one for the matrix pipe).
-template <bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
-__global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a) {
+// C = 256, MT = 5: eight MFMA waves, four 64-channel chunks, squares 0..79 (square 80: conv3x3_corner_kernel).  C = 128, MT = 6: four
+// MFMA waves (one per SIMD, 256 registers each beside the staging waves), two chunks, all 81 squares as six row tiles per board.
+template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
+__global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvArgs a) {
     static_assert(!(SKIP && MASKED), "the border-tile layout is built for the register-only epilogue");
-    constexpr int NT_ = 512 + 64 * NPW, NP = 64 * NPW;
+    static_assert((C == 256 && MT == 5) || (C == 128 && MT == 6 && !SKIP), "shapes this kernel is built for");
+    constexpr int NMW = C / 32, NCH = C / 64, NTILE = C / 16, KSG = C / 32, ROWB = C * 2, NTL = 2 * MT;
+    constexpr int NT_ = (NMW + NPW) * 64, NP = 64 * NPW;
     constexpr int kHalf = KA_BOARD * 8, kPieces = 2 * kHalf;            // 16-byte pieces of a unit: 2 boards x 81 squares x 8
     constexpr int KP = (kPieces + NP - 1) / NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1168,24 +1176,24 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
     const int nwg = gridDim.x, npairs_all = (a.B + 1) >> 1;
     if ((int)blockIdx.x >= npairs_all) return;
     for (int i = tid; i < kP2Lds / 16; i += NT_) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
-    const int npairs = (npairs_all - (int)blockIdx.x + nwg - 1) / nwg, nunits = 4 * npairs;
+    const int npairs = (npairs_all - (int)blockIdx.x + nwg - 1) / nwg, nunits = NCH * npairs;
     if (!MASKED) a.ep_y = nullptr;                           // (compile-time: conv_epilogue's masked branch is not compiled in)
     __syncthreads();
 
-    if (wave >= 8) {
+    if (wave >= NMW) {
         // ---------------- staging waves: piece i = pt + NP k of a unit = row i / 8 of the pair's 2 x 81 rows, 16-byte piece i % 8.
         // Everything a piece needs besides its data is a lane constant (its LDS slot, its byte offset inside the pair) or scalar
         // (the pair, the chunk): the tensors are addressed through buffer descriptors sized to the batch, so the rows of a missing
         // second board read as zeros and are never written, without a branch.  The vector instructions of these waves share the
         // SIMDs with the MFMA waves one for one.
-        const int pt = tid - 512, pc = pt & 7, swave = __builtin_amdgcn_readfirstlane(wave) - 8;
+        const int pt = tid - NMW * 64, pc = pt & 7, swave = __builtin_amdgcn_readfirstlane(wave) - NMW;
         const bool has_aff = a.in_scale != nullptr;
-        const unsigned nbytes = (unsigned)a.B * (KA_BOARD * 512);
+        const unsigned nbytes = (unsigned)a.B * (KA_BOARD * ROWB);
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, nbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.in2 : a.in), 0, nbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(TWO && a.in_out ? a.in_out : const_cast<void*>(a.in), 0,
                                                                               TWO && a.in_out ? nbytes : 0u, 0x00020000);
-        const int voff0 = (pt >> 3) * 512 + pc * 16;
+        const int voff0 = (pt >> 3) * ROWB + pc * 16;
         int ldso[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
@@ -1196,19 +1204,19 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
         auto live = [&](int k) { return (swave * 64 + NP * k) < kPieces; };
         bf16x8 pv[KP], pw[TWO ? KP : 1];
         auto stage_load = [&](int u) {
-            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3;
-            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * 512) + c4 * 128);
+            const int b0 = 2 * ((int)blockIdx.x + (u / NCH) * nwg), c4 = u % NCH;
+            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * ROWB) + c4 * 128);
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 if (!live(k)) continue;
-                const int vo = pt + NP * k < kPieces ? voff0 + k * (NP / 8) * 512 : (int)0x7fffffff;      // (past the pair: out of range)
+                const int vo = pt + NP * k < kPieces ? voff0 + k * (NP / 8) * ROWB : (int)0x7fffffff;      // (past the pair: out of range)
                 pv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, vo, soff, 2));
                 if (TWO) pw[TWO ? k : 0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in2, vo, soff, 2));
             }
         };
         auto stage_write = [&](int u) {
-            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg), c4 = u & 3, ch0 = c4 * 64 + pc * 8;
-            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * 512) + c4 * 128);
+            const int b0 = 2 * ((int)blockIdx.x + (u / NCH) * nwg), c4 = u % NCH, ch0 = c4 * 64 + pc * 8;
+            const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * ROWB) + c4 * 128);
             char* img = smem + (u & 1) * (2 * kP2Img);
             float sc[8], sh[8], k3[8], pb[2][8];
             {
@@ -1217,11 +1225,11 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 const f32x4 t0 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0) : z, t1 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4) : z;
                 const f32x4 u0 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0) : z, u1 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4) : z;
                 const bool bias = !TWO && a.in_bias;
-                const f32x4 p00 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * 256 + ch0) : z;
-                const f32x4 p01 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * 256 + ch0 + 4) : z;
+                const f32x4 p00 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * C + ch0) : z;
+                const f32x4 p01 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * C + ch0 + 4) : z;
                 const bool b1 = bias && b0 + 1 < a.B;
-                const f32x4 p10 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * 256 + ch0) : z;
-                const f32x4 p11 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * 256 + ch0 + 4) : z;
+                const f32x4 p10 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * C + ch0) : z;
+                const f32x4 p11 = b1 ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)(b0 + 1) * C + ch0 + 4) : z;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = t0[e]; sh[4 + e] = t1[e]; k3[e] = u0[e]; k3[4 + e] = u1[e];
@@ -1240,7 +1248,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                     for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
                     if (b0 + j >= a.B) v = bf16x8{};          // (a missing board stays all zeros: the transform of zeros is the shift)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r_out,
-                                                           voff0 + k * (NP / 8) * 512, soff, 0);
+                                                           voff0 + k * (NP / 8) * ROWB, soff, 0);
                 } else if (has_aff || a.relu || a.in_bias) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -1283,19 +1291,19 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
     // The address is a scalar base (the wave's channel tiles, the step) plus the lane's 32-bit offset: the step walk stays on the
     // scalar unit -- as 64-bit lane pointers it cost two vector adds and two registers per load pair
     // (buffer loads: descriptor of the whole pack in four scalar registers, the lane's 32-bit offset, the step as the scalar offset)
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpack), 0, 9 * 8 * 16 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpack), 0, 9 * KSG * NTILE * 1024, 0x00020000);
     const int wlane = __builtin_amdgcn_readfirstlane(wave) * 2048 + lane * 16;
     auto wfrag = [&](int c4, int s, bf16x8 (&f)[2]) {
-        if (s >= 18) { s -= 18; c4 = (c4 + 1) & 3; }
+        if (s >= 18) { s -= 18; c4 = (c4 + 1) % NCH; }
         const int tap = s >> 1, ks = c4 * 2 + (s & 1);
         // (readfirstlane: the unit counter is wave-uniform, but it lives under the wave-role branch and is not provably so)
-        const int so = __builtin_amdgcn_readfirstlane(((tap * 8 + ks) * 16) * 1024);
+        const int so = __builtin_amdgcn_readfirstlane(((tap * KSG + ks) * NTILE) * 1024);
         f[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
         f[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
     };
     // LDS byte offset of (row tile t, lane) in the first buffer, minus kP2Base.  Index order: tile t of board 0 (board 1: + kP2Img);
     // SKIP: ten entries, the lane's (board, square) of every tile of the border-tile layout
-    constexpr int NRB = SKIP ? 10 : 5;
+    constexpr int NRB = SKIP ? 10 : MT;
     int rowbase[NRB];
     unsigned sqp[3] = {0u, 0u, 0u};
 #pragma unroll
@@ -1306,29 +1314,32 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
             const int bd = t < 4 ? ((r >= 4 && r < 12) ? 1 : 0) : (t < 7 ? 0 : 1);
             rowbase[t] = bd * kP2Img + lds_square(0, sq) * kP2Stride + q * 16 - kP2Base;
         } else {
-            rowbase[t] = lds_square(0, t * 16 + r) * kP2Stride + q * 16 - kP2Base;
+            // (MT = 6: the padding rows 81..95 read square index kPW + 13 of the image: it and its eight neighbours are padding
+            //  squares to the right of the board, never written, all zero)
+            const int p = t * 16 + r;
+            rowbase[t] = (p < KA_BOARD ? lds_square(0, p) : kPW + 13) * kP2Stride + q * 16 - kP2Base;
         }
     }
     // (rowbase follows the buffer: + 2 kP2Img for the odd units, toggled in place at every unit's end -- a second set of ten offsets
     //  for the other buffer does not fit the register budget)
-    auto frag_off = [&](int t) { return SKIP ? rowbase[SKIP ? t : 0] : rowbase[t % 5] + (t / 5) * kP2Img; };
+    auto frag_off = [&](int t) { return SKIP ? rowbase[SKIP ? t : 0] : rowbase[t % MT] + (t / MT) * kP2Img; };
     bf16x8 wr[3][2];
     wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
-    f32x4 acc[10][2];
+    f32x4 acc[NTL][2];
     KA_LDS_BARRIER();                                        // unit 0 is staged
-    const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NMW / 2;
     if (late) KA_LDS_BARRIER();                              // waves 4-7 start one slot (half a unit) behind waves 0-3
     for (int u = 0; u < nunits; ++u) {
-        const int c4 = u & 3;
+        const int c4 = u % NCH;
         if (!c4) {
 #pragma unroll
-            for (int t = 0; t < 10; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < NTL; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
         const char* img = smem;
         // activation fragments: a ring of R, walked over the unit's (k-step, tile) pairs in issue order; each slot is refilled right
         // after the two MFMAs that read it with the fragment R pairs further on (R = 8: 16 MFMAs of this wave, 256-512 cycles
         // of the shared pipe, ahead of its use)
-        constexpr P2Seq Q = make_p2seq(SKIP);
+        constexpr P2Seq Q = make_p2seq(SKIP, NTL);
         constexpr int R = MASKED ? 5 : 8;
         bf16x8 fa[R];
         auto frag_at = [&](auto n_) {
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (STAG && s == 9) KA_LDS_BARRIER();      // slot boundary: nine k-steps before it, nine and the epilogue behind it
                 // (the masked epilogue needs the ring's registers: before it the next unit's first fragments are not requested)
-                if (!(MASKED && c4 == 3 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
+                if (!(MASKED && c4 == NCH - 1 && s >= 16)) wfrag(c4, s + 2, wr[(s + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s % 3][0], fa[n % R], acc[t][0], 0, 0, 0);
@@ -1355,20 +1366,20 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
             }
         });
         __builtin_amdgcn_sched_barrier(0);
-        if (c4 == 3) {
-            const int b0 = 2 * ((int)blockIdx.x + (u >> 2) * nwg);
+        if (c4 == NCH - 1) {
+            const int b0 = 2 * ((int)blockIdx.x + (u / NCH) * nwg);
             if constexpr (MASKED) {
                 // (opaque copies of the lane coordinates: the epilogue's addresses are invariant across the pairs, and hoisted
                 //  above the MFMA loop they spill it)
                 int rl = r, ql = q;
                 asm volatile("" : "+v"(rl), "+v"(ql));
-                conv_epilogue_masked_pair(a, acc, b0, b0 + 1 < a.B, wave * 2, rl, ql);
+                conv_epilogue_masked_pair<C, MT>(a, acc, b0, b0 + 1 < a.B, wave * 2, rl, ql);
                 wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
             } else if constexpr (SKIP) {
-                conv_epilogue_pair(a, acc, sqp, b0, b0 + 1 < a.B, wave * 2, r, q);
+                if constexpr (SKIP) conv_epilogue_pair(a, acc, sqp, b0, b0 + 1 < a.B, wave * 2, r, q);
             } else {
-                conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[0]), b0, wave * 2, 16, r, q);
-                if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, 5>(a, reinterpret_cast<f32x4 (&)[5][2]>(acc[5]), b0 + 1, wave * 2, 16, r, q);
+                conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[0]), b0, wave * 2, NTILE, r, q);
+                if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[MT]), b0 + 1, wave * 2, NTILE, r, q);
             }
         }
 #pragma unroll
@@ -1377,30 +1388,35 @@ __global__ __launch_bounds__(512 + 64 * NPW) void conv3x3_pc2_kernel(ConvArgs a)
     }
 }
 
-template <bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
+template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
 static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP, STAG>), done, what)) return rc;
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), done, what)) return rc;
     const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
-    hipLaunchKernelGGL((conv3x3_pc2_kernel<TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3(512 + 64 * NPW), kP2Lds, st, a);
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3((C / 32 + NPW) * 64), kP2Lds, st, a);
     return ka_check_launch(what);
 }
 static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
+    if (a.Cin == 128) {                                        // the 128-channel tower (BASELINE configs[1], keisei-ddp.toml): all 81 squares, no corner launch
+        if (a.in2 && a.ep_y) return launch_conv_pc2_form<128, 6, true, true, 4>(a, st, "conv3x3 (two boards per unit, 128 channels, two-tensor, masked)");
+        if (a.in2) return launch_conv_pc2_form<128, 6, true, false, 4>(a, st, "conv3x3 (two boards per unit, 128 channels, two-tensor)");
+        return launch_conv_pc2_form<128, 6, false, false, 4>(a, st, "conv3x3 (two boards per unit, 128 channels)");
+    }
     // border tiles (KA_CONV_PC2_SKIP=1): rows dealt so that three tiles are all halo for three taps each -- 10 % fewer MFMAs and
     // fragment reads, bit-compatible, and SLOWER as built (316 vs 288 us forward, profiles/NOTES_r04.md): ten lane offsets instead of
     // five push the MFMA loop past its 168 registers, and the spill reloads sit on the weight ring's vector-memory counter
     const bool skip = ka_opt(KA_OPT_CONV_PC2_SKIP, 0) != 0;
-    const bool stag = ka_opt(KA_OPT_CONV_PC2_STAG, 0) != 0;    // waves 4-7 half a unit behind waves 0-3
+    const bool stag = ka_opt(KA_OPT_CONV_PC2_STAG, 0) != 0;    // waves 4-7 half a unit behind waves 0-3 (measured level)
     if (stag && !skip) {
-        if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, masked, staggered)");
-        if (a.in2) return launch_conv_pc2_form<true, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, staggered)");
-        return launch_conv_pc2_form<false, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, staggered)");
+        if (a.in2 && a.ep_y) return launch_conv_pc2_form<256, 5, true, true, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, masked, staggered)");
+        if (a.in2) return launch_conv_pc2_form<256, 5, true, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, two-tensor, staggered)");
+        return launch_conv_pc2_form<256, 5, false, false, 4, false, true>(a, st, "conv3x3 (two boards per unit, staggered)");
     }
-    if (a.in2 && a.ep_y) return launch_conv_pc2_form<true, true, 4>(a, st, "conv3x3 (two boards per unit, two-tensor, masked)");
-    if (a.in2) return skip ? launch_conv_pc2_form<true, false, 4, true>(a, st, "conv3x3 (two boards per unit, two-tensor, border tiles)")
-                           : launch_conv_pc2_form<true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
-    return skip ? launch_conv_pc2_form<false, false, 4, true>(a, st, "conv3x3 (two boards per unit, border tiles)")
-                : launch_conv_pc2_form<false, false, 4>(a, st, "conv3x3 (two boards per unit)");
+    if (a.in2 && a.ep_y) return launch_conv_pc2_form<256, 5, true, true, 4>(a, st, "conv3x3 (two boards per unit, two-tensor, masked)");
+    if (a.in2) return skip ? launch_conv_pc2_form<256, 5, true, false, 4, true>(a, st, "conv3x3 (two boards per unit, two-tensor, border tiles)")
+                           : launch_conv_pc2_form<256, 5, true, false, 4>(a, st, "conv3x3 (two boards per unit, two-tensor)");
+    return skip ? launch_conv_pc2_form<256, 5, false, false, 4, true>(a, st, "conv3x3 (two boards per unit, border tiles)")
+                : launch_conv_pc2_form<256, 5, false, false, 4>(a, st, "conv3x3 (two boards per unit)");
 }
 
 // ---------------------------------------------------------------- square 80 of sixteen boards as one row tile
@@ -1580,6 +1596,8 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
             if (int rc = launch_conv_pc2(a, st)) return rc;
             return launch_conv_corner(a, st);
         }
+        if (p2 != 0 && pv != 0 && a.Cin == 128 && a.Cout == 128 && a.B >= 512 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3))
+            return launch_conv_pc2(a, st);
         if (pv != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 &&
             (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) {
             a.mt5 = want5;

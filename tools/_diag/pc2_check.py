@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from keisei_amd import _lib
-DEV = "cuda"; C = 256
+DEV = "cuda"; C = int(os.environ.get("CB_C", 256))
 def run_all(B, time_n=0):
     g = torch.Generator(device=DEV).manual_seed(B)
     rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
@@ -66,4 +66,4 @@ def run_all(B, time_n=0):
             e = float((out[:64].float() - ref32).abs().max()) / float(ref32.abs().max())
             print(f"B={B} {v}: max error vs fp32 conv of the bf16 operands {e:.2e} (bf16 output rounding: 3.9e-3)", flush=True)
             assert e < 6e-3
-run_all(515); run_all(1024); run_all(4096, time_n=30)
+run_all(515); run_all(1024); run_all(int(os.environ.get("CB_B", 4096)), time_n=30)

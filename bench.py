@@ -625,11 +625,10 @@ def main() -> None:
             if pmc is not None and args.workload == "40x256" and args.dtype == "bf16" and B == 4096:
                 prof = json.loads(pmc.read_text())
                 if prof.get("kernel_source_sha16") == kernel_source_id():
-                    # the tower's launches: conv3x3_kernel<bf16_t, 4, 1> (data gradients) and conv3x3_pc_kernel (forward) --
-                    # launch-weighted mean, like the timed launches
-                    recs = [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t")]
-                    recs = [max(recs, key=lambda v: v["launches"])] if recs else []
-                    recs += [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_pc_kernel")]
+                    # the tower's launches (conv3x3_pc2_kernel: forward and data gradients; older forms when a switch selects them)
+                    # -- launch-weighted mean, like the timed launches
+                    recs = [v for k, v in prof["kernels"].items() if k.startswith("conv3x3_kernel<bf16_t") and v["launches"] >= 10]
+                    recs += [v for k, v in prof["kernels"].items() if k.startswith(("conv3x3_pc_kernel", "conv3x3_pc2_kernel"))]
                     n = sum(v["launches"] for v in recs)
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in recs) / n) if n else None
                     corner = prof["kernels"].get("conv3x3_corner_kernel")      # (square 80: one launch behind every tower launch)
@@ -641,9 +640,9 @@ def main() -> None:
                                     f"{kernel_source_id()}: not reported")
             ev_ms_step = 1e3 * res["events_elapsed"] / res["events_steps"]
             two_streams = os.environ.get("KA_WGRAD_OVERLAP", "0") != "0"
-            roof = {"bound": "mfma", "kernel": "conv3x3_pc_kernel / conv3x3_kernel + conv3x3_corner_kernel (implicit-GEMM 3x3 conv: squares 0..79 as five row "
-                                               "tiles, square 80 of 16 boards as one more; forward launches on the producer-consumer form, "
-                                               "data-gradient launches on conv3x3_kernel with fused BatchNorm-backward passes" + (", concurrent with wgrad on a 2nd stream)" if two_streams else ")"),
+            roof = {"bound": "mfma", "kernel": "conv3x3_pc2_kernel + conv3x3_corner_kernel (implicit-GEMM 3x3 conv, two boards per weight fragment: squares "
+                                               "0..79 of both as ten row tiles, square 80 of 16 boards as one more; forward and data-gradient launches, the "
+                                               "latter with the fused BatchNorm-backward input and -- behind conv2 -- the masked epilogue" + (", concurrent with wgrad on a 2nd stream)" if two_streams else ")"),
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_note, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),
                     "flop_per_launch": conv_flop,

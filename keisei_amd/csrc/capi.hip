@@ -23,6 +23,10 @@ int ka_check_launch(const char* what) {
 }
 
 extern "C" const char* ka_last_error(void) { return g_err; }
+std::atomic<unsigned long long*>& ka_debug_stamps() {
+    static std::atomic<unsigned long long*> p{nullptr};
+    return p;
+}
 extern "C" int ka_version(void) { return 1; }
 extern "C" const char* ka_target_arch(void) { return "gfx950"; }
 

@@ -76,6 +76,10 @@ const KaOptVal* ka_opts();                                   // capi.hip
 inline bool ka_opt_set(KaOpt o) { return ka_opts()[o].set != 0; }
 inline int ka_opt(KaOpt o, int dflt) { const KaOptVal v = ka_opts()[o]; return v.set ? v.val : dflt; }
 
+// diagnostic only: [workgroup][8] stamp buffer of ka_debug_conv_stamps (slots 0 / 7: s_memtime at the start / end of the workgroup's
+// main loop, 3 / 4: s_memrealtime there); null in production -- no stamp executes
+std::atomic<unsigned long long*>& ka_debug_stamps();         // capi.hip
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950.

@@ -91,7 +91,7 @@ struct ConvArgs {
     int mt5;                      // five row tiles (squares 0..79) in the tower kernels, square 80 by conv3x3_corner_kernel
 };
 
-std::atomic<unsigned long long*> g_stamps{nullptr};   // diagnostic only (ka_debug_conv_stamps); null in production
+std::atomic<unsigned long long*>& g_stamps = ka_debug_stamps();   // diagnostic only (ka_debug_conv_stamps); null in production
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -1327,6 +1327,10 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
     wfrag(0, 0, wr[0]); wfrag(0, 1, wr[1]);
     f32x4 acc[NTL][2];
     KA_LDS_BARRIER();                                        // unit 0 is staged
+    if (a.stamps && tid == 0) {                              // diagnostic only (ka_debug_conv_stamps; null in production): the clock the kernel held
+        a.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+        a.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     const bool late = STAG && __builtin_amdgcn_readfirstlane(wave) >= NMW / 2;
     if (late) KA_LDS_BARRIER();                              // waves 4-7 start one slot (half a unit) behind waves 0-3
     for (int u = 0; u < nunits; ++u) {
@@ -1385,6 +1389,10 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
 #pragma unroll
         for (int t = 0; t < NRB; ++t) rowbase[t] += (u & 1) ? -2 * kP2Img : 2 * kP2Img;
         if (!(late && u == nunits - 1)) KA_LDS_BARRIER();    // these images may be overwritten, the next pair is complete
+    }
+    if (a.stamps && tid == 0) {
+        a.stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+        a.stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -31,6 +31,7 @@ struct WgradArgs {
     float* slab;             // [nsplit][9][Cout][Cin]
     int B, Cin, Cout, relu, boards_per_split, ntn, ntiles, nsplit;
     int stagger;             // waves 4-7 stage the next board AFTER their MFMAs instead of before them (see board_iter)
+    unsigned long long* stamps;   // diagnostic only (ka_debug_conv_stamps): [workgroup][8]; null in production
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -372,6 +373,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
     constexpr int NTHR = 512, SY = 128 * 2 + 32, SX = kTC * 2 + 32, KROWS = 82, PW = 17, XSQ = 11 * PW;
     constexpr int YB = KROWS * SY, TILE = YB + XSQ * SX, XTAB = 3 * TILE;      // [3 tiles][dY rows | haloed X squares] | square table
     constexpr int kTapBias = (PW + 1) * SX;
+    // PIPE: the A fragments of the next k-step of a board requested under this step's MFMAs (a second register set): built,
+    // bit-identical, and worth nothing (plain input 327 vs 326 us, profiles/NOTES_r04.md) -- off
+    constexpr bool PIPE = false;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (provably wave-uniform: the k-step walk below stays on the scalar unit)
     const int r = lane & 15, q = lane >> 4;
@@ -497,6 +501,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         if (s_p >= KA_BOARD) { s_p -= KA_BOARD; s_toff = toff_next; }
     };
 
+    if (a.stamps && tid == 0) {
+        a.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+        a.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     if (nb > 0) load_board(bbeg);
     // (every barrier of this kernel orders LDS traffic only: __syncthreads() would also drain the vector-memory counter, i.e. wait
     //  at each board for the prefetch loads of the board after next -- a full HBM round trip for the waves that issue them last)
@@ -520,15 +528,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         if (!late) stage_next();
         const int ks_hi = jl + 1 == nb ? (KA_BOARD * nb + 31) / 32 : (KA_BOARD * (jl + 1)) / 32;
         if (!skip) {
-#pragma unroll 1
-            for (; ks < ks_hi; ++ks) {
-                bf16x8 af[4];
+            // one k-step: 36 MFMAs on the A fragments `ac`; PIPE (the plain-input form, which has the registers): the A fragments of the
+            // NEXT step of this board are requested into `an` right behind this step's first B reads and land under its MFMAs
+            auto load_a = [&](bf16x8 (&f)[4]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + yo[0] + t * 32));
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + yo[1] + t * 32));
-                    af[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    f[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+            };
+            auto kstep = [&](bf16x8 (&ac)[4], bf16x8 (&an)[4], bool more) {
                 const int x0 = xo[0], x1 = xo[1];
                 auto load_b = [&](int tap) {
                     const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * SX + kTapBias;
@@ -536,27 +546,35 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
                     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + x1 + toff));
                     return (bf16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
-                // B fragments (the tap-shifted X rows) are fetched TWO taps ahead: one tap is four MFMAs, 64-128 cycles of the
-                // shared pipe, about one LDS round trip under the load of eight waves
                 bf16x8 bcur = load_b(0), bnx = load_b(1);
                 prepare();                                    // the next step's offsets, behind this step's first reads
+                if (PIPE && more) load_a(an);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     bf16x8 bn2 = bnx;
                     if (tap < 7) bn2 = load_b(tap + 2);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bcur, acc[tap][t], 0, 0, 0);
+                        acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[t], bcur, acc[tap][t], 0, 0, 0);
                     bcur = bnx; bnx = bn2;
                 }
-                // issue order: [8 A reads + 4 B reads] then 7 x { 2 B reads two taps ahead, 4 MFMAs of this tap }, 8 MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#pragma unroll
-                for (int tap = 0; tap < 7; ++tap) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            };
+            bf16x8 afA[4];
+            if constexpr (PIPE) {
+                bf16x8 afB[4];
+                if (ks < ks_hi) load_a(afA);
+#pragma unroll 1
+                for (; ks + 1 < ks_hi; ks += 2) {
+                    kstep(afA, afB, true);
+                    kstep(afB, afA, ks + 2 < ks_hi);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                if (ks < ks_hi) { kstep(afA, afB, false); ++ks; }
+            } else {
+#pragma unroll 1
+                for (; ks < ks_hi; ++ks) {
+                    load_a(afA);
+                    kstep(afA, afA, false);
+                }
             }
         } else {
             ks = ks_hi;
@@ -565,6 +583,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         KA_LDS_BARRIER();
     }
 
+    if (a.stamps && tid == 0) {
+        a.stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+        a.stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- partial slab: [split][tap][n][c], c contiguous (16 lanes -> 64 B runs)
     if (!skip) {
         const int c = c0 + cq * 16 + r;
@@ -679,7 +701,7 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     const int nsplit = wgrad_splits_for(B, Cin, Cout, target_wgs);
     const int bps = (B + nsplit - 1) / nsplit;
     const int ntn = (Cout + tn - 1) / tn, ntiles = ntn * ((Cin + kTC - 1) / kTC);
-    WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit, ka_opt(KA_OPT_WGRAD_STAG, 1)};
+    WgradArgs a{dy, x, in_scale, in_shift, in_bias, slab, B, Cin, Cout, relu, bps, ntn, ntiles, nsplit, ka_opt(KA_OPT_WGRAD_STAG, 1), ka_debug_stamps().load()};
     dim3 grid(8 * ntiles * ((nsplit + 7) / 8));
     int rc;
     const bool fused = in_scale || in_bias || relu;

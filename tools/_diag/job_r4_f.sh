@@ -3,7 +3,7 @@
 root=$(pwd); out=$root/gpurun_out; mkdir -p $out
 timeout -k 10 300 python tools/_diag/wgrad_lean_check.py > $out/r4f_wgrad_lean.txt 2>&1 || { tail -20 $out/r4f_wgrad_lean.txt; exit 1; }
 cat $out/r4f_wgrad_lean.txt
-for round in 1; do
+for round in 1 2; do
   for v in 0 1; do
     KA_WGRAD_LEAN=$v timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fp32 --no-secondary > $out/r4f_bench_${v}_$round.json 2> $out/r4f_bench_${v}_$round.err || { tail -5 $out/r4f_bench_${v}_$round.err; exit 1; }
     python - $out/r4f_bench_${v}_$round.json $v <<'PY'

@@ -17,7 +17,7 @@ for d in sys.argv[1:3]:
     if not fs: continue
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("conv3x3", "wgrad_kernel", "conv_b", "wgrad2")): continue
+        if not any(s in k for s in ("conv3x3", "wgrad_kernel", "wgrad_flat", "conv_b", "wgrad2")): continue
         k = k.replace("(anonymous namespace)::", "").replace("void ", "")
         k = k[:k.index("(")] if "(" in k else k
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1

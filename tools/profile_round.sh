@@ -7,9 +7,9 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --no-cpu-baseline --no-fp32 > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_fetch -o f -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-kernel-events > $out/${tag}_fetch.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_write -o w -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-kernel-events > $out/${tag}_write.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --no-cpu-baseline --no-fp32 --no-secondary > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_fetch -o f -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary --no-kernel-events > $out/${tag}_fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_write -o w -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary --no-kernel-events > $out/${tag}_write.log 2>&1
 cd $root
 python3 tools/pmc_traffic.py $(find $out/${tag}_fetch -name "*counter_collection.csv" | head -1) $(find $out/${tag}_write -name "*counter_collection.csv" | head -1) $out/${tag}_pmc_hbm_traffic.json "bench.py default workload (se_resnet 40x256, minibatch 4096, bf16), 1 warm-up + 1 timed step"
 tail -1 $out/${tag}_bench_under_rocprof.json | cut -c1-600

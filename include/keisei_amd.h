@@ -276,6 +276,14 @@ int ka_rollout_append(const float* obs, const void* legal, const long long* acti
                       float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values, float* d_rewards,
                       void* d_dones, void* d_terminated, long long* d_cats, float* d_score, long long* d_env_ids,
                       float* d_override, int* flags, int n, int obs_elems, int A, void* stream);
+/* as ka_rollout_append with the legal masks already PACKED: legal_bits (n, ka_mask_words(A)) uint32 rows (the device env's
+ * StepResult.legal_mask_bits, PendingTransitions.finalize()["legal_mask_bits"]) are copied word for word. */
+int ka_rollout_append_packed(const float* obs, const void* legal_bits, const long long* actions, const float* log_probs,
+                             const float* values, const float* rewards, const void* dones, const void* terminated,
+                             const long long* cats, const float* score, const long long* env_ids, const float* override_,
+                             float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values, float* d_rewards,
+                             void* d_dones, void* d_terminated, long long* d_cats, float* d_score, long long* d_env_ids,
+                             float* d_override, int* flags, int n, int obs_elems, int A, void* stream);
 int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream);
 int ka_pack_mask_bits(const void* legal, void* bits, int rows, int A, void* stream);
 

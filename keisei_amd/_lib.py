@@ -74,6 +74,7 @@ _SIGS = {
     "ka_transpose_multi": "p ii p",
     "ka_mask_words": "i",
     "ka_rollout_append": "pppppppppppp pppppppppppp p iii p",
+    "ka_rollout_append_packed": "pppppppppppp pppppppppppp p iii p",
     "ka_unpack_mask_bits": "ppp ii p",
     "ka_pack_mask_bits": "pp ii p",
     "ka_pending_open": "pppppppp ppppppppp p iii p",

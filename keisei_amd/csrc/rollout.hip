@@ -22,6 +22,7 @@ struct AppendArgs {
     uint8_t* d_dones; uint8_t* d_terminated; long long* d_cats; float* d_score; long long* d_env_ids; float* d_override;
     int* flags;      // [0] terminated without done, [1] category outside {-1,0,1,2}, [2] NaN score target, [3] bits of max |score|
     int obs_elems, A, words;
+    int packed;      // legal holds packed rows (n, words) uint32 already (the device env's / PendingTransitions' form): copied
 };
 
 constexpr int kAppendThreads = 256;
@@ -42,6 +43,10 @@ __global__ __launch_bounds__(kAppendThreads) void rollout_append_kernel(AppendAr
     const uint8_t* lm = a.legal + (size_t)row * a.A;
     uint32_t* bits = a.d_bits + (size_t)row * a.words;
     const int lane = tid & 63, wave = tid >> 6;
+    if (a.packed) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.legal) + (size_t)row * a.words;
+        for (int i = tid; i < a.words; i += kAppendThreads) bits[i] = src[i];
+    } else
     for (int base = wave * 64; base < a.words * 32; base += (kAppendThreads / 64) * 64) {
         const int j = base + lane;
         const unsigned long long vote = __ballot(j < a.A && lm[j] != 0);
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void pending_settle_kernel(PendingArgs a) {
 
 extern "C" int ka_mask_words(int A) { return (A + 31) / 32; }
 
-extern "C" int ka_rollout_append(const float* obs, const void* legal, const long long* actions, const float* log_probs,
+static int rollout_append_impl(const float* obs, const void* legal, int packed, const long long* actions, const float* log_probs,
                                  const float* values, const float* rewards, const void* dones, const void* terminated,
                                  const long long* cats, const float* score, const long long* env_ids, const float* override_,
                                  float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values,
@@ -222,9 +227,33 @@ extern "C" int ka_rollout_append(const float* obs, const void* legal, const long
                  static_cast<const uint8_t*>(dones), static_cast<const uint8_t*>(terminated), cats, score, env_ids, override_,
                  d_obs, static_cast<uint32_t*>(d_bits), d_actions, d_log_probs, d_values, d_rewards,
                  static_cast<uint8_t*>(d_dones), static_cast<uint8_t*>(d_terminated), d_cats, d_score, d_env_ids, d_override,
-                 flags, obs_elems, A, (A + 31) / 32};
+                 flags, obs_elems, A, (A + 31) / 32, packed};
     hipLaunchKernelGGL(rollout_append_kernel, dim3(n), dim3(kAppendThreads), 0, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("rollout_append");
+}
+extern "C" int ka_rollout_append(const float* obs, const void* legal, const long long* actions, const float* log_probs,
+                                 const float* values, const float* rewards, const void* dones, const void* terminated,
+                                 const long long* cats, const float* score, const long long* env_ids, const float* override_,
+                                 float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values,
+                                 float* d_rewards, void* d_dones, void* d_terminated, long long* d_cats, float* d_score,
+                                 long long* d_env_ids, float* d_override, int* flags, int n, int obs_elems, int A,
+                                 void* stream) {
+    return rollout_append_impl(obs, legal, 0, actions, log_probs, values, rewards, dones, terminated, cats, score, env_ids, override_,
+                               d_obs, d_bits, d_actions, d_log_probs, d_values, d_rewards, d_dones, d_terminated, d_cats, d_score,
+                               d_env_ids, d_override, flags, n, obs_elems, A, stream);
+}
+// the same with the legal masks handed over as PACKED rows (n, ka_mask_words(A)) uint32 -- what the device env and
+// PendingTransitions.finalize() hold: the words are copied, nothing is unpacked and packed again on the way
+extern "C" int ka_rollout_append_packed(const float* obs, const void* legal_bits, const long long* actions, const float* log_probs,
+                                        const float* values, const float* rewards, const void* dones, const void* terminated,
+                                        const long long* cats, const float* score, const long long* env_ids, const float* override_,
+                                        float* d_obs, void* d_bits, long long* d_actions, float* d_log_probs, float* d_values,
+                                        float* d_rewards, void* d_dones, void* d_terminated, long long* d_cats, float* d_score,
+                                        long long* d_env_ids, float* d_override, int* flags, int n, int obs_elems, int A,
+                                        void* stream) {
+    return rollout_append_impl(obs, legal_bits, 1, actions, log_probs, values, rewards, dones, terminated, cats, score, env_ids, override_,
+                               d_obs, d_bits, d_actions, d_log_probs, d_values, d_rewards, d_dones, d_terminated, d_cats, d_score,
+                               d_env_ids, d_override, flags, n, obs_elems, A, stream);
 }
 
 extern "C" int ka_unpack_mask_bits(const void* bits, const long long* idx, void* out, int rows, int A, void* stream) {

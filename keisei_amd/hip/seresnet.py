@@ -489,10 +489,14 @@ class SEResNetEngine:
         self._get_packs(T, dev)
         # (the flat tensor lists are cached while no module registered a submodule / parameter / buffer -- walking the module
         # tree costs more host time than the whole graph replay; the storage addresses themselves are checked on every call)
-        from keisei_amd.training._structure import structure_version
+        from keisei_amd.training._structure import structure_fingerprint, structure_version
         tl, ver = self._tensor_lists, structure_version()
+        self._tl_calls = getattr(self, "_tl_calls", 0) + 1
+        # (backstop every 64 calls: an edit that goes around every hook, e.g. `m._modules.pop(name)`, changes the counts)
+        if tl is not None and tl[2] == ver and self._tl_calls % 64 == 0 and structure_fingerprint(m) != tl[3]:
+            tl = None
         if tl is None or tl[2] != ver:
-            tl = self._tensor_lists = (list(m.buffers()), list(m.parameters()), ver)
+            tl = self._tensor_lists = (list(m.buffers()), list(m.parameters()), ver, structure_fingerprint(m))
         key = (tuple(obs.shape), T, str(dev), self._pack_tkey,
                tuple(b.data_ptr() for b in tl[0]), tuple(q.data_ptr() for q in tl[1]))
         with self._graph_lock:

@@ -336,7 +336,10 @@ def split_merge_step(obs: torch.Tensor, legal_masks: torch.Tensor, current_playe
     ranked = sorted(cohort)
     rank_of = {opp_id: r for r, opp_id in enumerate(ranked)}
     if game_opponent is None:
-        # no per-game assignment: the reference lets every model act on all opponent games and keeps the last one's actions
+        # no per-game assignment: the reference lets EVERY model act on all opponent games, in dict order, and keeps the last one's
+        # actions (katago_loop.py:404-431).  Here only that last model runs -- the merged actions are its own either way -- and each
+        # skipped model still consumes the one host draw its sampling would have taken (below), so a seeded rollout stays in
+        # step with the all-models form.  Deviation: the zero-legal / NaN guards of the skipped models do not fire.
         slot_of = torch.full((n,), rank_of[list(cohort)[-1]], dtype=torch.long, device=dev)
     else:
         wanted = _on(dev, game_opponent, torch.long)
@@ -366,6 +369,8 @@ def split_merge_step(obs: torch.Tensor, legal_masks: torch.Tensor, current_playe
         rank = rank_of[opp_id]
         count = sizes[rank + 1]
         if not count:
+            if game_opponent is None and obs.is_cuda and n - sizes[0] > 0:
+                torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)          # the seed draw of the model that does not run (see above)
             continue
         games = order[starts[rank + 1]:starts[rank + 1] + count]
         away = opponent_devices.get(opp_id) if opponent_devices is not None else \

@@ -253,7 +253,14 @@ class KataGoRolloutBuffer:
                                score_targets.detach().cpu())
         col = lambda t, dt: t.detach().to(device=dev, dtype=dt).reshape(n).contiguous()  # noqa: E731 (no-op when canonical)
         obs_c = obs.detach().to(device=dev, dtype=torch.float32).reshape(n, self._obs_elems).contiguous()
-        mask_c = legal_masks.detach().to(device=dev, dtype=torch.bool).reshape(n, self.action_space).contiguous()
+        # legal masks: bool rows (the reference's form) or the PACKED int32 rows (n, ceil(A / 32)) of the device env /
+        # PendingTransitions.finalize()["legal_mask_bits"], which are copied word for word into the store's packed column
+        words = (self.action_space + 31) // 32
+        packed = legal_masks.dtype == torch.int32 and legal_masks.dim() == 2 and legal_masks.shape[1] == words
+        if packed:
+            mask_c = legal_masks.detach().to(device=dev).contiguous()
+        else:
+            mask_c = legal_masks.detach().to(device=dev, dtype=torch.bool).reshape(n, self.action_space).contiguous()
         act_c, cat_c = col(actions, torch.long), col(value_categories, torch.long)
         lp_c, val_c, rew_c, score_c = (col(t, torch.float32) for t in (log_probs, values, rewards, score_targets))
         done_c, term_c = col(dones, torch.bool), col(terminated, torch.bool)
@@ -273,7 +280,8 @@ class KataGoRolloutBuffer:
         lo, hi = self._write_offset, self._write_offset + n
         st = self._storage
         dst = lambda key: st[key][lo:hi] if key in st else None  # noqa: E731
-        _lib.call("ka_rollout_append", obs_c, mask_c, act_c, lp_c, val_c, rew_c, done_c, term_c, cat_c, score_c, env_c, ov_c,
+        _lib.call("ka_rollout_append_packed" if packed else "ka_rollout_append", obs_c, mask_c, act_c, lp_c, val_c, rew_c, done_c, term_c,
+                  cat_c, score_c, env_c, ov_c,
                   dst("observations"), dst("legal_masks"), dst("actions"), dst("log_probs"), dst("values"), dst("rewards"),
                   dst("dones"), dst("terminated"), dst("value_categories"), dst("score_targets"),
                   dst("env_ids") if env_ids is not None else None,

@@ -440,4 +440,14 @@ def test_mode_cache_follows_structural_changes():
     model.extra = Odd()
     algo._set_training(False)
     assert Odd.calls >= 1 and not model.extra.training
-    del model.extra
+    v1 = structure_version()
+    del model.extra                                                      # removals count too: the cache is rebuilt
+    assert structure_version() > v1
+    algo._set_training(True)
+    assert algo._mode_cache[1] is not None and all(m.training for m in model.modules())
+    v2 = structure_version()
+    model.blocks[0].bn1.running_mean = None                              # a buffer dropped by assignment
+    assert structure_version() > v2
+    v3 = structure_version()
+    model.blocks[0].bn1.register_buffer("running_mean", torch.zeros(32))
+    assert structure_version() > v3

@@ -106,6 +106,26 @@ def test_device_store_equals_host_store(env_layout):
     assert set(fh) == set(fd) and all(same(fd[k], fh[k]) for k in fh)
 
 
+def test_device_store_takes_packed_masks_as_they_are():
+    """add() with the legal masks as PACKED int32 rows (the device env's StepResult.legal_mask_bits, PendingTransitions.finalize()
+    ["legal_mask_bits"]): ka_rollout_append_packed copies the words -- the store equals the one filled from bool rows."""
+    T, N = 5, 6
+    steps = synth_steps(T, N, seed=21)
+    ref, dev = KataGoRolloutBuffer(N, (50, 9, 9), A), KataGoRolloutBuffer(N, (50, 9, 9), A)
+    fill(ref, steps, DEV)
+    words = (A + 31) // 32
+    for s in steps:
+        legal = s["legal_masks"].to(DEV)
+        bits = torch.empty(legal.shape[0], words, dtype=torch.int32, device=DEV)
+        _lib.call("ka_pack_mask_bits", legal, bits, legal.shape[0], A, st())
+        packed_step = dict(s)
+        packed_step["legal_masks"] = bits
+        fill(dev, [packed_step], DEV)
+    fr, fd = ref.flatten(), dev.flatten()
+    assert set(fr) == set(fd) and all(same(fd[k], fr[k]) for k in fr)
+    assert torch.equal(ref.flatten_packed()["legal_bits"], dev.flatten_packed()["legal_bits"])
+
+
 def test_device_store_grows():
     steps = synth_steps(4, 400, seed=8, env_layout=False, overrides=True)     # 1600 rows > the initial 512 * 1
     host, dev = KataGoRolloutBuffer(1, (50, 9, 9), A), KataGoRolloutBuffer(1, (50, 9, 9), A)

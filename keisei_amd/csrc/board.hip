@@ -527,6 +527,11 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
     float sg[P16], sgy[P16], sy[P16];
 #pragma unroll
     for (int e = 0; e < P16; ++e) { sg[e] = 0.f; sgy[e] = 0.f; sy[e] = 0.f; }
+    // The two FC phases between the reduction and the second pass read their weights from L2 with the board's HBM traffic at a
+    // standstill: as rolled loops each weight is a round trip of its own, so both loops are written load-everything-then-multiply
+    // (same values, same order of additions) when the shape fits the fixed counts.
+    constexpr int kW2 = 16, kW1 = 16;
+    const bool w_pre = (2 * C + NTHR / H - 1) / (NTHR / H) <= kW2 && H <= kW1;
     __syncthreads();
     vec16 du[MAXSQ];
 #pragma unroll
@@ -614,7 +619,15 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
     {   // dh[j] = sum_k dse[k] W2[k][j]: thread (j, part) sums every parts-th k
         const int parts = NTHR / H, j = tid % H, part = tid / H;
         float a = 0.f;
-        for (int k = part; k < 2 * C; k += parts) a = fmaf(v_dse[k], W2[(size_t)k * H + j], a);
+        if (w_pre) {
+            float w2r[kW2];
+#pragma unroll
+            for (int u = 0; u < kW2; ++u) { const int k = part + u * parts; w2r[u] = k < 2 * C ? W2[(size_t)k * H + j] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < kW2; ++u) { const int k = part + u * parts; if (k < 2 * C) a = fmaf(v_dse[k], w2r[u], a); }
+        } else {
+            for (int k = part; k < 2 * C; k += parts) a = fmaf(v_dse[k], W2[(size_t)k * H + j], a);
+        }
         v_part[tid] = a;
     }
     __syncthreads();
@@ -629,7 +642,15 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
     __syncthreads();
     for (int c = tid; c < C; c += NTHR) {
         float a = 0.f;
-        for (int j = 0; j < H; ++j) a = fmaf(v_dh[j], W1[(size_t)j * C + c], a);
+        if (w_pre) {
+            float w1r[kW1];
+#pragma unroll
+            for (int j = 0; j < kW1; ++j) w1r[j] = j < H ? W1[(size_t)j * C + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kW1; ++j) if (j < H) a = fmaf(v_dh[j], w1r[j], a);
+        } else {
+            for (int j = 0; j < H; ++j) a = fmaf(v_dh[j], W1[(size_t)j * C + c], a);
+        }
         v_dsq[c] = a;
         const float gate = v_gate[c], add = a / KA_BOARD;
         s1p[(size_t)b * C + c] = fmaf(gate, red_g[c], KA_BOARD * add);

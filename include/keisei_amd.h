@@ -160,6 +160,16 @@ int ka_block_dx_tail_bwd(const void* dxc, const void* dout_up, const void* out_u
                          const float* dpool, void* dx, const void* y, const float* scale, const float* shift, const float* se,
                          const float* se1, const float* W2, const float* W1, const float* mean, const float* invstd, void* dz,
                          float* dse, float* dh, float* s1p, float* s2p, int B, int C, int H, int dtype, void* stream);
+/* The same launch as a CHAIN over the block boundaries, one activation read shorter.  All that the residual branch one block
+ * further down takes from dx is du = dx * [x > 0] (se_resnet.py:90: the ReLU after the residual sum) -- the value this launch
+ * forms for its own tail -- so du_out = dx * [x > 0] is written instead of dx, and du_up (the du_out of the launch above; NULL
+ * where the gradient enters from the heads) is added as it is: the block above's output is not read (4 activation reads + 2
+ * writes).  dz / dse / dh / s1p / s2p equal ka_block_dx_tail_bwd's bit for bit; ka_block_dx takes a du_out as its `dout`
+ * unchanged (masking twice by the same output changes nothing), which ends the chain at the first block. */
+int ka_block_dx_tail_bwd_du(const void* dxc, const void* du_up, const void* x, const float* xpool, const float* dpool,
+                            void* du_out, const void* y, const float* scale, const float* shift, const float* se,
+                            const float* se1, const float* W2, const float* W1, const float* mean, const float* invstd, void* dz,
+                            float* dse, float* dh, float* s1p, float* s2p, int B, int C, int H, int dtype, void* stream);
 
 /* ---- small dense layers: nn.Linear / 1x1 nn.Conv2d forward and backward (se_resnet.py:57-61,65-66,120-130) --
  * C[M,N] (+)= act(opA(A)[M,K] * opB(B)[K,N] + bias); opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k], likewise opB.

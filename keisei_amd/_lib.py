@@ -48,6 +48,7 @@ _SIGS = {
     "ka_block_dx": "pppppp p ii i p",
     "ka_block_dx_tail_bwd_supported": "iii",
     "ka_block_dx_tail_bwd": "pppppp p ppppppppp p pppp iii i p",
+    "ka_block_dx_tail_bwd_du": "ppppp p ppppppppp p pppp iii i p",
     "ka_gemm": "pppp iii iii ii iii i i i p",
     "ka_reduce_slabs": "pp i q i p",
     "ka_colsum": "pppp ii i p",

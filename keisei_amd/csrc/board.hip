@@ -480,9 +480,11 @@ struct DxArgs {
     const void* dxc; const void* dout_up; const void* out_up;   // conv1 data gradient, gradient and output of the block above (null for the heads)
     const float* xpool; const float* dpool;                     // pooled statistics of x, gradient wrt them
     void* dx;
+    int du_io;   // 1 (kernel form DX = 2): dout_up already carries its ReLU mask (out_up unused) and dx is WRITTEN masked by [x > 0] -- see ka_block_dx_tail_bwd_du
 };
 
-template <typename T, int MAXSQ, int NTHR, bool DX>
+// DX: 0 = the tail alone, 1 = with the block-input gradient of the block above, 2 = the same in its du-chain form
+template <typename T, int MAXSQ, int NTHR, int DX>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 6 && !DX) ? 6 : 4))) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                 if (dxc) t1 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C));
                 if (dup) {
                     t2 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dup + base + (size_t)p * C));
-                    t3 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(oup + base + (size_t)p * C));
+                    if constexpr (DX != 2) t3 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(oup + base + (size_t)p * C));
                 }
 #pragma unroll
                 for (int e = 0; e < P16; ++e) {
@@ -569,11 +571,12 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                 if (dup) {
                     float t[P16], o2[P16];
                     E::unpack(t2, t); E::unpack(t3, o2);
+                    // (a masked dout_up holds +0 where out_up <= 0: adding it as it is gives the same sum)
 #pragma unroll
-                    for (int e = 0; e < P16; ++e) gf[e] += o2[e] > 0.f ? t[e] : 0.f;
+                    for (int e = 0; e < P16; ++e) gf[e] += (DX == 2 || o2[e] > 0.f) ? t[e] : 0.f;
                 }
                 g = E::pack(gf);
-                __builtin_nontemporal_store(g, reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
+                if constexpr (DX != 2) __builtin_nontemporal_store(g, reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
             } else {
                 g = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C));
             }
@@ -587,6 +590,8 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                 sy[e] += yc;
             }
             du[i] = E::pack(gf);             // exact: a masked copy of dout
+            if constexpr (DX == 2)
+                __builtin_nontemporal_store(du[i], reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
         }
     }
     for (int off = groups; off < 64; off <<= 1) {             // lanes cg, cg + groups, ... of a wave hold the same channels
@@ -1207,7 +1212,7 @@ static int tail_bwd_launch(const void* dout, const void* out, const void* y, con
     const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
     const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 3 * C + (dxp ? 5 * C : 0)) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
-    const DxArgs dxa = dxp ? *dxp : DxArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const DxArgs dxa = dxp ? *dxp : DxArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 #define KA_TAIL_LAUNCH(MAXSQ, NTHR, DX_) \
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR, DX_>), dim3(B), dim3(NTHR), lds, st, \
                                             (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, \
@@ -1215,7 +1220,7 @@ static int tail_bwd_launch(const void* dout, const void* out, const void* y, con
 #define KA_TAIL_PICK(DX_) \
     if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512, DX_); else KA_TAIL_LAUNCH(11, 512, DX_); } \
     else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256, DX_); else KA_TAIL_LAUNCH(11, 256, DX_); }
-    if (dxp) { KA_TAIL_PICK(true) } else { KA_TAIL_PICK(false) }
+    if (dxp && dxp->du_io) { KA_TAIL_PICK(2) } else if (dxp) { KA_TAIL_PICK(1) } else { KA_TAIL_PICK(0) }
 #undef KA_TAIL_PICK
 #undef KA_TAIL_LAUNCH
     return ka_check_launch(dxp ? "block_dx_tail_bwd" : "tail_bwd_fused");
@@ -1246,7 +1251,28 @@ extern "C" int ka_block_dx_tail_bwd(const void* dxc, const void* dout_up, const 
     KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
                "block_dx_tail_bwd: null tensor");
     KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd: unsupported shape C=%d H=%d", C, H);
-    DxArgs dxa{dxc, dout_up, out_up, xpool, dpool, dx};
+    DxArgs dxa{dxc, dout_up, out_up, xpool, dpool, dx, 0};
+    return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
+                           static_cast<hipStream_t>(stream));
+}
+
+// The same launch for a chain of block boundaries, one activation read shorter: what the residual branch of the block
+// below needs of this launch's dx is only du = dx * [x > 0] -- and this launch forms exactly that for its own tail.  So
+//   du_out = dx * [x > 0]  is what is WRITTEN (dx itself is not), and
+//   du_up  (the du_out of the launch above, or NULL for the gradient entering from the heads) is ADDED as it is,
+// which takes the block above's output out of the reads (4 activation reads + 2 writes instead of 5 + 2).  dz / dse / dh /
+// s1 / s2 are bit for bit those of ka_block_dx_tail_bwd; ka_block_dx accepts a du_out as its `dout` unchanged (its mask
+// by the same `out` is idempotent), which is how the chain ends at the first block.
+extern "C" int ka_block_dx_tail_bwd_du(const void* dxc, const void* du_up, const void* x, const float* xpool,
+                                       const float* dpool, void* du_out, const void* y, const float* scale, const float* shift,
+                                       const float* se, const float* se1, const float* W2, const float* W1, const float* mean,
+                                       const float* invstd, void* dz, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                                       int H, int dtype, void* stream) {
+    KA_REQUIRE(x && xpool && dpool && du_out, "block_dx_tail_bwd_du: bad block_dx arguments");
+    KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
+               "block_dx_tail_bwd_du: null tensor");
+    KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd_du: unsupported shape C=%d H=%d", C, H);
+    DxArgs dxa{dxc, du_up, nullptr, xpool, dpool, du_out, 1};
     return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
                            static_cast<hipStream_t>(stream));
 }

@@ -742,6 +742,8 @@ class SEResNetEngine:
         # The block-input gradient of the block above and the backward tail of the next block meet at every block boundary:
         # one launch for the two (ka_block_dx_tail_bwd: 7 activation passes instead of 9, same results bit for bit) wherever the
         # shape allows it.  `pend` = the ka_block_dx call still owed: (dxc, dout_up, out_up, x, xpool, dpool, dx).
+        # The launches form a chain (ka_block_dx_tail_bwd_du): each writes du = dx * [x > 0] -- all the residual branch below
+        # needs -- instead of dx, and adds the du from above as it is, so the block above's output is not read (6 passes).
         Hse = m.blocks[0].se_fc1.weight.shape[0] if len(m.blocks) > 0 else 0
         fuse_dx = (len(m.blocks) > 0 and os.environ.get("KA_DX_TAIL", "1") != "0"
                    and bool(_lib.query("ka_block_dx_tail_bwd_supported", C, Hse, code)))
@@ -807,8 +809,8 @@ class SEResNetEngine:
             if pend is not None:
                 # (pend[3], the input of the block above, IS this block's output `out`)
                 dse1 = torch.empty(B, H, device=dev)
-                _call("ka_block_dx_tail_bwd", *pend, y2, sc2, sh2, se, se1, blk.se_fc2.weight, blk.se_fc1.weight, mu2, is2,
-                      dz, dse, dse1, s1p, s2p, B, C, H, code, st)
+                _call("ka_block_dx_tail_bwd_du", pend[0], pend[1], *pend[3:], y2, sc2, sh2, se, se1, blk.se_fc2.weight,
+                      blk.se_fc1.weight, mu2, is2, dz, dse, dse1, s1p, s2p, B, C, H, code, st)
                 self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
                 self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st, need_dx=False)
             elif _lib.query("ka_tail_bwd_fused_supported", C, H, code):

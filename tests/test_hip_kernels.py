@@ -600,6 +600,21 @@ def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
     torch.cuda.synchronize()
     for name, a, b in (("dx", dx, dx_r), ("dz", dz, dz_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
         assert torch.equal(a, b), name
+    # the chain form: takes the masked gradient of the block above (no out_up read), writes du = dx * [x > 0]
+    du_up = None if heads else torch.where(out_up > 0, dout_up, torch.zeros_like(dout_up))
+    du, dz, dse, dh, s1, s2 = outs()
+    _lib.call("ka_block_dx_tail_bwd_du", dxc, du_up, x, pool, dpool, du, y, sc, sh, se, se1, W2, W1, mu, istd, dz, dse, dh, s1, s2,
+              B, C, H, code, st())
+    torch.cuda.synchronize()
+    du_r = torch.where(x > 0, dx_r, torch.zeros_like(dx_r))
+    for name, a, b in (("du", du, du_r), ("dz", dz, dz_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
+        assert torch.equal(a, b), name
+    # ... and ka_block_dx takes a du as its dout: same result as from the unmasked gradient
+    if not heads:
+        dx2 = torch.empty_like(x)
+        _lib.call("ka_block_dx", dxc, du_up, out_up, x, pool, dpool, dx2, B, C, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(dx2, dx_r)
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])

@@ -37,6 +37,8 @@ cases += [
                                                               _lib.call("ka_tail_bwd_fused", dx2, x, y, sc, sh, se, se1, W2, W1, mu, istd, dz, dse, dh, s1, s2, B, C, H, code, st()))),
     ("block_dx_tail_bwd, one launch (5R+2W)", 7, lambda: _lib.call("ka_block_dx_tail_bwd", dxc, dout, out, x, pool, dpool, dx2, y, sc, sh, se, se1, W2, W1, mu, istd,
                                                                    dz, dse, dh, s1, s2, B, C, H, code, st())),
+    ("block_dx_tail_bwd_du, chain form (4R+2W)", 6, lambda: _lib.call("ka_block_dx_tail_bwd_du", dxc, dout, x, pool, dpool, dx2, y, sc, sh, se, se1, W2, W1, mu, istd,
+                                                                      dz, dse, dh, s1, s2, B, C, H, code, st())),
 ]
 for name, passes, fn in cases:
     ms = timeit(fn)

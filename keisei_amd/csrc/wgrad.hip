@@ -400,53 +400,69 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         reinterpret_cast<int*>(smem + XTAB)[tid] = YB + ((p / 9 + 1) * PW + (p % 9) + 1) * SX;
     }
 
-    // ---- staging roles: lane constants
+    // ---- staging roles: lane constants.  The staging shares its SIMD with the other wave's MFMAs, which leave the vector unit
+    // one issue slot in two: every vector instruction, exec-mask branch and address add of the staging is time the board period
+    // grows by (stamps, tools/_diag/wgrad_tl.py: 900-1100 cycles per board for what used to be ~85 instructions in ten branchy
+    // blocks, 500-700 for the 15 below).  So the tensors are read through buffer descriptors -- lane offset fixed for the whole
+    // launch, the board a scalar offset, lanes without a piece (rows past the board, columns past the tensor) parked out of range,
+    // where a load returns zeros -- and the LDS stores are unconditional: a lane without a row writes into the pad bytes of
+    // row 0 / square (1, 1), which nothing reads.
     const int yj = tid & 15, xj = tid & 7;
     const bool ycol_ok = n0 + yj * 8 < a.Cout, xcol_ok = c0 + xj * 8 < a.Cin;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (unsigned)a.B * (KA_BOARD * 2u) * (unsigned)a.Cout, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (unsigned)a.B * (KA_BOARD * 2u) * (unsigned)a.Cin, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FUSED ? a.in_bias : nullptr), 0,
+                                                                          FUSED && a.in_bias ? (unsigned)a.B * 4u * (unsigned)a.Cin : 0u, 0x00020000);
+    constexpr int kPark = 0x7fffffff;
     int ldsY[3], gY[3], ldsX[2], gX[2];
-    bool okY[3], okX[2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int row = (tid >> 4) + 32 * i;
-        okY[i] = row < KA_BOARD && ycol_ok;
-        ldsY[i] = row * SY + yj * 16;
-        gY[i] = (row * a.Cout + n0 + yj * 8) * 2;
+        gY[i] = row < KA_BOARD && ycol_ok ? (row * a.Cout + n0 + yj * 8) * 2 : kPark;
+        ldsY[i] = row < KA_BOARD ? row * SY + yj * 16 : 256;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + 64 * i, rr = row < KA_BOARD ? row : 0;
-        okX[i] = row < KA_BOARD && xcol_ok;
-        ldsX[i] = YB + ((rr / 9 + 1) * PW + (rr % 9) + 1) * SX + xj * 16;
-        gX[i] = (row * a.Cin + c0 + xj * 8) * 2;
+        const int row = (tid >> 3) + 64 * i;
+        gX[i] = row < KA_BOARD && xcol_ok ? (row * a.Cin + c0 + xj * 8) * 2 : kPark;
+        ldsX[i] = row < KA_BOARD ? YB + ((row / 9 + 1) * PW + (row % 9) + 1) * SX + xj * 16 : YB + (PW + 1) * SX + kTC * 2;
     }
-    float sc[FUSED ? 8 : 1], sh[FUSED ? 8 : 1], rb[FUSED ? 8 : 1];
+    const int gB = xcol_ok ? (c0 + xj * 8) * 4 : kPark;
+    // (columns past the tensor: scale = shift = 0 and a bias that reads as zeros keep their squares at exactly zero through the transform)
+    float sc[FUSED ? 8 : 1] = {}, sh[FUSED ? 8 : 1] = {};
+    f32x4 rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0;
     const bool has_aff = FUSED && a.in_scale != nullptr;
     if (has_aff && xcol_ok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale[c0 + xj * 8 + e]; sh[e] = a.in_shift[c0 + xj * 8 + e]; }
     }
+    // the last round of either tensor has rows for the first waves only (dY: rows 64 + 4 wave .., X: rows 64 + 8 wave ..): the
+    // others skip it, wave-uniformly (for X that is the whole second transform)
+    const bool y2 = 64 + 4 * wave < KA_BOARD, x1 = 64 + 8 * wave < KA_BOARD;
     bf16x8 ry[3], rx[2];
     auto load_board = [&](int b) {
-        const char* yb = static_cast<const char*>(a.dy) + (size_t)b * KA_BOARD * a.Cout * 2;
-        const char* xb = static_cast<const char*>(a.x) + (size_t)b * KA_BOARD * a.Cin * 2;
-        if (FUSED && a.in_bias && xcol_ok) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rb[e] = a.in_bias[(size_t)b * a.Cin + c0 + xj * 8 + e];
+        const int sy = __builtin_amdgcn_readfirstlane(b * (KA_BOARD * 2) * a.Cout), sx = __builtin_amdgcn_readfirstlane(b * (KA_BOARD * 2) * a.Cin);
+        if (FUSED && a.in_bias) {
+            const int sb = __builtin_amdgcn_readfirstlane(b * 4 * a.Cin);
+            rb0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, gB, sb, 0));
+            rb1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, gB + 16, sb, 0));
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ry[i] = okY[i] ? *reinterpret_cast<const bf16x8*>(yb + gY[i]) : bf16x8{};
+        for (int i = 0; i < 3; ++i)
+            if (i < 2 || y2) ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_y, gY[i], sy, 0));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rx[i] = okX[i] ? *reinterpret_cast<const bf16x8*>(xb + gX[i]) : bf16x8{};
+        for (int i = 0; i < 2; ++i)
+            if (i < 1 || x1) rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_x, gX[i], sx, 0));
     };
     auto store_board = [&](int toff) {                       // into the tile at byte offset toff of the ring
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if ((tid >> 4) + 32 * i < KA_BOARD) *reinterpret_cast<bf16x8*>(smem + toff + ldsY[i]) = ry[i];
+            if (i < 2 || y2) *reinterpret_cast<bf16x8*>(smem + toff + ldsY[i]) = ry[i];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if ((tid >> 3) + 64 * i >= KA_BOARD) continue;
+            if (i == 1 && !x1) continue;
             bf16x8 v = rx[i];
-            if (FUSED && xcol_ok && (has_aff || a.relu || a.in_bias)) {
+            if (FUSED && (has_aff || a.relu || a.in_bias)) {
                 float f[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
                 }
                 if (a.in_bias) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += rb[e];
+                    for (int e = 0; e < 4; ++e) { f[e] += rb0[e]; f[4 + e] += rb1[e]; }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)f[e];
@@ -516,8 +532,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
     prepare();                                                // step 0 (reads the table: behind the barrier above)
     KA_LDS_BARRIER();
     int ks = 0;
+#ifdef KA_DIAG_WGRAD_TL
+    // diagnostic build (tools/_diag/wgrad_tl.py): per-wave phase stamps of workgroup 0, boards 8..23 ->
+    // stamps[4096 * 8 + ((board - 8) * 8 + wave) * 8 + phase]
+#define KA_TL(ph) do { if (a.stamps && blockIdx.x == 0 && jl >= 8 && jl < 24 && lane == 0) \
+        a.stamps[4096 * 8 + ((jl - 8) * 8 + wave) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KA_TL(ph) do {} while (0)
+#endif
 #pragma unroll 1
     for (int jl = 0; jl < nb; ++jl) {
+        KA_TL(0);
         const int nxt = ((jl + 1) % 3) * TILE;
         auto stage_next = [&]() {
             if (jl + 1 < nb) {
@@ -526,6 +551,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
             }
         };
         if (!late) stage_next();
+        KA_TL(1);
         const int ks_hi = jl + 1 == nb ? (KA_BOARD * nb + 31) / 32 : (KA_BOARD * (jl + 1)) / 32;
         if (!skip) {
             // one k-step: 36 MFMAs on the A fragments `ac`; PIPE (the plain-input form, which has the registers): the A fragments of the
@@ -579,9 +605,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_kernel(WgradArgs a) {
         } else {
             ks = ks_hi;
         }
+        KA_TL(2);
         if (late) stage_next();
+        KA_TL(3);
         KA_LDS_BARRIER();
+        KA_TL(4);
     }
+#undef KA_TL
 
     if (a.stamps && tid == 0) {
         a.stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -706,7 +736,9 @@ extern "C" int ka_conv3x3_wgrad(const void* dy, const void* x, const float* in_s
     int rc;
     const bool fused = in_scale || in_bias || relu;
 #define KA_WG(T_, TN_) (fused ? launch_wgrad<T_, TN_, true>(a, grid, st) : launch_wgrad<T_, TN_, false>(a, grid, st))
-    if (dtype == KA_DTYPE_BF16 && tn == 128 && ka_opt(KA_OPT_WGRAD_LEAN, 1) != 0)
+    // (the lean kernel addresses a tensor through a 32-bit buffer descriptor with the board as a signed scalar offset)
+    const bool fits32 = (unsigned long long)B * KA_BOARD * 2 * (unsigned long long)(Cin > Cout ? Cin : Cout) < 0x7fffffffull;
+    if (dtype == KA_DTYPE_BF16 && tn == 128 && fits32 && ka_opt(KA_OPT_WGRAD_LEAN, 1) != 0)
         rc = fused ? launch_wgrad_flat<true>(a, grid, st) : launch_wgrad_flat<false>(a, grid, st);
     else if (dtype == KA_DTYPE_BF16) rc = tn == 64 ? KA_WG(bf16_t, 64) : KA_WG(bf16_t, 128);
     else if (dtype == KA_DTYPE_F32) rc = tn == 64 ? KA_WG(float, 64) : KA_WG(float, 128);

@@ -71,6 +71,8 @@ class SEResNetEngine:
         # 0.73 ms in the step's trace).  KA_WGRAD_OVERLAP=1 brings the two-stream schedule back.
         self.overlap_wgrad = os.environ.get("KA_WGRAD_OVERLAP", "0") != "0"
         self.fork_fc = os.environ.get("KA_FC_FORK", "1") != "0"      # small-batch forward: global-pool FC chain beside conv1
+        self._fc_side = None
+        self._gpool_done = None
         self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
@@ -376,15 +378,29 @@ class SEResNetEngine:
             ent["key"] = key
         return ent["views"]
 
-    def _gpool_bwd(self, i, blk, dg, g1, bpool, grads, pre, st, tr):
-        """input gradient of the global-pool bias chain (+ its deferred weight / bias gradients): dg (B, C) -> dpool (B, 3C)"""
+    def _gpool_bwd(self, i, blk, dg, g1, bpool, grads, pre, st, tr, side=None):
+        """input gradient of the global-pool bias chain (+ its deferred weight / bias gradients): dg (B, C) -> dpool (B, 3C).
+        `side` = (stream, event already recorded on the main stream): the chain launch goes to that stream behind the event
+        and self._gpool_done is the event to wait for before dpool / dg1 are read (KA_FC_BWD_SIDE=1, experiment)."""
         lin1, lin2 = blk.global_fc[0], blk.global_fc[2]
         B = dg.shape[0]
         if tr is not None:
             w2t, w1t = tr[i]
             dg1 = torch.empty(B, lin1.out_features, device=dg.device)
             dpool_x = torch.empty(B, lin1.in_features, device=dg.device)
-            _call("ka_fc_chain_bwd", dg, g1, w2t, w1t, dg1, dpool_x, B, lin2.out_features, lin1.out_features, lin1.in_features, st)
+            if side is not None:
+                sstream, ev = side
+                main = torch.cuda.current_stream(dg.device)
+                with torch.cuda.stream(sstream):
+                    sstream.wait_event(ev)
+                    _call("ka_fc_chain_bwd", dg, g1, w2t, w1t, dg1, dpool_x, B, lin2.out_features, lin1.out_features,
+                          lin1.in_features, _lib.stream_ptr(dg.device))
+                    done = torch.cuda.Event(); done.record(sstream)
+                for t in (dg, g1, dg1, dpool_x):
+                    t.record_stream(sstream)
+                self._gpool_done = done
+            else:
+                _call("ka_fc_chain_bwd", dg, g1, w2t, w1t, dg1, dpool_x, B, lin2.out_features, lin1.out_features, lin1.in_features, st)
             self._linear_bwd(dg, g1, lin2, grads, pre + "global_fc.2.weight", pre + "global_fc.2.bias", st, need_dx=False)
             self._linear_bwd(dg1, bpool, lin1, grads, pre + "global_fc.0.weight", pre + "global_fc.0.bias", st, need_dx=False)
             return dpool_x
@@ -580,6 +596,8 @@ class SEResNetEngine:
         # fork: their conv workgroups leave CUs free.
         fc_side = os.environ.get("KA_FC_SIDE")
         fside = self._wgrad_side(1, dev)[0] if (self.fork_fc and (fc_side == "1" or (fc_side is None and B < 512))) else None
+        # KA_FC_SIDE=2 (experiment): forked BEHIND conv1 instead -- eligible when conv1 has drained, i.e. beside the statistics kernels
+        flate = self._wgrad_side(1, dev)[0] if (fc_side == "2" and fside is None) else None
         main_f = torch.cuda.current_stream(dev)
         for i, blk in enumerate(m.blocks if tower_tab is None else ()):
             # g = global_fc(pool(x)) is only needed by conv2
@@ -597,13 +615,24 @@ class SEResNetEngine:
             bsum1 = torch.empty(B, C, device=dev); sq1 = torch.empty(rows, C, device=dev)
             self._timed("conv3x3", "ka_conv3x3_fwd", x, packs[f"blocks.{i}.conv1"][0], y1, None, None, None, 0,
                   bsum1 if train else None, sq1 if train else None, B, C, C, code, st)
+            if flate is not None:
+                ev = torch.cuda.Event(); ev.record(main_f)
+                with torch.cuda.stream(flate):
+                    flate.wait_event(ev)
+                    _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], _lib.stream_ptr(dev), keep)
+                    g_ready = torch.cuda.Event(); g_ready.record(flate)
+                pool.record_stream(flate); g.record_stream(main_f)
+                if g1 is not None:
+                    g1.record_stream(main_f)
             bn1_ctx = self._bn_forward_begin(blk.bn1, bsum1, B, sq1, rows, C, count, train, dev, st)
-            if fside is None:
+            if flate is not None:
+                pass
+            elif fside is None:
                 # on the main stream BEHIND conv1's statistics reduce: under SyncBatchNorm the chain (independent of bn1)
                 # runs while the layer's statistics all-reduce is on the wire
                 _, g1, g = self._fc_chain(pool, blk.global_fc[0], blk.global_fc[2], st, keep)
             sc1, sh1, mu1, is1 = self._bn_forward_end(bn1_ctx)
-            if fside is not None:
+            if fside is not None or flate is not None:
                 main_f.wait_event(g_ready)               # global-pool FC chain ran on the side stream beside conv1
             y2 = new_act(C)
             bsum2 = torch.empty(B, C, device=dev); sq2 = torch.empty(rows, C, device=dev)
@@ -796,6 +825,19 @@ class SEResNetEngine:
                 red.launch(bucket, f"conv[{i}:{i + bucket.numel() // per_block}]", ev)
                 bucket = None
 
+        fc_bwd_side = None
+        if os.environ.get("KA_FC_BWD_SIDE", "0") == "1" and fc_tr is not None and not self.overlap_wgrad:
+            if self._fc_side is None or self._fc_side.device != dev:
+                self._fc_side = torch.cuda.Stream(dev)
+            fc_bwd_side = self._fc_side
+        self._gpool_done = None
+
+        def gpool_join():
+            """the chain launch of the block above (side stream) must be done before its dpool / dg1 are read"""
+            if self._gpool_done is not None:
+                main.wait_event(self._gpool_done)
+                self._gpool_done = None
+
         # ---- tower, last block first
         for i in range(len(sv.blocks) - 1, -1, -1):
             blk = m.blocks[i]
@@ -806,6 +848,7 @@ class SEResNetEngine:
             dse = torch.empty(B, 2 * C, device=dev)
             dz = new_act()
             H = blk.se_fc1.weight.shape[0]
+            gpool_join()
             if pend is not None:
                 # (pend[3], the input of the block above, IS this block's output `out`)
                 dse1 = torch.empty(B, H, device=dev)
@@ -840,8 +883,14 @@ class SEResNetEngine:
                 self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
                 # the global-pool chain's backward (independent of bn1's coefficients) runs under bn1's statistics all-reduce
+                gside = None
+                if fc_bwd_side is not None:
+                    # (behind the weight-gradient launch: eligible when that has drained, i.e. beside the slab reduce and the
+                    #  statistics kernels, which leave the CUs to it)
+                    gev = torch.cuda.Event(); gev.record(main)
+                    gside = (fc_bwd_side, gev)
                 bn1_ctx = self._bn_backward_begin(blk.bn1, ep1, ep2, rows, C, count, train, dev, st)
-                dpool_x = self._gpool_bwd(i, blk, dg, g1, bpool, grads, pre, st, fc_tr)
+                dpool_x = self._gpool_bwd(i, blk, dg, g1, bpool, grads, pre, st, fc_tr, gside)
                 k1 = self._bn_backward_end(bn1_ctx, blk.bn1, C, count, mu1, is1, train, grads, pre + "bn1", dev, st)
                 dy1, dxc = new_act(), new_act()
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dh, y1, k1, dy1, packs[pre + "conv1"][1], dxc, None,
@@ -872,6 +921,7 @@ class SEResNetEngine:
             if fuse_dx and i > 0:
                 pend = (dxc, dout, out, bx, bpool, dpool_x, dx)        # joins the next block's tail
             else:
+                gpool_join()
                 _call("ka_block_dx", dxc, dout, out, bx, bpool, dpool_x, dx, B, C, code, st)
                 pend = None
             dout = dx

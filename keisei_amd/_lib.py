@@ -153,6 +153,7 @@ def _load() -> ctypes.CDLL:
 def reload_options() -> int:
     """The library reads its KA_* switches from the environment once (first launch).  A process that changes one afterwards
     -- tests, A/B tools flipping a kernel form in place -- calls this to have them read again; returns how many are set."""
+    _QUERIES.clear()
     return int(_load().ka_options_reload())
 
 
@@ -210,34 +211,67 @@ def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def call(name: str, *args) -> None:
-    """Call a status-returning entry point; raises KeiseiHipError with ka_last_error() on failure."""
+_PLANS: dict = {}      # name -> (bound ctypes function, indices of the pointer arguments, argument count)
+_Tensor = torch.Tensor
+_cur_dev = torch.cuda.current_device
+
+
+def _plan(name: str):
     lib = _load()
     sig = _SIGS[name].replace(" ", "")
-    if len(args) != len(sig):
-        raise TypeError(f"{name}: expected {len(sig)} arguments, got {len(args)}")
-    conv = [(_ptr(a) if c == "p" else a) for c, a in zip(sig, args)]
+    ent = (getattr(lib, name), tuple(i for i, c in enumerate(sig) if c == "p"), len(sig))
+    _PLANS[name] = ent
+    return ent
+
+
+def call(name: str, *args) -> None:
+    """Call a status-returning entry point; raises KeiseiHipError with ka_last_error() on failure.
+    (A step is ~1000 of these and small configurations are bound by the host's launch rate: the per-name work -- the cleaned
+    signature, the bound function -- is done once, the per-call work is one pass over the pointer arguments.)"""
+    ent = _PLANS.get(name)
+    if ent is None:
+        ent = _plan(name)
+    fn, ptr_idx, n = ent
+    if len(args) != n:
+        raise TypeError(f"{name}: expected {n} arguments, got {len(args)}")
+    conv = list(args)
+    dev = None
+    for i in ptr_idx:
+        a = conv[i]
+        if a is None:
+            continue
+        if type(a) is _Tensor or isinstance(a, _Tensor):
+            if dev is None and a.is_cuda:
+                dev = a.device.index
+            conv[i] = a.data_ptr()
+        else:
+            conv[i] = int(a)
     # launches go to the CURRENT device (and set per-device kernel attributes there): a model that lives on another
     # card than the current one (the reference places league opponents on a second GPU, katago_loop.py:371-422) is
     # launched under that card's device guard
-    dev = next((a.device.index for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
-    if dev is not None and dev != torch.cuda.current_device():
+    if dev is not None and dev != _cur_dev():
         with torch.cuda.device(dev):
             if _CHECK:
                 _check_tensors(name, args)
-            rc = getattr(lib, name)(*conv)
+            rc = fn(*conv)
     else:
         if _CHECK:
             _check_tensors(name, args)
-        rc = getattr(lib, name)(*conv)
+        rc = fn(*conv)
     if rc != 0:
-        raise KeiseiHipError(f"{name} failed ({rc}): {lib.ka_last_error().decode()}")
+        raise KeiseiHipError(f"{name} failed ({rc}): {_load().ka_last_error().decode()}")
+
+
+_QUERIES: dict = {}    # (name, args) -> value: the queries are pure functions of their (shape) arguments and of the KA_* switches
 
 
 def query(name: str, *args) -> int:
-    """Call an int-returning pure query (no status convention)."""
-    lib = _load()
-    return int(getattr(lib, name)(*args))
+    """Call an int-returning pure query (no status convention); results are remembered until reload_options()."""
+    key = (name, args)
+    v = _QUERIES.get(key)
+    if v is None:
+        v = _QUERIES[key] = int(getattr(_load(), name)(*args))
+    return v
 
 
 DTYPE_F32, DTYPE_BF16 = 0, 1

@@ -68,7 +68,7 @@ def test_default_line_carries_the_secondary_measurements():
     assert sec["whole_update"]["samples_per_s"] > 0 and sec["whole_update"]["store"] == "device"
     assert sec["whole_update"]["transitions"] == 128 * 128
     for k in ("workload_6x128", "transformer"):
-        assert sec[k]["samples_per_s"] > 0 and sec[k]["steps"] == 3 and "workload" in sec[k]
+        assert sec[k]["samples_per_s"] > 0 and 3 <= sec[k]["steps"] <= 20 and "workload" in sec[k]
         r = sec[k]["roofline"]
         assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 

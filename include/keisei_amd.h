@@ -117,6 +117,18 @@ int ka_bn_coeffs_parts(const double* part, double count, const float* gamma, con
                        float* shift, float* mean, float* invstd, int C, void* stream);
 int ka_bn_bwd_coeffs_parts(const double* part, double count, const float* gamma, const float* mean, const float* invstd,
                            float* dgamma, float* dbeta, float* k, int C, int train, void* stream);
+/* ... and the two steps as ONE launch (nn.BatchNorm2d's training statistics, se_resnet.py:51,53, and their autograd backward):
+ * ka_bn_reduce(sums = NULL) + ka_bn_coeffs_parts, ka_pair_reduce(sums = NULL) + ka_bn_bwd_coeffs_parts.  The workgroup that
+ * finishes a 64-channel column group last computes the group's coefficients from the 64 partial rows in slice order (same values
+ * as the two launches, bit for bit).  counters: (C + 63) / 64 ints, zero before the first use and left zero; one such launch at
+ * a time per (part, counters) pair. */
+int ka_bn_reduce_coeffs(const float* bsum, int B, const float* sqpart, int R, int C, double* part, int* counters, double count,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift, float* mean,
+                        float* invstd, void* stream);
+int ka_pair_reduce_bwd_coeffs(const float* p1, const float* p2, int rows, int C, double* part, int* counters, double count,
+                              const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k,
+                              int train, void* stream);
 int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, void* dy, int B, int C, int dtype, void* stream);
 int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C, void* stream);
 

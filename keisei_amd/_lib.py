@@ -34,6 +34,8 @@ _SIGS = {
     "ka_bn_coeffs": "p d p pppp p ff pppp i p",
     "ka_bn_coeffs_parts": "p d pppp p ff pppp i p",
     "ka_bn_bwd_coeffs_parts": "p d ppp ppp i i p",
+    "ka_bn_reduce_coeffs": "p i p i i pp d pppp p ff pppp p",
+    "ka_pair_reduce_bwd_coeffs": "pp i i pp d ppp ppp i p",
     "ka_bn_eval_coeffs": "pppp f pp i p",
     "ka_bn_bwd_coeffs": "pp d p ppp ppp i i p",
     "ka_affine_rows": "ppp f p ii p",

@@ -106,9 +106,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
 // Used for BN forward statistics (per-board sums + per-workgroup squares from the conv epilogue) and for the BN
 // backward sums (two per-board planes).
 constexpr int kRedSlices = 64;
-__global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __restrict__ A, int rowsA,
-                                                             const float* __restrict__ Bp, int rowsB, int C,
-                                                             double* __restrict__ part) {
+__device__ __forceinline__ void colsum2_stage1_body(const float* __restrict__ A, int rowsA, const float* __restrict__ Bp, int rowsB,
+                                                    int C, double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;
     const int slice = blockIdx.y * 4 + sub, nsl = kRedSlices * 4;
@@ -137,6 +136,31 @@ __global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __rest
         part[(size_t)blockIdx.y * 2 * C + C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
     }
 }
+__global__ __launch_bounds__(256) void colsum2_stage1_kernel(const float* __restrict__ A, int rowsA,
+                                                             const float* __restrict__ Bp, int rowsB, int C,
+                                                             double* __restrict__ part) {
+    colsum2_stage1_body(A, rowsA, Bp, rowsB, C, part);
+}
+// Stage 1 and the coefficient kernel that follows it in ONE launch: the workgroup that finishes a 64-channel column group LAST
+// (an arrival counter per group, reset by that workgroup for the next launch) computes the group's coefficients from the 64
+// partial rows, in slice order -- so the result does not depend on which workgroup that is.  The partials cross XCDs (each has
+// its own L2): every workgroup publishes its row with a device-scope release fence before it arrives, the last one acquires
+// before it reads.  164 launches (and as many launch boundaries) less per training step.
+__device__ __forceinline__ bool colsum2_arrive_last(int* __restrict__ counters) {
+    __shared__ int is_last;
+    __syncthreads();                                         // this workgroup's partial row is written
+    if (threadIdx.x == 0) {
+        __threadfence();                                     // release: the row is visible device-wide before the arrival is
+        const int prev = atomicAdd(&counters[blockIdx.x], 1);
+        is_last = prev == (int)gridDim.y - 1;
+        if (is_last) counters[blockIdx.x] = 0;               // (nobody else touches it until the next launch)
+    }
+    __syncthreads();
+    if (!is_last) return false;
+    __threadfence();                                         // acquire: the other workgroups' rows
+    return true;
+}
+
 // training-mode coefficients: y_hat*gamma+beta == x*scale+shift.  Updates running stats like
 // nn.BatchNorm2d (momentum form, unbiased running variance).
 // `sums` is either the reduced [2C] vector (nparts == 1) or the stage-1 partials [nparts][2C], summed here in slice order
@@ -176,12 +200,14 @@ __global__ void colsum2_stage2_sync_kernel(const double* __restrict__ part, doub
     if (local_copy) local_copy[c] = s;
 }
 
-__global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
-                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                 float* running_var, long long* num_batches_tracked, float momentum, float eps,
-                                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-                                 float* __restrict__ invstd_out, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_coeffs_body(int c, const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                               float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                               float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                               float* __restrict__ invstd_out, int C) {
+    // (inlined into two kernels: without this the compiler is free to contract a*b+c differently in each, and the running
+    //  statistics of the one-launch and two-launch paths drift apart by an ulp)
+#pragma clang fp contract(off)
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (c >= C) return;
     if (count_dev) count = *count_dev;          // global element count after a cross-rank all-reduce
@@ -199,6 +225,26 @@ __global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, do
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+}
+__global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                 float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                 float* __restrict__ invstd_out, int C) {
+    bn_coeffs_body(blockIdx.x * blockDim.x + threadIdx.x, sums, nparts, count, count_dev, gamma, beta, running_mean, running_var,
+                   num_batches_tracked, momentum, eps, scale, shift, mean_out, invstd_out, C);
+}
+__global__ __launch_bounds__(256) void colsum2_bn_coeffs_kernel(const float* __restrict__ A, int rowsA, const float* __restrict__ Bp, int rowsB,
+                                                                int C, double* part, int* __restrict__ counters, double count,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                                                float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    colsum2_stage1_body(A, rowsA, Bp, rowsB, C, part);
+    if (!colsum2_arrive_last(counters)) return;
+    if (threadIdx.x < 64)
+        bn_coeffs_body(blockIdx.x * 64 + threadIdx.x, part, kRedSlices, count, nullptr, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, momentum, eps, scale, shift, mean_out, invstd_out, C);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -229,12 +275,12 @@ __global__ void bn_eval_coeffs_multi_kernel(const long long* __restrict__ table)
 }
 
 // dgamma/dbeta from the LOCAL sums; dy = k1*dz + k2 + k3*y from the (possibly all-reduced) sums
-__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
-                                     int nparts, double count, const double* __restrict__ count_dev,
-                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                     const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ k, int C, int train) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_bwd_coeffs_body(int c, const double* __restrict__ sums_local, const double* __restrict__ sums_global,
+                                                   int nparts, double count, const double* __restrict__ count_dev,
+                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, float* __restrict__ k, int C, int train) {
+#pragma clang fp contract(off)
     if (c >= C) return;
     if (count_dev) count = *count_dev;
     // nparts > 1: both pointers are the same stage-1 partials (no cross-rank reduction in between)
@@ -247,6 +293,24 @@ __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, cons
     const double k3 = train ? -g * is * is * g2 / count : 0.0;
     const double k2 = train ? -g * is * g1 / count - k3 * mu : 0.0;
     k[c] = (float)k1; k[C + c] = (float)k2; k[2 * C + c] = (float)k3;
+}
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
+                                     int nparts, double count, const double* __restrict__ count_dev,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ k, int C, int train) {
+    bn_bwd_coeffs_body(blockIdx.x * blockDim.x + threadIdx.x, sums_local, sums_global, nparts, count, count_dev, gamma, mean, invstd,
+                       dgamma, dbeta, k, C, train);
+}
+__global__ __launch_bounds__(256) void colsum2_bn_bwd_coeffs_kernel(const float* __restrict__ A, const float* __restrict__ Bp, int rows, int C,
+                                                                    double* part, int* __restrict__ counters, double count,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ k, int train) {
+    colsum2_stage1_body(A, rows, Bp, rows, C, part);
+    if (!colsum2_arrive_last(counters)) return;
+    if (threadIdx.x < 64)
+        bn_bwd_coeffs_body(blockIdx.x * 64 + threadIdx.x, part, part, kRedSlices, count, nullptr, gamma, mean, invstd, dgamma, dbeta, k, C, train);
 }
 
 // out[b,c] = a[c]*in[b,c]*mul + s[c]     (SE squeeze of the normalised conv2 output)
@@ -1077,6 +1141,30 @@ extern "C" int ka_bn_bwd_coeffs_parts(const double* part, double count, const fl
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), part, part,
                        kRedSlices, count, nullptr, gamma, mean, invstd, dgamma, dbeta, k, C, train);
     return ka_check_launch("bn_bwd_coeffs_parts");
+}
+
+// ka_bn_reduce(sums = NULL) + ka_bn_coeffs_parts in one launch (colsum2_bn_coeffs_kernel).  counters: (C + 63) / 64 ints, zero before
+// the first use (the kernel leaves them zero); part as ka_bn_reduce.  One such launch at a time per (part, counters) pair.
+extern "C" int ka_bn_reduce_coeffs(const float* bsum, int B, const float* sqpart, int R, int C, double* part, int* counters,
+                                   double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
+                                   float* mean, float* invstd, void* stream) {
+    KA_REQUIRE(bsum && sqpart && part && counters && gamma && beta && scale && shift && mean && invstd && count > 0,
+               "bn_reduce_coeffs: bad arguments");
+    hipLaunchKernelGGL(colsum2_bn_coeffs_kernel, dim3((C + 63) / 64, kRedSlices), dim3(256), 0, static_cast<hipStream_t>(stream), bsum, B,
+                       sqpart, R, C, part, counters, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                       scale, shift, mean, invstd);
+    return ka_check_launch("bn_reduce_coeffs");
+}
+
+// ka_pair_reduce(sums = NULL) + ka_bn_bwd_coeffs_parts in one launch (colsum2_bn_bwd_coeffs_kernel); counters / part as above
+extern "C" int ka_pair_reduce_bwd_coeffs(const float* p1, const float* p2, int rows, int C, double* part, int* counters, double count,
+                                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                         float* k, int train, void* stream) {
+    KA_REQUIRE(p1 && p2 && part && counters && gamma && mean && invstd && k && count > 0, "pair_reduce_bwd_coeffs: bad arguments");
+    hipLaunchKernelGGL(colsum2_bn_bwd_coeffs_kernel, dim3((C + 63) / 64, kRedSlices), dim3(256), 0, static_cast<hipStream_t>(stream), p1, p2,
+                       rows, C, part, counters, count, gamma, mean, invstd, dgamma, dbeta, k, train);
+    return ka_check_launch("pair_reduce_bwd_coeffs");
 }
 
 extern "C" int ka_affine_rows(const float* in, const float* a, const float* s, float mul, float* out, int B, int C,

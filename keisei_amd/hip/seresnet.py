@@ -73,6 +73,10 @@ class SEResNetEngine:
         self.fork_fc = os.environ.get("KA_FC_FORK", "1") != "0"      # small-batch forward: global-pool FC chain beside conv1
         self._fc_side = None
         self._gpool_done = None
+        self._redcnt = None
+        # BatchNorm statistics: stage-1 reduce and coefficient kernel as one launch (KA_BN_ONE_LAUNCH=1; measured 0.8 % slower than
+        # the two launches -- the device-scope fences of 256 workgroups cost more than a launch boundary -- so off by default)
+        self.bn_one_launch = os.environ.get("KA_BN_ONE_LAUNCH", "0") == "1"
         self._in_forward = False
         self.kernel_events = None       # bench.py: {"conv3x3": [...], "wgrad": [...]} event pairs per launch
         self.weights_epoch = 0          # bumped by the fused optimiser (raw-pointer updates bypass _version)
@@ -103,6 +107,12 @@ class SEResNetEngine:
         if self._redws is None or self._redws.numel() < n or self._redws.device != device:
             self._redws = torch.empty(n, dtype=torch.float64, device=device)
         return self._redws
+
+    def _red_counters(self, device) -> torch.Tensor:
+        """arrival counters of the one-launch statistics kernels (zero between launches: the kernels reset them)"""
+        if self._redcnt is None or self._redcnt.device != device:
+            self._redcnt = torch.zeros(64, dtype=torch.int32, device=device)
+        return self._redcnt
 
     def _wgrad_side(self, n: int, device):
         """(side stream, partial-slab buffer) of the weight-gradient GEMMs.  In backward they are issued on a second
@@ -285,6 +295,8 @@ class SEResNetEngine:
             sums = torch.empty(2 * C + 1, dtype=torch.float64, device=device)
             _call("ka_sync_reduce", bsum, rows_b, sq, rows_s, C, float(count), sums, None, ws, st)
             work = self._allreduce_async(sums)
+        elif self.bn_one_launch and C <= 64 * 64:
+            return (bn, None, None, (ws, bsum, rows_b, sq, rows_s), C, count, train, device, st)     # one launch, in _bn_forward_end
         else:
             _call("ka_bn_reduce", bsum, rows_b, sq, rows_s, C, None, ws, st)     # stage 1 only: partials stay in ws
         return (bn, sums, work, ws, C, count, train, device, st)
@@ -310,6 +322,10 @@ class SEResNetEngine:
             self._allreduce_wait(work)
             _call("ka_bn_coeffs", sums, float(count), sums[2 * C:], bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
                   scale, shift, mean, invstd, C, st)
+        elif isinstance(ws, tuple):
+            ws, bsum, rows_b, sq, rows_s = ws
+            _call("ka_bn_reduce_coeffs", bsum, rows_b, sq, rows_s, C, ws, self._red_counters(device), float(count), bn.weight, bn.bias,
+                  rm, rv, nbt, momentum, float(bn.eps), scale, shift, mean, invstd, st)
         else:
             _call("ka_bn_coeffs_parts", ws, float(count), bn.weight, bn.bias, rm, rv, nbt, momentum, float(bn.eps),
                   scale, shift, mean, invstd, C, st)
@@ -683,6 +699,8 @@ class SEResNetEngine:
             gsums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
             _call("ka_sync_reduce", s1p, rows, s2p, rows, C, float(count), gsums, sums, ws, st)
             return (sums, gsums, self._allreduce_async(gsums), ws)
+        if self.bn_one_launch and C <= 64 * 64:
+            return (None, None, None, (ws, s1p, s2p, rows))                  # one launch, in _bn_backward_end
         _call("ka_pair_reduce", s1p, s2p, rows, C, None, ws, st)             # stage 1 only: partials stay in ws
         return (None, None, None, ws)
 
@@ -694,6 +712,10 @@ class SEResNetEngine:
             self._allreduce_wait(work)
             _call("ka_bn_bwd_coeffs", sums, gsums, float(count), gsums[2 * C:], bn.weight, mu, istd, dgam, dbet, k, C,
                   1 if train else 0, st)
+        elif isinstance(ws, tuple):
+            ws, s1p, s2p, rows = ws
+            _call("ka_pair_reduce_bwd_coeffs", s1p, s2p, rows, C, ws, self._red_counters(dev), float(count), bn.weight, mu, istd,
+                  dgam, dbet, k, 1 if train else 0, st)
         else:
             _call("ka_bn_bwd_coeffs_parts", ws, float(count), bn.weight, mu, istd, dgam, dbet, k, C, 1 if train else 0, st)
         grads[prefix + ".weight"], grads[prefix + ".bias"] = dgam, dbet

@@ -680,6 +680,38 @@ def test_bn_coefficients_from_partials_match_two_step_path():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,R,C", [(37, 5, 64), (515, 129, 256), (4096, 256, 256), (300, 300, 96), (64, 3, 32)])
+def test_bn_statistics_in_one_launch_equal_the_two_launches(B, R, C):
+    """ka_bn_reduce_coeffs / ka_pair_reduce_bwd_coeffs (stage-1 reduce + coefficients by the last-arriving workgroup of a column
+    group) == ka_bn_reduce / ka_pair_reduce (sums = NULL) + ka_*_coeffs_parts, every output bit for bit -- repeated back to back
+    on changing inputs, so that a workgroup that read a partial row before it was published would show."""
+    g = torch.Generator().manual_seed(B + C)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    count = float(B * 81)
+    ws_a = torch.empty(_lib.query("ka_reduce_workspace_doubles", C), dtype=torch.float64, device=DEV)
+    ws_b = torch.full_like(ws_a, float("nan"))
+    cnt = torch.zeros(64, dtype=torch.int32, device=DEV)
+    rm_a, rv_a, rm_b, rv_b = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt_a, nbt_b = torch.zeros((), dtype=torch.int64, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    for it in range(40):
+        bsum = torch.randn(B, C, generator=g).to(DEV); sq = ((torch.rand(R, C, generator=g) + 1.0) * 81 * B / R).to(DEV)
+        a = [torch.empty(C, device=DEV) for _ in range(4)]; b = [torch.full((C,), float("nan"), device=DEV) for _ in range(4)]
+        _lib.call("ka_bn_reduce", bsum, B, sq, R, C, None, ws_a, st())
+        _lib.call("ka_bn_coeffs_parts", ws_a, count, gamma, beta, rm_a, rv_a, nbt_a, 0.1, 1e-5, *a, C, st())
+        _lib.call("ka_bn_reduce_coeffs", bsum, B, sq, R, C, ws_b, cnt, count, gamma, beta, rm_b, rv_b, nbt_b, 0.1, 1e-5, *b, st())
+        s1, s2 = torch.randn(B, C, generator=g).to(DEV), torch.randn(B, C, generator=g).to(DEV)
+        ka = [torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(3 * C, device=DEV)]
+        kb = [torch.full_like(t, float("nan")) for t in ka]
+        _lib.call("ka_pair_reduce", s1, s2, B, C, None, ws_a, st())
+        _lib.call("ka_bn_bwd_coeffs_parts", ws_a, count, gamma, a[2], a[3], *ka, C, 1, st())
+        _lib.call("ka_pair_reduce_bwd_coeffs", s1, s2, B, C, ws_b, cnt, count, gamma, b[2], b[3], *kb, 1, st())
+        torch.cuda.synchronize()
+        for name, x, y in zip(("scale", "shift", "mean", "invstd", "dgamma", "dbeta", "k"), a + ka, b + kb):
+            assert torch.equal(x, y), (it, name)
+        assert int(cnt.abs().sum()) == 0, "arrival counters must be back at zero after every launch"
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and int(nbt_a) == int(nbt_b) == 40
+
+
 @pytest.mark.parametrize("dtn,B,cin,cout", [("f32", 1, 48, 48), ("f32", 2, 96, 80), ("bf16", 7, 96, 32), ("bf16", 1, 64, 96)])
 def test_conv3x3_odd_shapes(dtn, B, cin, cout):
     """single boards, channel counts that are not powers of two (chunking by a divisor of Cin, a lone last output tile)"""

@@ -282,8 +282,8 @@ def test_bf16_backward_tracks_fp32_gradients():
 def test_backward_schedules_give_identical_gradients(monkeypatch, amp):
     """The backward's launch schedule is a choice, not arithmetic: weight gradients on the main stream (default) or on a second
     stream (KA_WGRAD_OVERLAP=1), block boundaries as one launch (default) or two (KA_DX_TAIL=0), the global-pool FC chains on the
-    main stream (default) or forked beside the statistics kernels (KA_FC_SIDE=2, KA_FC_BWD_SIDE=1) -- every parameter gradient
-    bit for bit the same."""
+    main stream (default) or forked beside the statistics kernels (KA_FC_SIDE=2, KA_FC_BWD_SIDE=1), BatchNorm statistics as two
+    launches (default) or one (KA_BN_ONE_LAUNCH=1) -- every parameter gradient bit for bit the same."""
     shape = orc.NetShape(3, 64, 8, 32, 16, 64, 32)
     sd = orc.init_like_state_dict(shape)
     g = torch.Generator().manual_seed(11)
@@ -292,8 +292,8 @@ def test_backward_schedules_give_identical_gradients(monkeypatch, amp):
     cp, cv, cs = torch.randn(B, 9, 9, 139, generator=g).to(DEV), torch.randn(B, 3, generator=g).to(DEV), torch.randn(B, 1, generator=g).to(DEV)
     grads = {}
     for name, env in (("default", {}), ("two streams", {"KA_WGRAD_OVERLAP": "1"}), ("two launches", {"KA_DX_TAIL": "0"}),
-                      ("forked chains", {"KA_FC_SIDE": "2", "KA_FC_BWD_SIDE": "1"})):
-        for k in ("KA_WGRAD_OVERLAP", "KA_DX_TAIL", "KA_FC_SIDE", "KA_FC_BWD_SIDE"):
+                      ("forked chains", {"KA_FC_SIDE": "2", "KA_FC_BWD_SIDE": "1"}), ("one-launch statistics", {"KA_BN_ONE_LAUNCH": "1"})):
+        for k in ("KA_WGRAD_OVERLAP", "KA_DX_TAIL", "KA_FC_SIDE", "KA_FC_BWD_SIDE", "KA_BN_ONE_LAUNCH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -306,7 +306,7 @@ def test_backward_schedules_give_identical_gradients(monkeypatch, amp):
         ((o.policy_logits * cp).sum() / B + (o.value_logits * cv).sum() + (o.score_lead * cs).sum()).backward()
         torch.cuda.synchronize()
         grads[name] = {n: prm.grad.clone() for n, prm in m.named_parameters()}
-    for name in ("two streams", "two launches", "forked chains"):
+    for name in ("two streams", "two launches", "forked chains", "one-launch statistics"):
         for n, ref in grads["default"].items():
             assert torch.equal(grads[name][n], ref), (name, n)
 

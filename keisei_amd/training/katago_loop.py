@@ -223,7 +223,9 @@ class PendingTransitions:
         """Settle the open slots selected by `finalize_mask` (games without an open slot are skipped).  Returns None when
         there is nothing to settle, else a dict with rows in game order: obs, actions, log_probs, values, rewards, dones,
         terminated (floats), legal_masks, score_targets, env_ids -- plus legal_mask_bits and value_cats.  `accumulate`: this
-        step's learner rewards, added first (accumulate_reward() folded into the same launch)."""
+        step's learner rewards, added first (accumulate_reward() folded into the same launch).
+        On the device the rows are views into two persistent column sets used in turn: a settled batch stays valid until the
+        finalize() after the next one (the loop hands it to the rollout store at once, as the reference does, katago_loop.py:1523)."""
         if self._gpu:
             return self._settle_device(finalize_mask, dones, terminated, accumulate)
         if accumulate is not None:
@@ -247,10 +249,18 @@ class PendingTransitions:
         flags_f32 = int(dones.dtype == torch.float32 and terminated.dtype == torch.float32)
         as_flag = (lambda t: t.to(device=dev, dtype=torch.float32).contiguous()) if flags_f32 else \
                   (lambda t: (t != 0).to(device=dev).contiguous())
-        e = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device=dev)
-        o = dict(obs=e(n, *self.obs.shape[1:]), legal_mask_bits=e(n, self._words, dtype=torch.int32), actions=e(n, dtype=torch.long),
-                 log_probs=e(n), values=e(n), rewards=e(n), dones=e(n), terminated=e(n), score_targets=e(n),
-                 env_ids=e(n, dtype=torch.long), value_cats=e(n, dtype=torch.long))
+        # the output columns are two persistent sets used in turn (no num_envs-row allocations per call, and the [:k]
+        # views handed out do not pin fresh full-size blocks): a settled batch stays valid until the finalize AFTER the next one
+        sets = getattr(self, "_out_sets", None)
+        if sets is None:
+            e = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device=dev)
+            sets = self._out_sets = [dict(obs=e(n, *self.obs.shape[1:]), legal_mask_bits=e(n, self._words, dtype=torch.int32),
+                                          actions=e(n, dtype=torch.long), log_probs=e(n), values=e(n), rewards=e(n), dones=e(n),
+                                          terminated=e(n), score_targets=e(n), env_ids=e(n, dtype=torch.long),
+                                          value_cats=e(n, dtype=torch.long)) for _ in range(2)]
+            self._out_flip = 0
+        o = sets[self._out_flip]
+        self._out_flip ^= 1
         nxt = self._cur ^ 1
         _lib.call("ka_pending_settle", self.obs, self.legal_mask_bits, self.actions, self.log_probs, self.values, self.rewards,
                   self.score_targets, self._valid[self._cur], self._valid[nxt],

@@ -212,6 +212,9 @@ int ka_fc_chain_bwd(const float* dy, const float* hidden, const float* W2T, cons
                     int M, int N2, int H, int K1, void* stream);
 int ka_transpose_multi(const void* table, int n, int max_tiles, void* stream);
 int ka_reduce_slabs(const float* slab, float* out, int nsplit, long long n, int accumulate, void* stream);
+/* two slab sets of one split count in one launch (a layer's weight- and bias-gradient partials); same sums, same order */
+int ka_reduce_slabs2(const float* slab_a, float* out_a, long long na, const float* slab_b, float* out_b, long long nb, int nsplit,
+                     void* stream);
 int ka_colsum(const float* A, const float* Bm, float* part, float* part2, int M, int N, int nsplit, void* stream);
 int ka_relu_mask(float* g, const float* h, long long n, void* stream);
 /* policy-head BatchNorm over fp32 rows (M = B*81, N = policy_channels; se_resnet.py:121,144) */
@@ -399,6 +402,11 @@ int ka_tf_gemm_tn_bias(const void* A, const void* B, float* C, float* colsum, in
 int ka_tf_gemm_tn_slabs(int M, int nsplit);
 int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int ldi, int ldo, int dtype, void* stream);
 int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream);
+/* the bf16 operand copies of n nn.Linear weights (transformer.py:37-52: in_proj / out_proj / linear1 / linear2 of every encoder
+ * layer, policy_fc) in one launch and from one read of each weight: table rows {W fp32 (N, K), out (N, ldo) bf16, outT (K, ldt) bf16,
+ * N, K, ldo, ldt, first tile}, ldo % 8 == 0, ldt % 8 == 0; total_tiles = sum of ceil(ldt / 64) * ceil(ldo / 64).
+ * Same values as ka_tf_cast_pad + ka_tf_transpose_pad per layer. */
+int ka_tf_weights16_multi(const void* table, int n, int total_tiles, void* stream);
 /* x[b,s,:] += row_embed[s/9] + col_embed[s%9] (transformer.py:84-87) and the embedding gradients (scratch: 65*81*d floats) */
 int ka_tf_add_pos(void* x, const float* row_embed, const float* col_embed, int B, int d, int dtype, void* stream);
 int ka_tf_pos_grad(const void* dx, float* scratch, float* drow, float* dcol, int B, int d, int dtype, void* stream);

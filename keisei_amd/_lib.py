@@ -53,6 +53,7 @@ _SIGS = {
     "ka_block_dx_tail_bwd_du": "ppppp p ppppppppp p pppp iii i p",
     "ka_gemm": "pppp iii iii ii iii i i i p",
     "ka_reduce_slabs": "pp i q i p",
+    "ka_reduce_slabs2": "pp q pp q i p",
     "ka_colsum": "pppp ii i p",
     "ka_relu_mask": "pp q p",
     "ka_rows_affine_relu": "pppp q i p",
@@ -97,6 +98,7 @@ _SIGS = {
     "ka_tf_gemm_tn_slabs": "ii",
     "ka_tf_transpose_pad": "pp iiii i p",
     "ka_tf_cast_pad": "pp q iii i p",
+    "ka_tf_weights16_multi": "p ii p",
     "ka_tf_add_pos": "ppp ii i p",
     "ka_tf_pos_grad": "pppp ii i p",
     "ka_tf_layernorm_fwd": "pppppp q i f i p",

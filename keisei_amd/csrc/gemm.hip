@@ -322,7 +322,15 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __res
                                     int accumulate) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {                      // (eight partials in flight, added in order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; ++k) s += slab[(size_t)k * n + i];
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -583,6 +591,37 @@ extern "C" int ka_reduce_slabs(const float* slab, float* out, int nsplit, long l
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid1d((size_t)n, 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), slab, out, nsplit, (size_t)n, accumulate);
     return ka_check_launch("reduce_slabs");
+}
+
+// two slab sets of one split count in one launch (a linear layer's weight- and bias-gradient partials): out_a[i] = sum_s slab_a[s*na + i],
+// out_b likewise -- the same sums in the same order as two ka_reduce_slabs calls
+__global__ void reduce_slabs2_kernel(const float* __restrict__ sa, float* __restrict__ oa, size_t na, const float* __restrict__ sb,
+                                     float* __restrict__ ob, size_t nb, int nsplit) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+        const bool first = i < na;
+        const float* __restrict__ sl = first ? sa : sb;
+        const size_t n = first ? na : nb, j = first ? i : i - na;
+        // (eight partials requested before the first is added: as a rolled loop every split was an L2 round trip of its own;
+        //  the additions keep their order)
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sl[(size_t)(k + u) * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; ++k) s += sl[(size_t)k * n + j];
+        (first ? oa : ob)[j] = s;
+    }
+}
+extern "C" int ka_reduce_slabs2(const float* slab_a, float* out_a, long long na, const float* slab_b, float* out_b, long long nb,
+                                int nsplit, void* stream) {
+    KA_REQUIRE(slab_a && out_a && slab_b && out_b && nsplit >= 1 && na > 0 && nb > 0, "reduce_slabs2: bad arguments");
+    hipLaunchKernelGGL(reduce_slabs2_kernel, dim3(grid1d((size_t)(na + nb), 2048)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       slab_a, out_a, (size_t)na, slab_b, out_b, (size_t)nb, nsplit);
+    return ka_check_launch("reduce_slabs2");
 }
 
 // part (and part2) must hold nsplit*N floats; rows are split evenly over nsplit slices

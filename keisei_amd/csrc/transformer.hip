@@ -755,6 +755,60 @@ __global__ void cast_pad_kernel(const T* __restrict__ in, uint16_t* __restrict__
     }
 }
 
+// The bf16 weight cache of every linear layer in ONE launch: for each fp32 weight W (N, K) both copies the GEMMs read -- W as
+// [N][ldo] (ldo >= K, pad columns zero) and W^T as [K][ldt] (ldt >= N, pad columns zero) -- from one read of W.  As 2 x 27 launches
+// of cast_pad_kernel / transpose_pad_kernel (scalar accesses, W read twice: the policy layer alone is 933 MB per read) this was
+// 1.15 ms of a 38 ms step.  table[j] = {W, out, outT, N, K, ldo, ldt, first tile of the job}; a workgroup owns a 64 x 64 tile:
+// 16-byte pieces in, 16-byte pieces out both ways (the transpose through LDS).  Same rounding as the single kernels (f2bf).
+__global__ __launch_bounds__(256) void weights16_multi_kernel(const long long* __restrict__ table, int njobs) {
+    int lo = 0, hi = njobs - 1;                    // last job whose first tile is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)table[(size_t)mid * 8 + 7] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* t = table + (size_t)lo * 8;
+    const float* __restrict__ W = reinterpret_cast<const float*>(t[0]);
+    uint16_t* __restrict__ out = reinterpret_cast<uint16_t*>(t[1]);
+    uint16_t* __restrict__ outT = reinterpret_cast<uint16_t*>(t[2]);
+    const int N = (int)t[3], K = (int)t[4], ldo = (int)t[5], ldt = (int)t[6];
+    const int ktiles = (ldo + 63) / 64, local = (int)blockIdx.x - (int)t[7];
+    const int n0 = (local / ktiles) * 64, k0 = (local % ktiles) * 64;
+    __shared__ uint16_t tile[64][64 + 2];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (tid >> 3) + 32 * h, pc = tid & 7;            // row n, 8 columns k
+        const int n = n0 + row, k = k0 + pc * 8;
+        float f[8];
+        if (n < N && k + 8 <= K && (K & 3) == 0) {            // (rows are 16-byte aligned only when K % 4 == 0)
+            const f32x4 a = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k), b = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (n < N && k + e < K) ? W[(size_t)n * K + k + e] : 0.f;
+        }
+        uint4 v;
+        uint16_t* e16 = reinterpret_cast<uint16_t*>(&v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { e16[e] = f2bf(f[e]); tile[row][pc * 8 + e] = e16[e]; }
+        if (n < N && k < ldo) *reinterpret_cast<uint4*>(out + (size_t)n * ldo + k) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = (tid >> 3) + 32 * h, pc = tid & 7;            // output row k, 8 columns n
+        const int k = k0 + col, n = n0 + pc * 8;
+        if (k < K && n < ldt) {
+            uint4 v;
+            uint16_t* e16 = reinterpret_cast<uint16_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) e16[e] = tile[pc * 8 + e][col];
+            *reinterpret_cast<uint4*>(outT + (size_t)k * ldt + n) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ positional embedding
 // x[b, s, :] += row_embed[s / 9] + col_embed[s % 9]     (transformer.py:84-87)
 template <typename T>
@@ -1993,6 +2047,15 @@ extern "C" int ka_tf_transpose_pad(const void* in, void* out, int M, int N, int 
     KA_TF_DISPATCH(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                                              static_cast<const T*>(in), static_cast<uint16_t*>(out), M, N, ldi, ldo));
     return ka_check_launch("tf_transpose_pad");
+}
+// the bf16 weight cache of n linear layers in one launch (weights16_multi_kernel): table rows {W fp32 (N, K) row-major, out (N, ldo)
+// bf16, outT (K, ldt) bf16, N, K, ldo, ldt, first tile}; K % 4 == 0, ldo % 8 == 0, ldt % 8 == 0, every pointer 16-byte aligned;
+// total_tiles = sum over the jobs of ceil(ldt / 64) * ceil(ldo / 64)
+extern "C" int ka_tf_weights16_multi(const void* table, int n, int total_tiles, void* stream) {
+    KA_REQUIRE(table && n > 0 && total_tiles > 0, "tf_weights16_multi: bad arguments");
+    hipLaunchKernelGGL(weights16_multi_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const long long*>(table), n);
+    return ka_check_launch("tf_weights16_multi");
 }
 extern "C" int ka_tf_cast_pad(const void* in, void* out, long long M, int N, int ldi, int ldo, int dtype, void* stream) {
     KA_REQUIRE(in && out && ldo >= N, "tf_cast_pad: bad arguments");

@@ -41,6 +41,7 @@ class TransformerEngine:
         self.model = model
         self._w16: Dict[str, tuple] = {}
         self._w16_key = None
+        self._w16_table = None          # (weight pointers, device job table, jobs, tiles) of ka_tf_weights16_multi
         self.weights_epoch = 0
         self._scratch: Dict[str, torch.Tensor] = {}
 
@@ -66,6 +67,7 @@ class TransformerEngine:
         if key == self._w16_key:
             return self._w16
         st = _lib.stream_ptr(device)
+        fresh = False
         for name, w, _ in lins:
             N, K = w.shape
             ent = self._w16.get(name)
@@ -73,8 +75,28 @@ class TransformerEngine:
                 ent = (torch.empty(N, _r32(K), dtype=torch.bfloat16, device=device),
                        torch.empty(K, _r32(N), dtype=torch.bfloat16, device=device))
                 self._w16[name] = ent
-            _call("ka_tf_cast_pad", w, ent[0], N, K, K, _r32(K), _lib.DTYPE_F32, st)
-            _call("ka_tf_transpose_pad", w, ent[1], N, K, K, _r32(N), _lib.DTYPE_F32, st)
+                fresh = True
+        multi = (os.environ.get("KA_TF_W16_MULTI", "1") != "0"
+                 and all(w.is_contiguous() and w.dtype == torch.float32 for _, w, _ in lins))
+        if multi:
+            # every layer's two copies in ONE launch, from one read of the weight (ka_tf_weights16_multi)
+            ptrs = tuple(w.data_ptr() for _, w, _ in lins)
+            tab = self._w16_table
+            if tab is None or fresh or tab[0] != ptrs or tab[1].device != device:
+                rows, first = [], 0
+                for name, w, _ in lins:
+                    N, K = w.shape
+                    o, oT = self._w16[name]
+                    rows.append([w.data_ptr(), o.data_ptr(), oT.data_ptr(), N, K, o.shape[1], oT.shape[1], first])
+                    first += ((oT.shape[1] + 63) // 64) * ((o.shape[1] + 63) // 64)
+                tab = self._w16_table = (ptrs, torch.tensor(rows, dtype=torch.int64).to(device), len(rows), first)
+            _call("ka_tf_weights16_multi", tab[1], tab[2], tab[3], st)
+        else:
+            for name, w, _ in lins:
+                N, K = w.shape
+                ent = self._w16[name]
+                _call("ka_tf_cast_pad", w, ent[0], N, K, K, _r32(K), _lib.DTYPE_F32, st)
+                _call("ka_tf_transpose_pad", w, ent[1], N, K, K, _r32(N), _lib.DTYPE_F32, st)
         self._w16_key = key
         return self._w16
 
@@ -130,8 +152,7 @@ class TransformerEngine:
                 slab = self._buf("slab", ns * N * K, torch.float32, dev)
                 cs = self._buf("colsum", ns * N, torch.float32, dev)
                 _call("ka_tf_gemm_tn_bias", dy, x, slab, cs, M, N, K, N, x.shape[1], K, want, st)
-                _call("ka_reduce_slabs", slab, dW, ns, N * K, 0, st)
-                _call("ka_reduce_slabs", cs, db, ns, N, 0, st)
+                _call("ka_reduce_slabs2", slab, dW, N * K, cs, db, N, ns, st)       # weight- and bias-gradient partials in one launch
         else:
             nsb = max(1, min(1024, (M + 255) // 256))
             part = self._buf("colsum", nsb * N, torch.float32, dev)

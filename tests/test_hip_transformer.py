@@ -189,6 +189,37 @@ def test_transpose_and_cast_pad():
     assert torch.equal(out[:, :45].cpu(), x.bfloat16()) and float(out[:, 45:].abs().max()) == 0
 
 
+def test_weight_cache_in_one_launch_equals_the_per_layer_copies():
+    """ka_tf_weights16_multi (both bf16 copies of every layer from one read of the weight) == ka_tf_cast_pad + ka_tf_transpose_pad per
+    layer, pad columns included; shapes with ragged 64-tiles and pad columns on both copies.  ka_reduce_slabs2 == two ka_reduce_slabs."""
+    g = torch.Generator().manual_seed(3)
+    r32 = lambda v: (v + 31) // 32 * 32
+    shapes = [(768, 256), (256, 256), (1024, 256), (256, 1024), (70, 44), (139, 2592), (11, 4), (256, 50), (33, 7)]
+    ws = [torch.randn(N, K, generator=g).to(DEV) for N, K in shapes]
+    ref, got, rows, first = [], [], [], 0
+    for w in ws:
+        N, K = w.shape
+        a = torch.full((N, r32(K)), 7.0, dtype=torch.bfloat16, device=DEV); b = torch.full((K, r32(N)), 7.0, dtype=torch.bfloat16, device=DEV)
+        _lib.call("ka_tf_cast_pad", w, a, N, K, K, r32(K), _lib.DTYPE_F32, st())
+        _lib.call("ka_tf_transpose_pad", w, b, N, K, K, r32(N), _lib.DTYPE_F32, st())
+        ref.append((a, b))
+        c = torch.full_like(a, 9.0); d = torch.full_like(b, 9.0)
+        got.append((c, d))
+        rows.append([w.data_ptr(), c.data_ptr(), d.data_ptr(), N, K, r32(K), r32(N), first])
+        first += ((r32(N) + 63) // 64) * ((r32(K) + 63) // 64)
+    _lib.call("ka_tf_weights16_multi", torch.tensor(rows, dtype=torch.int64).to(DEV), len(rows), first, st())
+    torch.cuda.synchronize()
+    for (a, b), (c, d), shp in zip(ref, got, shapes):
+        assert torch.equal(a, c) and torch.equal(b, d), shp
+    ns, na, nb = 7, 1000, 37
+    sa, sb = torch.randn(ns, na, generator=g).to(DEV), torch.randn(ns, nb, generator=g).to(DEV)
+    oa, ob, pa, pb = (torch.empty(n, device=DEV) for n in (na, nb, na, nb))
+    _lib.call("ka_reduce_slabs", sa, oa, ns, na, 0, st()); _lib.call("ka_reduce_slabs", sb, ob, ns, nb, 0, st())
+    _lib.call("ka_reduce_slabs2", sa, pa, na, sb, pb, nb, ns, st())
+    torch.cuda.synchronize()
+    assert torch.equal(oa, pa) and torch.equal(ob, pb)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_layernorm_forward_backward(dt):
     M, d = 243, 64

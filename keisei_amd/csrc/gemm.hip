@@ -217,8 +217,10 @@ struct ChainArgs {
     float* y;            // (M,N2)
     int M, K1, ldx, H, N2;
     const float* hmask;  // optional (M,H): hidden = (W1 x') * [hmask > 0], no bias, no ReLU -- the backward of a chain (ReLU mask of the saved hidden)
+    unsigned long long* stamps;   // diagnostic only (ka_debug_conv_stamps + a -DKA_DIAG_FC_TL build, tools/_diag/fc_chain_tl.py): per-wave phase stamps
 };
 
+constexpr int kFcBatch = 12;     // weight pieces of a wave in flight together (48 registers)
 __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int xs_ld = a.K1 + 4, hs_ld = a.H + 4;
@@ -227,6 +229,20 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
     float* part = hs + 16 * hs_ld;            // [ksplit][16][H]   (only when H/16 < 8)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * 16;
+#ifdef KA_DIAG_FC_TL
+#define KA_FTL(ph) do { if (a.stamps && blockIdx.x % 100 == 0 && blockIdx.x < 300 && lane == 0) \
+        a.stamps[((blockIdx.x / 100) * 8 + wave) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KA_FTL(ph) do {} while (0)
+#endif
+    KA_FTL(0);
+    float touch = 0.f;       // (kept alive to the kernel's last statement, so that nothing waits for these reads on their own)
+    // ---- the phase-2 weights start their way into the L2 now (one 4-byte read per 64-byte piece, spread over the workgroup,
+    // results discarded): phase 2 then finds them there instead of paying a fabric trip per tile
+    {
+        const size_t w2_pieces = ((size_t)a.N2 * a.H * sizeof(float) + 63) / 64;
+        for (size_t i = tid; i < w2_pieces; i += 512) touch += a.W2[i * 16];
+    }
     // ---- stage x' (rows beyond M repeat the last row; their results are never stored)
     const int k4n = a.K1 >> 2;
     for (int i = tid; i < 16 * k4n; i += 512) {
@@ -242,7 +258,9 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
         }
         *reinterpret_cast<f32x4*>(xs + row * xs_ld + c4) = v;
     }
+    KA_FTL(1);
     __syncthreads();
+    KA_FTL(2);
     // ---- phase 1: hidden = relu(x' W1^T + b1)
     const int T1 = a.H >> 4;
     const int ksplit = T1 >= 8 ? 1 : 8 / T1;            // T1 in {1,2,4} -> 8,4,2 K ranges per tile
@@ -254,12 +272,23 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             const float* xrow = xs + r * xs_ld + 4 * q;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const int kbeg = kp * klen, kend = kbeg + klen;
-#pragma unroll 4
-            for (int k = kbeg; k < kend; k += 16) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + k);
-                const f32x4 av = *reinterpret_cast<const f32x4*>(xrow + k);
+            // The weights of a layer are NOT in the L2 when its chain kernel starts (a step's worth of 170 MB tensors has passed
+            // since; tools/_diag/fc_chain_cold.py times the kernel that way).  The pieces go out kFcBatch at a time, then the MFMAs
+            // run on them in k order (same products, same order: bit-identical): 4 trips instead of 12 for the 768-wide chain --
+            // cold, with the touch above, 38 -> 32 us; the per-wave stamps (tools/_diag/fc_chain_tl.py) still show phase 1 at ~27 k
+            // cycles against 9 k of exact-f32 matrix work, with one or four accumulators per tile alike (NOTES_r04 section 17).
+            for (int k0 = kbeg; k0 < kend; k0 += 16 * kFcBatch) {
+                f32x4 bv[kFcBatch];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+                for (int u = 0; u < kFcBatch; ++u)
+                    if (k0 + 16 * u < kend) bv[u] = *reinterpret_cast<const f32x4*>(wrow + k0 + 16 * u);
+#pragma unroll
+                for (int u = 0; u < kFcBatch; ++u) {
+                    if (k0 + 16 * u >= kend) break;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(xrow + k0 + 16 * u);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[u][i], acc, 0, 0, 0);
+                }
             }
             // acc lane (r, q), element i: hidden[m = 4q+i][n = 16 tile + r]
             if (ksplit == 1) {
@@ -276,7 +305,9 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             }
         }
     }
+    KA_FTL(3);
     __syncthreads();
+    KA_FTL(4);
     if (ksplit > 1) {
         for (int i = tid; i < 16 * a.H; i += 512) {
             const int row = i / a.H, n = i - row * a.H;
@@ -292,6 +323,7 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             const int row = i / a.H, n = i - row * a.H;
             if (m0 + row < a.M) a.hidden_out[(size_t)(m0 + row) * a.H + n] = hs[row * hs_ld + n];
         }
+    KA_FTL(5);
     // ---- phase 2: y = hidden W2^T + b2
     const int T2 = (a.N2 + 15) >> 4;
     for (int tile = wave; tile < T2; tile += 8) {
@@ -299,12 +331,18 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
         const float* wrow = a.W2 + (size_t)n * a.H + 4 * q;
         const float* hrow = hs + r * hs_ld + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k = 0; k < a.H; k += 16) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(wrow + k);
-            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k);
+        for (int k0 = 0; k0 < a.H; k0 += 16 * kFcBatch) {      // (as phase 1: the tile's weight pieces in one trip)
+            f32x4 bv[kFcBatch];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+            for (int u = 0; u < kFcBatch; ++u)
+                if (k0 + 16 * u < a.H) bv[u] = *reinterpret_cast<const f32x4*>(wrow + k0 + 16 * u);
+#pragma unroll
+            for (int u = 0; u < kFcBatch; ++u) {
+                if (k0 + 16 * u >= a.H) break;
+                const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k0 + 16 * u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[u][i], acc, 0, 0, 0);
+            }
         }
         if (tile * 16 + r < a.N2) {
             const float bias = a.b2 ? a.b2[n] : 0.f;
@@ -315,6 +353,9 @@ __global__ __launch_bounds__(512) void fc_chain_kernel(ChainArgs a) {
             }
         }
     }
+    KA_FTL(6);
+#undef KA_FTL
+    if (touch == 1.2345678e38f && a.hidden_out) a.hidden_out[0] = touch;        // (never true: see `touch`)
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s*n + i]
@@ -521,7 +562,7 @@ extern "C" int ka_fc_chain(const float* x, const float* in_scale, const float* i
     KA_REQUIRE(lds <= 160 * 1024, "fc_chain: LDS %zu B", lds);
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&fc_chain_kernel), attr_done, "fc_chain")) return rc;
-    ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2, nullptr};
+    ChainArgs a{x, in_scale, in_shift, in_alpha, W1, b1, W2, b2, x_out, hidden_out, y, M, K1, ldx, H, N2, nullptr, ka_debug_stamps().load()};
     hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("fc_chain");
 }
@@ -545,7 +586,7 @@ extern "C" int ka_fc_chain_bwd(const float* dy, const float* hidden, const float
     KA_REQUIRE(lds <= 160 * 1024, "fc_chain_bwd: LDS %zu B", lds);
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&fc_chain_kernel), attr_done, "fc_chain_bwd")) return rc;
-    ChainArgs a{dy, nullptr, nullptr, 1.f, W2T, nullptr, W1T, nullptr, nullptr, dhidden_out, dx, M, N2, N2, H, K1, hidden};
+    ChainArgs a{dy, nullptr, nullptr, 1.f, W2T, nullptr, W1T, nullptr, nullptr, dhidden_out, dx, M, N2, N2, H, K1, hidden, ka_debug_stamps().load()};
     hipLaunchKernelGGL(fc_chain_kernel, dim3((M + 15) / 16), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     return ka_check_launch("fc_chain_bwd");
 }

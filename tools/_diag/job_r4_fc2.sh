@@ -1,0 +1,9 @@
+#!/bin/bash
+root=$(pwd); out=$root/gpurun_out; mkdir -p $out
+for r in 1 2; do
+  for v in base fcu8 fcu16; do
+    lib=keisei_amd/libka_$v.so; [ $v = base ] && lib=keisei_amd/libkeisei_amd.so
+    echo "== $v"; KEISEI_AMD_LIB=$PWD/$lib timeout -k 10 120 python tools/_diag/fc_chain_cold.py 2>&1 | grep -v amdgpu
+  done
+done > $out/r4_fc_cold.txt 2>&1
+cat $out/r4_fc_cold.txt

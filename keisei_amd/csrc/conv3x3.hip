@@ -1037,6 +1037,67 @@ __device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32
     }
 }
 
+// The corner tile's epilogue inside conv3x3_pc2_kernel (ConvArgs::mt5 == 2): lane (r, q) holds, for channel tile j, the four
+// channels cb[j] .. + 3 of square 80 of board bb.  conv3x3_corner_kernel's epilogue statement for statement -- the per-board sums
+// the tower part of this kernel stored for squares 0..79 receive the corner's terms from the lane that owns (bb, cb[j]); they were
+// stored by another lane of THIS wave (row 0 of the board's tiles): the caller waits for those stores, then the terms are added at the L2.
+// 16 bytes straight from the L2 (sc1: device-coherent, past the CU's vector cache, which may hold a line from before this wave's
+// own stores to it): requested here, complete after corner_wait().  What was measured instead: an acquire fence in front of plain
+// loads costs 7-10 us per launch, fp32 atomic adds at the L2 (global_atomic_add_f32, 16-32 per lane) 15-45 us.
+__device__ __forceinline__ f32x4 ld4_l2_request(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void corner_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) :: "memory");
+}
+__device__ __forceinline__ void corner_tile_epilogue(const ConvArgs& a, const f32x4 (&acc)[2], int bb, bool live, int nt0, int q) {
+    if (!live) return;
+    int cb[2];
+    f32x4 pbs[2], psq[2], ps1[2], ps2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                            // every sum this lane will add to, requested together
+        cb[j] = chan_of(nt0 + j, 4 * q, 16);
+        const size_t srow = (size_t)bb * 256 + cb[j];
+        pbs[j] = psq[j] = ps1[j] = ps2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bsum) pbs[j] = ld4_l2_request(a.bsum + srow);
+        if (a.sqpart) psq[j] = ld4_l2_request(a.sqpart + srow);
+        if (a.ep_y) { ps1[j] = ld4_l2_request(a.ep_s1 + srow); ps2[j] = ld4_l2_request(a.ep_s2 + srow); }
+    }
+    corner_wait(pbs[0], pbs[1], psq[0], psq[1], ps1[0], ps1[1]);
+    corner_wait(ps2[0], ps2[1], psq[0], psq[1], ps1[0], ps1[1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x4 v = acc[j];
+        const size_t orow = ((size_t)bb * KA_BOARD + 80) * 256 + cb[j], srow = (size_t)bb * 256 + cb[j];
+        if (a.bsum) *reinterpret_cast<f32x4*>(a.bsum + srow) = pbs[j] + v;
+        if (a.sqpart) *reinterpret_cast<f32x4*>(a.sqpart + srow) = psq[j] + f32x4{v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]};
+        bf16x4 o;
+        if (!a.ep_y) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        } else {
+            // da = dh * [bn(y) > 0] and its BatchNorm-backward terms (conv_epilogue's masked branch, term for term)
+            const f32x4 esc = *reinterpret_cast<const f32x4*>(a.ep_scale + cb[j]), esh = *reinterpret_cast<const f32x4*>(a.ep_shift + cb[j]);
+            const f32x4 emu = *reinterpret_cast<const f32x4*>(a.ep_mean + cb[j]), eis = *reinterpret_cast<const f32x4*>(a.ep_invstd + cb[j]);
+            const bf16x4 yv = *reinterpret_cast<const bf16x4*>(static_cast<const char*>(a.ep_y) + orow * 2);
+            f32x4 t1, t2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (float)yv[e];
+                const __bf16 db = (__bf16)v[e];
+                const float d = (y * esc[e] + esh[e] > 0.f) ? (float)db : 0.f;
+                t1[e] = d; t2[e] = d * ((y - emu[e]) * eis[e]);
+                o[e] = (__bf16)d;
+            }
+            *reinterpret_cast<f32x4*>(a.ep_s1 + srow) = ps1[j] + t1;
+            *reinterpret_cast<f32x4*>(a.ep_s2 + srow) = ps2[j] + t2;
+        }
+        *reinterpret_cast<bf16x4*>(static_cast<char*>(a.out) + orow * 2) = o;
+    }
+}
+
 // ---------------------------------------------------------------- two boards per weight fragment (bf16, Cin = Cout = 256)
 // What paces conv3x3_pc_kernel is not the matrix pipe but the weight stream: every (board, chunk) unit pulls its 590 KB of
 // fragments out of the L2 again -- 4.8 GB per launch at B = 4096, i.e. 15 TB/s through a path that delivers about 70 GB/s per
@@ -1051,6 +1112,11 @@ __device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32
 constexpr int kP2Stride = 64 * 2 + 32;                                  // bytes per square of a 64-channel image: 16 fragment lanes on 16 bank slots
 constexpr int kP2Img = kImgSquares1 * kP2Stride;                        // 28 960 B
 constexpr int kP2Lds = 4 * kP2Img;                                      // [buffer][board]
+// in-kernel corner (ConvArgs::mt5 == 2): behind the images, nine pair slots x two boards of [4 corner squares][256 channels] bf16 --
+// the rows of the corner tile -- and a 16-byte dump slot for the staging lanes that hold no corner square
+constexpr int kP2SideRow = 4 * 512 + 16;                                // as kCornerStride: 16 fragment lanes on 16 bank slots
+constexpr int kP2SideSlots = 9;
+constexpr int kP2Side = kP2Lds, kP2Dump = kP2Side + 2 * kP2SideSlots * kP2SideRow, kP2LdsCorner = kP2Dump + 16;
 constexpr int kP2Base = (kPW + 1) * kP2Stride;                          // the most negative tap offset, folded into the row base
 
 // ---- border tiles (SKIP).  A tap that steps off the board multiplies the zero halo: 104 of the 729 (square, tap) products of a
@@ -1202,6 +1268,20 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
         }
         // round k of this wave has pieces at all?  (NP = 256: the sixth round is sixteen lanes of the first staging wave)
         auto live = [&](int k) { return (swave * 64 + NP * k) < kPieces; };
+        // in-kernel corner: a piece of squares 70, 71, 79, 80 (taps 0, 1, 3, 4 of square 80) is ALSO written, transformed as it is,
+        // into the pair's slot of the side buffer; cso[k]: its offset inside the slot, -1 for every other piece (which writes the
+        // dump slot instead: the store itself stays unconditional)
+        const bool corner_in = C == 256 && MT == 5 && a.mt5 == 2;
+        int cso[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int row = min((pt + NP * k) >> 3, 2 * KA_BOARD - 1), j = row >= KA_BOARD ? 1 : 0, sq = row - j * KA_BOARD;
+            const int ps = sq == 70 ? 0 : sq == 71 ? 1 : sq == 79 ? 2 : sq == 80 ? 3 : -1;
+            cso[k] = (corner_in && ps >= 0 && pt + NP * k < kPieces) ? j * kP2SideRow + ps * 512 + pc * 16 : -1;
+        }
+        int chas = 0;                                            // bit k: some lane of this wave holds a corner piece in round k
+#pragma unroll
+        for (int k = 0; k < KP; ++k) chas |= (__builtin_amdgcn_readfirstlane((int)(__ballot(cso[k] >= 0) != 0ull)) & 1) << k;
         bf16x8 pv[KP], pw[TWO ? KP : 1];
         auto stage_load = [&](int u) {
             const int b0 = 2 * ((int)blockIdx.x + (u / NCH) * nwg), c4 = u % NCH;
@@ -1263,7 +1343,24 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 *reinterpret_cast<bf16x8*>(img + ldso[k]) = v;
             }
         };
-        auto stage = [&](int u) { stage_load(u); stage_write(u); };
+        // in-kernel corner: the lanes that just wrote a piece of a corner square copy it (their own LDS write, read back in order) into
+        // the pair's slot of the side buffer -- pair (u / NCH) of this workgroup, nine slots in turn, the chunk's 128 bytes inside a
+        // square; every other lane moves 16 bytes of its piece to the dump slot.  (A loop of its own: a second store per piece inside
+        // stage_write makes the compiler spill ~900 bytes per lane across the whole kernel.)
+        auto side_write = [&](int u) {
+            if constexpr (C == 256 && MT == 5) {
+                if (!corner_in) return;
+                const char* img = smem + (u & 1) * (2 * kP2Img);
+                const int side0 = kP2Side + 2 * ((u / NCH) % kP2SideSlots) * kP2SideRow + (u % NCH) * 128;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    if (!live(k) || !((chas >> k) & 1)) continue;        // (wave-uniform: this wave holds a corner piece in round k)
+                    const bf16x8 t = *reinterpret_cast<const bf16x8*>(img + ldso[k]);
+                    *reinterpret_cast<bf16x8*>(smem + (cso[k] >= 0 ? side0 + cso[k] : kP2Dump)) = t;
+                }
+            }
+        };
+        auto stage = [&](int u) { stage_load(u); stage_write(u); side_write(u); };
         stage(0);
         KA_LDS_BARRIER();
         if constexpr (STAG) {
@@ -1272,6 +1369,7 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 stage_load(v);
                 KA_LDS_BARRIER();
                 stage_write(v);
+                side_write(v);
                 KA_LDS_BARRIER();
             }
             KA_LDS_BARRIER();
@@ -1385,6 +1483,42 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[0]), b0, wave * 2, NTILE, r, q);
                 if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[MT]), b0 + 1, wave * 2, NTILE, r, q);
             }
+            if constexpr (C == 256 && MT == 5 && !SKIP && !STAG) {
+                // ---- in-kernel corner (mt5 == 2): square 80 of the boards of up to eight pairs is ONE more row tile.  Its rows --
+                // taps 0, 1, 3, 4 of the square, 256 channels, transformed -- were left in the side buffer by the staging waves,
+                // which at this point wait at the unit's barrier (the pair they staged last went into the ninth slot).  Every MFMA
+                // wave pulls the tile's 64 weight fragments twelve-less-four steps ahead and runs 64 MFMAs in the order of
+                // conv3x3_corner_kernel, (128-channel chunk, tap, k-step): out[b, 80, :] and the sums are bit-identical to that kernel's.
+                const int pidx = u / NCH;
+                if (a.mt5 == 2 && ((pidx & 7) == 7 || pidx == npairs - 1)) {
+                    const int g0 = pidx & ~7;
+                    const int pr = g0 + (r >> 1), prc = min(pr, pidx);
+                    const char* arow = smem + kP2Side + (2 * (prc % kP2SideSlots) + (r & 1)) * kP2SideRow + q * 16;
+                    auto cw = [&](int step, bf16x8 (&f)[2]) {
+                        const int ps = (step >> 2) & 3, tap = ps < 2 ? ps : ps + 1, ks = (step >> 4) * 4 + (step & 3);
+                        const int so = __builtin_amdgcn_readfirstlane(((tap * KSG + ks) * NTILE) * 1024);
+                        f[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+                        f[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
+                    };
+                    constexpr int kAh = 8;
+                    bf16x8 wq[kAh][2];
+#pragma unroll
+                    for (int s2 = 0; s2 < kAh; ++s2) cw(s2, wq[s2]);
+                    f32x4 cacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int step = 0; step < 32; ++step) {
+                        const bf16x8 w0 = wq[step % kAh][0], w1 = wq[step % kAh][1];
+                        if (step + kAh < 32) cw(step + kAh, wq[step % kAh]);
+                        const int ps = (step >> 2) & 3, ks = (step >> 4) * 4 + (step & 3);
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(arow + ps * 512 + ks * 64);
+                        cacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af, cacc[0], 0, 0, 0);
+                        cacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af, cacc[1], 0, 0, 0);
+                    }
+                    const int bb = 2 * ((int)blockIdx.x + pr * nwg) + (r & 1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sums of squares 0..79 this wave stored have reached the L2
+                    corner_tile_epilogue(a, cacc, bb, pr <= pidx && bb < a.B, wave * 2, q);
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NRB; ++t) rowbase[t] += (u & 1) ? -2 * kP2Img : 2 * kP2Img;
@@ -1401,7 +1535,8 @@ static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* w
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
     if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), done, what)) return rc;
     const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
-    hipLaunchKernelGGL((conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3((C / 32 + NPW) * 64), kP2Lds, st, a);
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3((C / 32 + NPW) * 64),
+                       C == 256 ? kP2LdsCorner : kP2Lds, st, a);       // (the 256-channel forms always carry the side buffer: their staging stores are unconditional)
     return ka_check_launch(what);
 }
 static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
@@ -1600,9 +1735,12 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         // data gradient with the register-only epilogue; 3 (default) + the masked epilogue
         const int p2 = ka_opt(KA_OPT_CONV_PC2, 3);
         if (p2 != 0 && want5 && pv != 0 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3)) {
-            a.mt5 = 1;
+            // square 80: as one more row tile inside the kernel (mt5 = 2, KA_CONV_CORNER_IN) or by conv3x3_corner_kernel behind it
+            const bool corner_in = ka_opt(KA_OPT_CONV_CORNER_IN, 1) != 0 && ka_opt(KA_OPT_CONV_PC2_SKIP, 0) == 0 &&
+                                   ka_opt(KA_OPT_CONV_PC2_STAG, 0) == 0;
+            a.mt5 = corner_in ? 2 : 1;
             if (int rc = launch_conv_pc2(a, st)) return rc;
-            return launch_conv_corner(a, st);
+            return corner_in ? KA_OK : launch_conv_corner(a, st);
         }
         if (p2 != 0 && pv != 0 && a.Cin == 128 && a.Cout == 128 && a.B >= 512 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3))
             return launch_conv_pc2(a, st);

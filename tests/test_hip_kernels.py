@@ -905,6 +905,47 @@ def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(ka_env, B):
         assert not ref[0].float().isnan().any()
 
 
+@pytest.mark.parametrize("B", [512, 515, 1024, 4096, 4302, 9000])
+def test_in_kernel_corner_equals_the_corner_launch(ka_env, B):
+    """KA_CONV_CORNER_IN=1: square 80 of up to eight board pairs as one more row tile inside conv3x3_pc2_kernel (rows left in the side
+    buffer by the staging waves) == conv3x3_corner_kernel launched behind it: outputs, the written-back dy and every per-board sum bit
+    for bit, all four launch kinds.  Board counts: a half-empty last pair (515), exactly eight pairs per workgroup (4096), nine in
+    some (4302: a second, one-pair group and the ninth side slot), more than two groups (9000)."""
+    C = 256
+    g = torch.Generator(device=DEV).manual_seed(B + 11)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, x2, yprev = (rnd(B, 81, C).to(torch.bfloat16) for _ in range(3))
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, _lib.stream_ptr())
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    gb = rnd(B, C) * 0.1
+    k3 = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+
+    def run(kind):
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        out, dyo = nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16)
+        bsum, sq, e1, e2 = nan(B, C), nan(B, C), nan(B, C), nan(B, C)
+        st = _lib.stream_ptr()
+        if kind == 0: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st)
+        if kind == 1: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, gb, 1, bsum, sq, B, C, C, 1, st)
+        if kind == 2: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st)
+        if kind == 3: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st)
+        torch.cuda.synchronize()
+        return out, dyo, bsum, sq, e1, e2
+
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    for kind in range(4):
+        ka_env.set("KA_CONV_CORNER_IN", "0")
+        ref = run(kind)
+        ka_env.set("KA_CONV_CORNER_IN", "1")
+        got = run(kind)
+        assert not bool(ref[0].float().isnan().any()), kind
+        for name, a, b in zip(("out", "dy", "bsum", "sqpart", "ep_s1", "ep_s2"), ref, got):
+            assert same(a.float(), b.float()), (kind, name)
+
+
 @pytest.mark.parametrize("B,C", [(515, 256), (1024, 256), (4096, 256), (515, 128), (2048, 128)])
 def test_two_board_conv_equals_the_one_board_forms_up_to_reassociation(ka_env, B, C):
     """conv3x3_pc2_kernel (two boards per weight fragment: the default for the forward forms and the plain-epilogue data gradient at

@@ -642,8 +642,8 @@ def main() -> None:
             ev_ms_step = 1e3 * res["events_elapsed"] / res["events_steps"]
             two_streams = os.environ.get("KA_WGRAD_OVERLAP", "0") != "0"
             roof = {"bound": "mfma", "kernel": "conv3x3_pc2_kernel (implicit-GEMM 3x3 conv, two boards per weight fragment: squares 0..79 of both as ten row "
-                                               "tiles, square 80 of the workgroup's 16 boards as one more tile inside the kernel -- conv3x3_corner_kernel behind "
-                                               "it under KA_CONV_CORNER_IN=0; forward and data-gradient launches, the "
+                                               "tiles, square 80 of the workgroup's 16 boards as one more tile inside the kernel -- by conv3x3_corner_kernel behind "
+                                               "the masked form; forward and data-gradient launches, the "
                                                "latter with the fused BatchNorm-backward input and -- behind conv2 -- the masked epilogue" + (", concurrent with wgrad on a 2nd stream)" if two_streams else ")"),
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_note, "launches_timed": len(conv_ms), "avg_launch_ms": round(avg, 4),

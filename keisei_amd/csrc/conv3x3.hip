@@ -1041,32 +1041,46 @@ __device__ __forceinline__ void conv_epilogue_masked_pair(const ConvArgs& a, f32
 // channels cb[j] .. + 3 of square 80 of board bb.  conv3x3_corner_kernel's epilogue statement for statement -- the per-board sums
 // the tower part of this kernel stored for squares 0..79 receive the corner's terms from the lane that owns (bb, cb[j]); they were
 // stored by another lane of THIS wave (row 0 of the board's tiles): the caller waits for those stores, then the terms are added at the L2.
-// 16 bytes straight from the L2 (sc1: device-coherent, past the CU's vector cache, which may hold a line from before this wave's
-// own stores to it): requested here, complete after corner_wait().  What was measured instead: an acquire fence in front of plain
-// loads costs 7-10 us per launch, fp32 atomic adds at the L2 (global_atomic_add_f32, 16-32 per lane) 15-45 us.
-__device__ __forceinline__ f32x4 ld4_l2_request(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void corner_wait(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) :: "memory");
+// Eight 16-byte reads straight from the L2 (sc1: device-coherent, past the CU's vector cache, which may hold a line from before this
+// wave's own stores to it), requested together and complete when the statement ends -- ONE asm statement, so that the compiler
+// cannot place a spill of a destination between its load and the wait (it does not know these loads are in flight).  What was
+// measured instead: an acquire fence in front of plain loads costs 7-10 us per launch, fp32 atomic adds at the L2
+// (global_atomic_add_f32, 16-32 per lane) 15-45 us.
+__device__ __forceinline__ void ld4x8_l2(const float* const (&p)[8], f32x4 (&v)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
 }
 __device__ __forceinline__ void corner_tile_epilogue(const ConvArgs& a, const f32x4 (&acc)[2], int bb, bool live, int nt0, int q) {
     if (!live) return;
     int cb[2];
     f32x4 pbs[2], psq[2], ps1[2], ps2[2];
+    {   // every sum this lane will add to, in one go (an array the launch does not carry reads the board's bsum / weight-pack line instead)
+        const float* any = a.bsum ? a.bsum : reinterpret_cast<const float*>(a.wpack);
+        const float* src[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                            // every sum this lane will add to, requested together
-        cb[j] = chan_of(nt0 + j, 4 * q, 16);
-        const size_t srow = (size_t)bb * 256 + cb[j];
-        pbs[j] = psq[j] = ps1[j] = ps2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bsum) pbs[j] = ld4_l2_request(a.bsum + srow);
-        if (a.sqpart) psq[j] = ld4_l2_request(a.sqpart + srow);
-        if (a.ep_y) { ps1[j] = ld4_l2_request(a.ep_s1 + srow); ps2[j] = ld4_l2_request(a.ep_s2 + srow); }
+        for (int j = 0; j < 2; ++j) {
+            cb[j] = chan_of(nt0 + j, 4 * q, 16);
+            const size_t srow = (size_t)bb * 256 + cb[j];
+            src[j] = a.bsum ? a.bsum + srow : any;
+            src[2 + j] = a.sqpart ? a.sqpart + srow : any;
+            src[4 + j] = a.ep_y ? a.ep_s1 + srow : any;
+            src[6 + j] = a.ep_y ? a.ep_s2 + srow : any;
+        }
+        f32x4 got[8];
+        ld4x8_l2(src, got);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { pbs[j] = got[j]; psq[j] = got[2 + j]; ps1[j] = got[4 + j]; ps2[j] = got[6 + j]; }
     }
-    corner_wait(pbs[0], pbs[1], psq[0], psq[1], ps1[0], ps1[1]);
-    corner_wait(ps2[0], ps2[1], psq[0], psq[1], ps1[0], ps1[1]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const f32x4 v = acc[j];
@@ -1736,7 +1750,10 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         const int p2 = ka_opt(KA_OPT_CONV_PC2, 3);
         if (p2 != 0 && want5 && pv != 0 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3)) {
             // square 80: as one more row tile inside the kernel (mt5 = 2, KA_CONV_CORNER_IN) or by conv3x3_corner_kernel behind it
-            const bool corner_in = ka_opt(KA_OPT_CONV_CORNER_IN, 1) != 0 && ka_opt(KA_OPT_CONV_PC2_SKIP, 0) == 0 &&
+            // (KA_CONV_CORNER_IN: 1, default = the forward forms and the plain-epilogue data gradient; 2 = the masked form too, which
+            //  measures 5-7 us slower that way -- its tile epilogue reads eight sums back; 0 = the launch everywhere)
+            const int cin = ka_opt(KA_OPT_CONV_CORNER_IN, 1);
+            const bool corner_in = cin != 0 && (cin >= 2 || !a.ep_y) && ka_opt(KA_OPT_CONV_PC2_SKIP, 0) == 0 &&
                                    ka_opt(KA_OPT_CONV_PC2_STAG, 0) == 0;
             a.mt5 = corner_in ? 2 : 1;
             if (int rc = launch_conv_pc2(a, st)) return rc;

@@ -11,6 +11,6 @@ cat $out/r4cin_standalone.txt
 run() { timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fp32 --no-secondary 2>/dev/null | tail -1 | cut -c1-130; }
 for r in 1 2 3; do
   echo "corner launch"; KA_CONV_CORNER_IN=0 run
-  echo "in-kernel corner"; KA_CONV_CORNER_IN=1 run
+  echo "in-kernel corner (default: not the masked form)"; run
 done > $out/r4cin_ab.txt
 cat $out/r4cin_ab.txt

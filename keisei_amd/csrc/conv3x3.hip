@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
         // in-kernel corner: a piece of squares 70, 71, 79, 80 (taps 0, 1, 3, 4 of square 80) is ALSO written, transformed as it is,
         // into the pair's slot of the side buffer; cso[k]: its offset inside the slot, -1 for every other piece (which writes the
         // dump slot instead: the store itself stays unconditional)
-        const bool corner_in = C == 256 && MT == 5 && a.mt5 == 2;
+        const bool corner_in = C == 256 && MT == 5 && !MASKED && a.mt5 == 2;
         int cso[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
@@ -1497,8 +1497,9 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[0]), b0, wave * 2, NTILE, r, q);
                 if (b0 + 1 < a.B) conv_epilogue<bf16_t, 2, MT>(a, reinterpret_cast<f32x4 (&)[MT][2]>(acc[MT]), b0 + 1, wave * 2, NTILE, r, q);
             }
-            if constexpr (C == 256 && MT == 5 && !SKIP && !STAG) {
-                // ---- in-kernel corner (mt5 == 2): square 80 of the boards of up to eight pairs is ONE more row tile.  Its rows --
+            if constexpr (C == 256 && MT == 5 && !SKIP && !STAG && !MASKED) {
+                // ---- in-kernel corner (mt5 == 2; not compiled into the masked form: there it measured 6 us slower than the launch,
+                // and its registers cost that form another 52 bytes of scratch per lane): square 80 of the boards of up to eight pairs is ONE more row tile.  Its rows --
                 // taps 0, 1, 3, 4 of the square, 256 channels, transformed -- were left in the side buffer by the staging waves,
                 // which at this point wait at the unit's barrier (the pair they staged last went into the ninth slot).  Every MFMA
                 // wave pulls the tile's 64 weight fragments twelve-less-four steps ahead and runs 64 MFMAs in the order of
@@ -1750,10 +1751,9 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         const int p2 = ka_opt(KA_OPT_CONV_PC2, 3);
         if (p2 != 0 && want5 && pv != 0 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3)) {
             // square 80: as one more row tile inside the kernel (mt5 = 2, KA_CONV_CORNER_IN) or by conv3x3_corner_kernel behind it
-            // (KA_CONV_CORNER_IN: 1, default = the forward forms and the plain-epilogue data gradient; 2 = the masked form too, which
-            //  measures 5-7 us slower that way -- its tile epilogue reads eight sums back; 0 = the launch everywhere)
-            const int cin = ka_opt(KA_OPT_CONV_CORNER_IN, 1);
-            const bool corner_in = cin != 0 && (cin >= 2 || !a.ep_y) && ka_opt(KA_OPT_CONV_PC2_SKIP, 0) == 0 &&
+            // (KA_CONV_CORNER_IN: 1, default = inside the forward forms and the plain-epilogue data gradient; 0 = the launch everywhere.
+            //  The masked form keeps the launch: inside, its tile epilogue -- eight sums read back -- measured 5-7 us slower)
+            const bool corner_in = ka_opt(KA_OPT_CONV_CORNER_IN, 1) != 0 && !a.ep_y && ka_opt(KA_OPT_CONV_PC2_SKIP, 0) == 0 &&
                                    ka_opt(KA_OPT_CONV_PC2_STAG, 0) == 0;
             a.mt5 = corner_in ? 2 : 1;
             if (int rc = launch_conv_pc2(a, st)) return rc;

@@ -939,7 +939,7 @@ def test_in_kernel_corner_equals_the_corner_launch(ka_env, B):
     for kind in range(4):
         ka_env.set("KA_CONV_CORNER_IN", "0")
         ref = run(kind)
-        ka_env.set("KA_CONV_CORNER_IN", "2")                  # (2: the masked form too; the default, 1, leaves that one to the launch)
+        ka_env.set("KA_CONV_CORNER_IN", "1")                  # (the default; the masked form, kind 2, keeps the launch either way)
         got = run(kind)
         assert not bool(ref[0].float().isnan().any()), kind
         for name, a, b in zip(("out", "dy", "bsum", "sqpart", "ep_s1", "ep_s2"), ref, got):

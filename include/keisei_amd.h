@@ -51,6 +51,13 @@ int ka_options_reload(void);
 int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, const float* in_scale, const float* in_shift,
                    const float* in_bias, int relu, float* bsum, float* sqpart, int B, int Cin, int Cout, int dtype,
                    void* stream);
+/* ka_conv3x3_fwd that also writes the transformed input x' (the tensor `F.relu(self.bn1(...)) + g...` of se_resnet.py:71,78, which the
+ * reference materialises and autograd saves for conv2's weight gradient) to x_out (B, 81, Cin), so that ka_conv3x3_wgrad reads it as
+ * a plain operand instead of repeating the transform per tile.  x_out == NULL: ka_conv3x3_fwd.  Shapes: ka_conv3x3_fwd_keep_supported. */
+int ka_conv3x3_fwd_keep_supported(int B, int Cin, int Cout, int dtype);
+int ka_conv3x3_fwd_keep(const void* in, const void* wpack, void* out, const float* in_scale, const float* in_shift,
+                        const float* in_bias, int relu, float* bsum, float* sqpart, void* x_out, int B, int Cin, int Cout, int dtype,
+                        void* stream);
 int ka_conv3x3_sqpart_rows(int B);
 /* Data-gradient convolution with the surrounding BatchNorm-backward passes fused in (bf16): the input is
  * dy = in*k[0:C] + k[C:2C] + in2*k[2C:3C] (= ka_bn_bwd_apply on the fly, also written to dy_out for the weight-gradient

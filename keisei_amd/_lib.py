@@ -18,6 +18,8 @@ _LIB_PATH = Path(os.environ.get("KEISEI_AMD_LIB") or Path(__file__).resolve().pa
 # signature strings: p = pointer (torch tensor | int | None), i = int, f = float, d = double, q = long long
 _SIGS = {
     "ka_conv3x3_fwd": "pppppp i pp iii i p",
+    "ka_conv3x3_fwd_keep_supported": "iiii",
+    "ka_conv3x3_fwd_keep": "pppppp i pp p iii i p",
     "ka_conv3x3_dgrad_fused": "ppppp pp ppppp pp iii i p",
     "ka_conv3x3_sqpart_rows": "i",
     "ka_debug_conv_stamps": "p",

@@ -1271,8 +1271,10 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
         const unsigned nbytes = (unsigned)a.B * (KA_BOARD * ROWB);
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, nbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.in2 : a.in), 0, nbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(TWO && a.in_out ? a.in_out : const_cast<void*>(a.in), 0,
-                                                                              TWO && a.in_out ? nbytes : 0u, 0x00020000);
+        // (in_out: the two-tensor form's dy; the forward transform form's x' when the caller keeps it for the weight gradient --
+        //  a null in_out is a descriptor of zero bytes: the stores are dropped)
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.in_out ? a.in_out : const_cast<void*>(a.in), 0,
+                                                                              a.in_out ? nbytes : 0u, 0x00020000);
         const int voff0 = (pt >> 3) * ROWB + pc * 16;
         int ldso[KP];
 #pragma unroll
@@ -1353,6 +1355,10 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                         v[e] = (__bf16)f[0]; v[e + 1] = (__bf16)f[1];
                     }
                     if (b0 + j >= a.B) v = bf16x8{};
+                    // (the transformed input, kept for the weight gradient when the caller asked: ka_conv3x3_fwd_keep.  256 channels
+                    //  only: in the 128-channel kernel this store makes the compiler spill 656 bytes per lane)
+                    if constexpr (C == 256) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r_out,
+                                                           voff0 + k * (NP / 8) * ROWB, soff, 0);
                 }
                 *reinterpret_cast<bf16x8*>(img + ldso[k]) = v;
             }
@@ -1827,6 +1833,31 @@ extern "C" int ka_conv3x3_fwd(const void* in, const void* wpack, void* out, cons
                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, g_stamps.load()};
     KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
     KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KA_DTYPE_BF16) return conv_dispatch<bf16_t>(a, st);
+    if (dtype == KA_DTYPE_F32) return conv_dispatch<float>(a, st);
+    ka_set_error("conv3x3: unknown dtype %d", dtype);
+    return KA_ERR_ARG;
+}
+
+// ka_conv3x3_fwd that also WRITES the transformed input x' = [relu](in * in_scale + in_shift) + in_bias -- the tensor the convolution
+// actually multiplies -- to x_out (B, 81, Cin): the weight gradient of the layer then reads it as a plain operand instead of
+// repeating the transform per tile (wgrad_flat_kernel<true>: +37 us per launch at B = 4096).  Only the two-board kernel's staging
+// waves can do it for nothing (ka_conv3x3_fwd_keep_supported); x_out == NULL is ka_conv3x3_fwd.
+extern "C" int ka_conv3x3_fwd_keep_supported(int B, int Cin, int Cout, int dtype) {
+    if (dtype != KA_DTYPE_BF16 || Cin != Cout || B < 512) return 0;
+    if (ka_opt(KA_OPT_CONV_P, 1) == 0 || ka_opt(KA_OPT_CONV_PC2, 3) == 0) return 0;
+    return Cin == 256 && ka_opt(KA_OPT_CONV_MT, 5) != 6;
+}
+extern "C" int ka_conv3x3_fwd_keep(const void* in, const void* wpack, void* out, const float* in_scale, const float* in_shift,
+                                   const float* in_bias, int relu, float* bsum, float* sqpart, void* x_out, int B, int Cin, int Cout,
+                                   int dtype, void* stream) {
+    KA_REQUIRE(in && wpack && out, "conv3x3: null tensor");
+    KA_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
+    KA_REQUIRE(!x_out || ((in_scale || in_bias || relu) && ka_conv3x3_fwd_keep_supported(B, Cin, Cout, dtype)),
+               "conv3x3_fwd_keep: x_out needs an input transform and a shape the two-board kernel takes (B=%d Cin=%d Cout=%d)", B, Cin, Cout);
+    ConvArgs a{in, wpack, out, in_scale, in_shift, in_bias, bsum, sqpart, B, Cin, Cout, 0, relu,
+               nullptr, nullptr, x_out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, g_stamps.load()};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == KA_DTYPE_BF16) return conv_dispatch<bf16_t>(a, st);
     if (dtype == KA_DTYPE_F32) return conv_dispatch<float>(a, st);

@@ -615,6 +615,8 @@ class SEResNetEngine:
         # KA_FC_SIDE=2 (experiment): forked BEHIND conv1 instead -- eligible when conv1 has drained, i.e. beside the statistics kernels
         flate = self._wgrad_side(1, dev)[0] if (fc_side == "2" and fside is None) else None
         main_f = torch.cuda.current_stream(dev)
+        keep_x2 = (T == torch.bfloat16 and os.environ.get("KA_KEEP_X2", "0") == "1"
+                   and bool(_lib.query("ka_conv3x3_fwd_keep_supported", B, C, C, code)))
         for i, blk in enumerate(m.blocks if tower_tab is None else ()):
             # g = global_fc(pool(x)) is only needed by conv2
             if fside is not None:
@@ -652,15 +654,23 @@ class SEResNetEngine:
                 main_f.wait_event(g_ready)               # global-pool FC chain ran on the side stream beside conv1
             y2 = new_act(C)
             bsum2 = torch.empty(B, C, device=dev); sq2 = torch.empty(rows, C, device=dev)
-            self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
-                  bsum2, sq2 if train else None, B, C, C, code, st)
+            # x2 = relu(bn1(y1)) + g, the tensor conv2 multiplies: with KA_KEEP_X2=1 it is kept (written by the conv's own staging waves)
+            # so that conv2's weight gradient reads a plain operand instead of recomputing it per tile.  Measured: weight gradients
+            # -16 us per launch, conv launches +3 us, the step 98.02 -> 97.87 ms, for 6.8 GB more HBM traffic and memory: off by default
+            x2 = new_act(C) if (keep and keep_x2) else None
+            if x2 is not None:
+                self._timed("conv3x3", "ka_conv3x3_fwd_keep", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
+                            bsum2, sq2 if train else None, x2, B, C, C, code, st)
+            else:
+                self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
+                            bsum2, sq2 if train else None, B, C, C, code, st)
             sc2, sh2, mu2, is2 = self._bn_forward(blk.bn2, bsum2, B, sq2, rows, C, count, train, dev, st)
             sqz, se1, se = self._fc_chain(bsum2, blk.se_fc1, blk.se_fc2, st, keep, affine=(sc2, sh2, 1.0 / 81.0))
             out = new_act(C)
             pool_out = torch.empty(B, 4 * C, device=dev)
             _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
             if keep:
-                sv.blocks.append((x, pool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out))
+                sv.blocks.append((x, pool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out, x2))
             x, pool = out, pool_out
 
         # ---- heads
@@ -863,7 +873,7 @@ class SEResNetEngine:
         # ---- tower, last block first
         for i in range(len(sv.blocks) - 1, -1, -1):
             blk = m.blocks[i]
-            (bx, bpool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out) = sv.blocks[i]
+            (bx, bpool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out, x2) = sv.blocks[i]
             pre = f"blocks.{i}."
             if not train:
                 mu1, is1 = eval_stats(blk.bn1); mu2, is2 = eval_stats(blk.bn2)
@@ -902,7 +912,10 @@ class SEResNetEngine:
                 self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dz, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
                             y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
                 dW2 = conv_grad(blk.conv2.weight, i, False)
-                self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
+                if x2 is not None:       # the forward kept conv2's input: a plain operand
+                    self._wgrad_launch(side, main, (dy2, dW2), dy2, x2, None, None, None, 0, slab, dW2, B, C, C, C, 0, twg, code)
+                else:
+                    self._wgrad_launch(side, main, (dy2, dW2), dy2, y1, sc1, sh1, g, 1, slab, dW2, B, C, C, C, 0, twg, code)
                 grads[pre + "conv2.weight"] = dW2
                 # the global-pool chain's backward (independent of bn1's coefficients) runs under bn1's statistics all-reduce
                 gside = None

@@ -905,6 +905,39 @@ def test_producer_consumer_conv_is_bit_identical_to_conv3x3_kernel(ka_env, B):
         assert not ref[0].float().isnan().any()
 
 
+@pytest.mark.parametrize("B", [515, 1024])
+def test_forward_conv_keeps_its_transformed_input_for_the_weight_gradient(B):
+    """ka_conv3x3_fwd_keep: same output and sums as ka_conv3x3_fwd, and x_out = bf16(relu(x * scale + shift) + bias) -- the operand the
+    convolution multiplied -- such that ka_conv3x3_wgrad on it as a plain input gives the weight gradient of the fused-input form
+    (which repeats that transform per tile) bit for bit."""
+    C = 256
+    if not _lib.query("ka_conv3x3_fwd_keep_supported", B, C, C, 1):
+        pytest.skip("shape not taken by the two-board kernel")
+    g = torch.Generator(device=DEV).manual_seed(B + 3)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x, dy = rnd(B, 81, C).to(torch.bfloat16), rnd(B, 81, C).to(torch.bfloat16)
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 0, 1, st())
+    sc, sh, gb = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1, rnd(B, C) * 0.1
+    nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+    o0, b0, q0 = nan(B, 81, C, dt=torch.bfloat16), nan(B, C), nan(B, C)
+    o1, b1, q1, xk = nan(B, 81, C, dt=torch.bfloat16), nan(B, C), nan(B, C), nan(B, 81, C, dt=torch.bfloat16)
+    _lib.call("ka_conv3x3_fwd", x, wp, o0, sc, sh, gb, 1, b0, q0, B, C, C, 1, st())
+    _lib.call("ka_conv3x3_fwd_keep", x, wp, o1, sc, sh, gb, 1, b1, q1, xk, B, C, C, 1, st())
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(b0, b1) and torch.equal(q0, q1)
+    ref = (torch.relu(torch.addcmul(sh, x.float(), sc)) + gb[:, None, :]).to(torch.bfloat16)     # (fma, max, add: one rounding to bf16)
+    assert float((xk.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+    ns = _lib.query("ka_wgrad_splits", B, C, C, 0)
+    slab = torch.empty(ns * 9 * C * C, device=DEV)
+    dw_f, dw_p = nan(C, C, 3, 3), nan(C, C, 3, 3)
+    _lib.call("ka_conv3x3_wgrad", dy, x, sc, sh, gb, 1, slab, dw_f, B, C, C, C, 0, 0, 1, st())
+    _lib.call("ka_conv3x3_wgrad", dy, xk, None, None, None, 0, slab, dw_p, B, C, C, C, 0, 0, 1, st())
+    torch.cuda.synchronize()
+    assert not bool(dw_f.isnan().any()) and torch.equal(dw_f, dw_p)
+
+
 @pytest.mark.parametrize("B", [512, 515, 1024, 4096, 4302, 9000])
 def test_in_kernel_corner_equals_the_corner_launch(ka_env, B):
     """KA_CONV_CORNER_IN: square 80 of up to eight board pairs as one more row tile inside conv3x3_pc2_kernel (rows left in the side

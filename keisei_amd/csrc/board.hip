@@ -169,6 +169,15 @@ __device__ __forceinline__ bool colsum2_arrive_last(int* __restrict__ counters) 
 __device__ __forceinline__ double sum_parts(const double* __restrict__ p, int nparts, int stride, int c) {
     double s = 0.0;
     int k = 0;
+    // (all kRedSlices partials of a sum requested before the first is added: in batches of 16 a coefficient kernel was eight dependent
+    //  L2 round trips long -- 6.4 us for a 256-channel layer, 328 such launches per step)
+    for (; k + 64 <= nparts; k += 64) {
+        double v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = p[(size_t)(k + u) * stride + c];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) s += v[u];
+    }
     for (; k + 16 <= nparts; k += 16) {
         double v[16];
 #pragma unroll
@@ -226,7 +235,7 @@ __device__ __forceinline__ void bn_coeffs_body(int c, const double* __restrict__
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
-__global__ void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void bn_coeffs_kernel(const double* __restrict__ sums, int nparts, double count, const double* __restrict__ count_dev,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, float momentum, float eps,
                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
@@ -294,7 +303,7 @@ __device__ __forceinline__ void bn_bwd_coeffs_body(int c, const double* __restri
     const double k2 = train ? -g * is * g1 / count - k3 * mu : 0.0;
     k[c] = (float)k1; k[C + c] = (float)k2; k[2 * C + c] = (float)k3;
 }
-__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void bn_bwd_coeffs_kernel(const double* __restrict__ sums_local, const double* __restrict__ sums_global,
                                      int nparts, double count, const double* __restrict__ count_dev,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, float* __restrict__ dgamma,

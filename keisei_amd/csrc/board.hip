@@ -117,6 +117,13 @@ __device__ __forceinline__ void colsum2_stage1_body(const float* __restrict__ A,
         // eight rows of each operand requested before the first is added (same order of additions: the loop was a chain of
         // L2 round trips)
         int r = slice;
+        for (; r + 15 * nsl < rowsA && r + 15 * nsl < rowsB; r += 16 * nsl) {      // (4096 rows over 256 slices: all sixteen at once)
+            float va[16], vb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { va[u] = A[(size_t)(r + u * nsl) * C + c]; vb[u] = Bp[(size_t)(r + u * nsl) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { s += (double)va[u]; ss += (double)vb[u]; }
+        }
         for (; r + 7 * nsl < rowsA && r + 7 * nsl < rowsB; r += 8 * nsl) {
             float va[8], vb[8];
 #pragma unroll

@@ -68,6 +68,16 @@ int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const float* k, void
                            float* bsum, const void* ep_y, const float* ep_scale, const float* ep_shift,
                            const float* ep_mean, const float* ep_invstd, float* ep_s1, float* ep_s2, int B, int Cin,
                            int Cout, int dtype, void* stream);
+/* ka_conv3x3_dgrad_fused with the gradient input in factored form: `du` and gate_add = [gate | add] ([2][B][Cin] fp32) with
+ * dz = du * gate[b,c] + add[b,c] -- the gradient wrt bn2's output, se_resnet.py:86-90 backward: the ReLU-masked gradient of the
+ * block output times the SE gate plus the squeeze path's per-board term -- as ka_block_dx_tail_bwd_du_gate leaves it.  dz is
+ * formed in fp32 inside the input transform (never rounded to bf16, never stored): dy = dz*k[0:C] + k[C:2C] + in2*k[2C:3C].
+ * Shapes: ka_conv3x3_dgrad_gated_supported (the two-board tower kernel: B >= 512, 256 or 128 channels, bf16). */
+int ka_conv3x3_dgrad_gated_supported(int B, int Cin, int Cout, int dtype, int masked);
+int ka_conv3x3_dgrad_fused_gated(const void* du, const float* gate_add, const void* in2, const float* k,
+                                 void* dy_out, const void* wpack, void* out, float* bsum, const void* ep_y,
+                                 const float* ep_scale, const float* ep_shift, const float* ep_mean, const float* ep_invstd,
+                                 float* ep_s1, float* ep_s2, int B, int Cin, int Cout, int dtype, void* stream);
 /* (Co,Ci,3,3) fp32 torch-layout weights -> MFMA B-fragment order (a derived cache; the stored parameter keeps
  * the reference's shape).  mode 0: forward, Nout = Co, Kin = Ci rounded up (zero channels); mode 1: data
  * gradient (in/out swapped, taps flipped), Nout = Ci, Kin = Co.  dst bytes = 9*(Kin/cpk)*(Nout/16)*1024. */
@@ -189,6 +199,15 @@ int ka_block_dx_tail_bwd_du(const void* dxc, const void* du_up, const void* x, c
                             void* du_out, const void* y, const float* scale, const float* shift, const float* se,
                             const float* se1, const float* W2, const float* W1, const float* mean, const float* invstd, void* dz,
                             float* dse, float* dh, float* s1p, float* s2p, int B, int C, int H, int dtype, void* stream);
+/* The chain launch WITHOUT dz (4 activation reads + 1 write): dz = du_out * gate_out[b,c] + add_out[b,c] (gate = sigmoid of the
+ * SE gate logits, add = dsq / 81: se_resnet.py:83-90 backward) has a single reader, the conv2 data gradient, which takes the three
+ * through ka_conv3x3_dgrad_fused_gated.  bf16(fmaf(du_out, gate_out, add_out)) is ka_block_dx_tail_bwd_du's dz bit for bit;
+ * du_out / dse / dh / s1p / s2p are the same bits. */
+int ka_block_dx_tail_bwd_du_gate(const void* dxc, const void* du_up, const void* x, const float* xpool, const float* dpool,
+                                 void* du_out, const void* y, const float* scale, const float* shift, const float* se,
+                                 const float* se1, const float* W2, const float* W1, const float* mean, const float* invstd,
+                                 float* gate_out, float* add_out, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                                 int H, int dtype, void* stream);
 
 /* ---- small dense layers: nn.Linear / 1x1 nn.Conv2d forward and backward (se_resnet.py:57-61,65-66,120-130) --
  * C[M,N] (+)= act(opA(A)[M,K] * opB(B)[K,N] + bias); opA(A)[m,k] = transA ? A[k*lda+m] : A[m*lda+k], likewise opB.

@@ -21,6 +21,8 @@ _SIGS = {
     "ka_conv3x3_fwd_keep_supported": "iiii",
     "ka_conv3x3_fwd_keep": "pppppp i pp p iii i p",
     "ka_conv3x3_dgrad_fused": "ppppp pp ppppp pp iii i p",
+    "ka_conv3x3_dgrad_gated_supported": "iiiii",
+    "ka_conv3x3_dgrad_fused_gated": "pppppp pp ppppp pp iii i p",
     "ka_conv3x3_sqpart_rows": "i",
     "ka_debug_conv_stamps": "p",
     "ka_pack_conv3x3": "pp iiii i i p",
@@ -53,6 +55,7 @@ _SIGS = {
     "ka_block_dx_tail_bwd_supported": "iii",
     "ka_block_dx_tail_bwd": "pppppp p ppppppppp p pppp iii i p",
     "ka_block_dx_tail_bwd_du": "ppppp p ppppppppp p pppp iii i p",
+    "ka_block_dx_tail_bwd_du_gate": "ppppp p ppppppppp pp pppp iii i p",
     "ka_gemm": "pppp iii iii ii iii i i i p",
     "ka_reduce_slabs": "pp i q i p",
     "ka_reduce_slabs2": "pp q pp q i p",

@@ -561,9 +561,17 @@ struct DxArgs {
     const float* xpool; const float* dpool;                     // pooled statistics of x, gradient wrt them
     void* dx;
     int du_io;   // 1 (kernel form DX = 2): dout_up already carries its ReLU mask (out_up unused) and dx is WRITTEN masked by [x > 0] -- see ka_block_dx_tail_bwd_du
+                 // 2 (kernel form DX = 3): the same, and dz is NOT written: gate_out / add_out carry what forms it (ka_block_dx_tail_bwd_du_gate)
+    float* gate_out; float* add_out;                            // [B, C] each: dz = du * gate_out + add_out
 };
 
-// DX: 0 = the tail alone, 1 = with the block-input gradient of the block above, 2 = the same in its du-chain form
+// DX: 0 = the tail alone, 1 = with the block-input gradient of the block above, 2 = the same in its du-chain form,
+// 3 = the du chain WITHOUT dz: dz = du * gate[b, c] + add[b, c] is affine in the du this launch writes anyway, and its only
+// reader -- the conv2 data gradient's input transform -- can form it from du and the two per-(board, channel) vectors
+// (ka_conv3x3_dgrad_fused_gated).  One activation write less (4 reads + 1 write), du is not kept in registers for a second
+// pass, and nothing of a board streams after its FC chain.  s1 / s2 were never sums over the rounded dz (see above), so they
+// are unchanged.  (Form 3 at six waves per SIMD -- three boards per CU -- spills at 80 registers: 285 us against 227, and 496
+// against 175 once the loads are batched; not kept.)
 template <typename T, int MAXSQ, int NTHR, int DX>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 6 && !DX) ? 6 : 4))) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
@@ -615,11 +623,81 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
     constexpr int kW2 = 16, kW1 = 16;
     const bool w_pre = (2 * C + NTHR / H - 1) / (NTHR / H) <= kW2 && H <= kW1;
     __syncthreads();
-    vec16 du[MAXSQ];
+    constexpr bool kGate = DX >= 3;          // dz not written: du is not kept
+    vec16 du[kGate ? 1 : MAXSQ];
+    // Gate form inside the chain (both dxc and du_up given: every launch but the one under the heads): the same arithmetic with
+    // the loads of two squares -- eight 16-byte pieces per thread -- requested together.  The general loop below branches per
+    // square (p < 81, the optional operands), so its four loads are one HBM round trip per square: six in a row per thread, which
+    // at two boards per CU is what bounded the launch (4.1 TB/s).  A square past the board reads square 80 and adds zeros.
+    bool batched = false;
+    if constexpr (kGate) {
+        const T* dxc = static_cast<const T*>(dxa.dxc);
+        const T* dup = static_cast<const T*>(dxa.dout_up);
+        batched = dxc != nullptr && dup != nullptr && H % 4 == 0;     // (H % 4: the LDS vectors below stay 16-byte aligned)
+        if (batched) {
+            constexpr int KB = 2;
+#pragma unroll 1
+            for (int i0 = 0; i0 < MAXSQ; i0 += KB) {
+                vec16 ro[KB], ry[KB], r1[KB], r2[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    if (i0 + k >= MAXSQ) continue;
+                    const size_t o = base + (size_t)min(slice + (i0 + k) * nsl, KA_BOARD - 1) * C;
+                    ro[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(out + o));
+                    ry[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(y + o));
+                    r1[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dxc + o));
+                    r2[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dup + o));
+                }
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    if (i0 + k >= MAXSQ) continue;
+                    const int p = slice + (i0 + k) * nsl;
+                    const bool valid = p < KA_BOARD;
+                    // the square's coefficients as 16-byte LDS reads, taken again per square (the offset is opaque to the
+                    // compiler: held across the loop they are 48 registers, which spill)
+                    int co = c0;
+                    asm volatile("" : "+v"(co));
+                    float gf[P16], of[P16], yf[P16], yc[P16], t[P16];
+                    E::unpack(ro[k], of); E::unpack(ry[k], yf);
+#pragma unroll
+                    for (int h = 0; h < P16; h += 4) {           // four channels at a time: 24 coefficient registers, not 48
+                        const f32x4 q0 = *reinterpret_cast<const f32x4*>(v_dx + co + h), q1 = *reinterpret_cast<const f32x4*>(v_dx + C + co + h);
+                        const f32x4 q2 = *reinterpret_cast<const f32x4*>(v_dx + 2 * C + co + h), q3 = *reinterpret_cast<const f32x4*>(v_dx + 3 * C + co + h);
+                        const f32x4 q4 = *reinterpret_cast<const f32x4*>(v_dx + 4 * C + co + h), q5 = *reinterpret_cast<const f32x4*>(v_mu + co + h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = of[h + e];
+                            gf[h + e] = q2[e] + q4[e] * (v - q0[e]) + (v == q1[e] ? q3[e] : 0.f);
+                            yc[h + e] = valid ? yf[h + e] - q5[e] : 0.f;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    E::unpack(r1[k], t);
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) gf[e] += t[e];
+                    E::unpack(r2[k], t);
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) gf[e] += t[e];
+                    const vec16 g = E::pack(gf);                 // (dx rounded to T before it is used, as in the general loop)
+                    E::unpack(g, gf);
+#pragma unroll
+                    for (int e = 0; e < P16; ++e) {
+                        gf[e] = (valid && of[e] > 0.f) ? gf[e] : 0.f;
+                        sg[e] += gf[e];
+                        sgy[e] = fmaf(gf[e], yc[e], sgy[e]);
+                        sy[e] += yc[e];
+                    }
+                    if (valid) __builtin_nontemporal_store(E::pack(gf), reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
+                }
+                __builtin_amdgcn_sched_barrier(0);               // (the next batch's loads hoisted above this one's arithmetic spill)
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
+        if (kGate && batched) break;
         const int p = slice + i * nsl;
-        du[i] = vec16{};
+        du[kGate ? 0 : i] = vec16{};
         if (p < KA_BOARD) {
             vec16 g;
             const vec16 o = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(out + base + (size_t)p * C));
@@ -635,7 +713,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                 if (dxc) t1 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dxc + base + (size_t)p * C));
                 if (dup) {
                     t2 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dup + base + (size_t)p * C));
-                    if constexpr (DX != 2) t3 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(oup + base + (size_t)p * C));
+                    if constexpr (DX < 2) t3 = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(oup + base + (size_t)p * C));
                 }
 #pragma unroll
                 for (int e = 0; e < P16; ++e) {
@@ -653,10 +731,10 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                     E::unpack(t2, t); E::unpack(t3, o2);
                     // (a masked dout_up holds +0 where out_up <= 0: adding it as it is gives the same sum)
 #pragma unroll
-                    for (int e = 0; e < P16; ++e) gf[e] += (DX == 2 || o2[e] > 0.f) ? t[e] : 0.f;
+                    for (int e = 0; e < P16; ++e) gf[e] += (DX >= 2 || o2[e] > 0.f) ? t[e] : 0.f;
                 }
                 g = E::pack(gf);
-                if constexpr (DX != 2) __builtin_nontemporal_store(g, reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
+                if constexpr (DX < 2) __builtin_nontemporal_store(g, reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
             } else {
                 g = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(dout + base + (size_t)p * C));
             }
@@ -669,9 +747,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
                 sgy[e] = fmaf(gf[e], yc, sgy[e]);      // (explicit: both instantiations must round alike)
                 sy[e] += yc;
             }
-            du[i] = E::pack(gf);             // exact: a masked copy of dout
-            if constexpr (DX == 2)
-                __builtin_nontemporal_store(du[i], reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
+            du[kGate ? 0 : i] = E::pack(gf);             // exact: a masked copy of dout
+            if constexpr (DX >= 2)
+                __builtin_nontemporal_store(du[kGate ? 0 : i], reinterpret_cast<vec16*>(static_cast<T*>(dxa.dx) + base + (size_t)p * C));
         }
     }
     for (int off = groups; off < 64; off <<= 1) {             // lanes cg, cg + groups, ... of a wave hold the same channels
@@ -740,7 +818,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
         const float gate = v_gate[c], add = a / KA_BOARD;
         s1p[(size_t)b * C + c] = fmaf(gate, red_g[c], KA_BOARD * add);
         s2p[(size_t)b * C + c] = invstd[c] * fmaf(gate, red_gy[c], add * red_y[c]);
+        if constexpr (kGate) { dxa.gate_out[(size_t)b * C + c] = gate; dxa.add_out[(size_t)b * C + c] = add; }
     }
+    if constexpr (kGate) return;
     __syncthreads();
     float gate[P16], add[P16];
 #pragma unroll
@@ -839,8 +919,11 @@ __global__ __launch_bounds__(kThreads) void block_dx_kernel(
 // instructions than the channel-pair form, and the forward tail keeps its squares in registers so that the pooled
 // statistics are an exact two-pass computation (sum and max first, then squared deviations and ties) with two LDS
 // combines instead of a serial Welford chain with a division per element.
-template <typename T, int MAXSQ, int NTHR>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6 || sizeof(T) == 4 ? 6 : 4))) void block_tail_fwd16_kernel(
+// KB > 0: the loads of KB squares are requested together (addresses clamped to the board, a square past it adds nothing).  The
+// per-square loop (KB = 0) branches on p < 81 and on the optional operands, so every square of a thread is an HBM round trip
+// of its own: six in a row.  KB = 6 takes all of a thread's squares in one round trip at four waves per SIMD.
+template <typename T, int MAXSQ, int NTHR, int KB = 0>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(((MAXSQ <= 6 || sizeof(T) == 4) && KB < 6) ? 6 : 4))) void block_tail_fwd16_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C) {
     typedef Elem<T> E;
@@ -877,8 +960,45 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(MAXSQ <= 6
     }
     if (!raw) __syncthreads();               // coefficients read before redA/redB are reused
     vec16 ov[MAXSQ];
+    if constexpr (KB > 0) {
+        const T* resp = res ? res : y;           // (no residual: the load is wasted, not branched around)
+#pragma unroll
+        for (int i0 = 0; i0 < MAXSQ; i0 += KB) {
+            vec16 yv[KB], rv[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (i0 + k >= MAXSQ) continue;
+                const size_t o = base + (size_t)min(slice + (i0 + k) * nsl, KA_BOARD - 1) * C;
+                yv[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(y + o));
+                rv[k] = __builtin_nontemporal_load(reinterpret_cast<const vec16*>(resp + o));
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (i0 + k >= MAXSQ) continue;
+                const int p = slice + (i0 + k) * nsl;
+                const bool valid = p < KA_BOARD;
+                float u[P16], r[P16];
+                E::unpack(yv[k], u); E::unpack(rv[k], r);
+#pragma unroll
+                for (int e = 0; e < P16; ++e) {
+                    float v = u[e];
+                    if (!raw) {
+                        v = fmaf(v, ca[e], cb[e]);
+                        if (res) v += r[e];
+                        v = rnd<T>(fmaxf(v, 0.f));
+                    }
+                    u[e] = v;
+                    sum[e] += valid ? v : 0.f; mx[e] = valid ? fmaxf(mx[e], v) : mx[e];
+                }
+                ov[i0 + k] = valid ? E::pack(u) : vec16{};
+                if (!raw && valid) __builtin_nontemporal_store(ov[i0 + k], reinterpret_cast<vec16*>(out + base + (size_t)p * C));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXSQ; ++i) {
+        if (KB > 0) break;
         const int p = slice + i * nsl;
         ov[i] = vec16{};
         if (p < KA_BOARD) {
@@ -1213,15 +1333,23 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
         const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4;
         const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
         const size_t lds = (size_t)4 * nrow * C * sizeof(float);
-#define KA_TAILF_LAUNCH(MAXSQ, NTHR) \
-        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
+#define KA_TAILF_LAUNCH_KB(MAXSQ, NTHR, KB_) \
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR, KB_>), dim3(B), dim3(NTHR), lds, st, \
                                                 (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C))
+#define KA_TAILF_LAUNCH(MAXSQ, NTHR) KA_TAILF_LAUNCH_KB(MAXSQ, NTHR, 0)
         if (lds <= 64 * 1024) {
+            // KA_TAIL_FWD_KB: squares whose loads a thread requests together (512-thread, six-square shapes): 0 one at a time
+            const int kb = ka_opt(KA_OPT_TAIL_FWD_KB, 0);
+            if (nt == 512 && nsq <= 6 && kb > 0) {
+                if (kb == 2) KA_TAILF_LAUNCH_KB(6, 512, 2); else if (kb == 3) KA_TAILF_LAUNCH_KB(6, 512, 3); else KA_TAILF_LAUNCH_KB(6, 512, 6);
+                return ka_check_launch("block_tail_fwd");
+            }
             if (nt == 512) { if (nsq <= 6) KA_TAILF_LAUNCH(6, 512); else KA_TAILF_LAUNCH(11, 512); }
             else           { if (nsq <= 6) KA_TAILF_LAUNCH(6, 256); else KA_TAILF_LAUNCH(11, 256); }
             return ka_check_launch("block_tail_fwd");
         }
 #undef KA_TAILF_LAUNCH
+#undef KA_TAILF_LAUNCH_KB
     }
     KA_BOARD_CHECK("block_tail_fwd");
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_tail_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
@@ -1316,7 +1444,7 @@ static int tail_bwd_launch(const void* dout, const void* out, const void* y, con
     const int groups = C / p16, nrow = nt / (groups > 64 ? groups : 64);
     const size_t lds = ((size_t)3 * nrow * C + 2 * C + nt + H + 3 * C + (dxp ? 5 * C : 0)) * sizeof(float);
     KA_REQUIRE(lds <= 64 * 1024, "tail_bwd_fused: LDS footprint %zu B", lds);
-    const DxArgs dxa = dxp ? *dxp : DxArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const DxArgs dxa = dxp ? *dxp : DxArgs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
 #define KA_TAIL_LAUNCH(MAXSQ, NTHR, DX_) \
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL((tail_bwd_fused_kernel<T, MAXSQ, NTHR, DX_>), dim3(B), dim3(NTHR), lds, st, \
                                             (const T*)dout, (const T*)out, (const T*)y, scale, shift, se, se1, W2, W1, mean, \
@@ -1324,7 +1452,7 @@ static int tail_bwd_launch(const void* dout, const void* out, const void* y, con
 #define KA_TAIL_PICK(DX_) \
     if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512, DX_); else KA_TAIL_LAUNCH(11, 512, DX_); } \
     else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256, DX_); else KA_TAIL_LAUNCH(11, 256, DX_); }
-    if (dxp && dxp->du_io) { KA_TAIL_PICK(2) } else if (dxp) { KA_TAIL_PICK(1) } else { KA_TAIL_PICK(0) }
+    if (dxp && dxp->du_io == 2) { KA_TAIL_PICK(3) } else if (dxp && dxp->du_io) { KA_TAIL_PICK(2) } else if (dxp) { KA_TAIL_PICK(1) } else { KA_TAIL_PICK(0) }
 #undef KA_TAIL_PICK
 #undef KA_TAIL_LAUNCH
     return ka_check_launch(dxp ? "block_dx_tail_bwd" : "tail_bwd_fused");
@@ -1355,7 +1483,7 @@ extern "C" int ka_block_dx_tail_bwd(const void* dxc, const void* dout_up, const 
     KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
                "block_dx_tail_bwd: null tensor");
     KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd: unsupported shape C=%d H=%d", C, H);
-    DxArgs dxa{dxc, dout_up, out_up, xpool, dpool, dx, 0};
+    DxArgs dxa{dxc, dout_up, out_up, xpool, dpool, dx, 0, nullptr, nullptr};
     return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
                            static_cast<hipStream_t>(stream));
 }
@@ -1376,8 +1504,28 @@ extern "C" int ka_block_dx_tail_bwd_du(const void* dxc, const void* du_up, const
     KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && dz && dse && dh && s1p && s2p,
                "block_dx_tail_bwd_du: null tensor");
     KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd_du: unsupported shape C=%d H=%d", C, H);
-    DxArgs dxa{dxc, du_up, nullptr, xpool, dpool, du_out, 1};
+    DxArgs dxa{dxc, du_up, nullptr, xpool, dpool, du_out, 1, nullptr, nullptr};
     return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, dz, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
+                           static_cast<hipStream_t>(stream));
+}
+
+// The chain launch without dz.  dz = du_out * gate + add (gate = sigmoid of the SE gate logit, add = dsq / 81, both per
+// (board, channel)) has one reader, the conv2 data gradient, whose input transform is already an affine map per channel:
+// ka_conv3x3_dgrad_fused_gated takes du_out, gate_out and add_out instead of dz.  One activation write less per block
+// (4 reads + 1 write); bf16(fmaf(du_out, gate_out, add_out)) is bit for bit the dz of ka_block_dx_tail_bwd_du, and du_out /
+// dse / dh / s1 / s2 are the same bits.
+extern "C" int ka_block_dx_tail_bwd_du_gate(const void* dxc, const void* du_up, const void* x, const float* xpool,
+                                            const float* dpool, void* du_out, const void* y, const float* scale,
+                                            const float* shift, const float* se, const float* se1, const float* W2,
+                                            const float* W1, const float* mean, const float* invstd, float* gate_out,
+                                            float* add_out, float* dse, float* dh, float* s1p, float* s2p, int B, int C,
+                                            int H, int dtype, void* stream) {
+    KA_REQUIRE(x && xpool && dpool && du_out, "block_dx_tail_bwd_du_gate: bad block_dx arguments");
+    KA_REQUIRE(y && scale && shift && se && se1 && W2 && W1 && mean && invstd && gate_out && add_out && dse && dh && s1p && s2p,
+               "block_dx_tail_bwd_du_gate: null tensor");
+    KA_REQUIRE(B > 0 && ka_block_dx_tail_bwd_supported(C, H, dtype), "block_dx_tail_bwd_du_gate: unsupported shape C=%d H=%d", C, H);
+    DxArgs dxa{dxc, du_up, nullptr, xpool, dpool, du_out, 2, gate_out, add_out};
+    return tail_bwd_launch(nullptr, x, y, scale, shift, se, se1, W2, W1, mean, invstd, nullptr, dse, dh, s1p, s2p, B, C, H, dtype, &dxa,
                            static_cast<hipStream_t>(stream));
 }
 

@@ -72,7 +72,11 @@ struct ConvArgs {
     void* out;
     const float* in_scale;   // [Cin] or null: x' = x*scale + shift
     const float* in_shift;
-    const float* in_bias;    // [B,Cin] or null: per-board bias added after the ReLU
+    const float* in_bias;    // [B,Cin] or null: per-board bias added after the ReLU.  WITH in2 (two-tensor form) it is instead
+                             // gate_add = [gate | add], [2][B][Cin]: `in` is du and the gradient the transform applies to is
+                             // dz = in*gate[b,c] + add[b,c] (ka_conv3x3_dgrad_fused_gated), x' = dz*in_scale + in_shift + in2*in_k3 with dz
+                             // never rounded to bf16 nor written; conv3x3_pc2_kernel<GATED> (which also takes in_shift / in_k3 as
+                             // in_scale + Cin / 2 Cin) and conv3x3_corner_kernel only
     float* bsum;             // [B,Cout] or null
     float* sqpart;           // [B, Cout] or null: per-board sums of squares
     int B, Cin, Cout, KC, relu;
@@ -1243,8 +1247,9 @@ __device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x4 (&ac
 // conv3x3_pc_kernel<..., STAG>, which did not pay there: that kernel waits for its weight stream, this one for the matrix pipe).
 // C = 256, MT = 5: eight MFMA waves, four 64-channel chunks, squares 0..79 (square 80: conv3x3_corner_kernel).  C = 128, MT = 6: four
 // MFMA waves (one per SIMD, 256 registers each beside the staging waves), two chunks, all 81 squares as six row tiles per board.
-template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
+template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false, bool GATED = false>
 __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvArgs a) {
+    static_assert(!GATED || (TWO && MASKED && !SKIP && !STAG), "the gated input is conv2's data gradient: two-tensor, masked");
     static_assert(!(SKIP && MASKED), "the border-tile layout is built for the register-only epilogue");
     static_assert((C == 256 && MT == 5) || (C == 128 && MT == 6 && !SKIP), "shapes this kernel is built for");
     constexpr int NMW = C / 32, NCH = C / 64, NTILE = C / 16, KSG = C / 32, ROWB = C * 2, NTL = 2 * MT;
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
         // second board read as zeros and are never written, without a branch.  The vector instructions of these waves share the
         // SIMDs with the MFMA waves one for one.
         const int pt = tid - NMW * 64, pc = pt & 7, swave = __builtin_amdgcn_readfirstlane(wave) - NMW;
-        const bool has_aff = a.in_scale != nullptr;
+        const bool has_aff = GATED || a.in_scale != nullptr;
         const unsigned nbytes = (unsigned)a.B * (KA_BOARD * ROWB);
         const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, nbytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(TWO ? a.in2 : a.in), 0, nbytes, 0x00020000);
@@ -1310,16 +1315,21 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 if (TWO) pw[TWO ? k : 0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in2, vo, soff, 2));
             }
         };
-        auto stage_write = [&](int u) {
+        auto stage_write = [&](int u) __attribute__((always_inline)) {
             const int b0 = 2 * ((int)blockIdx.x + (u / NCH) * nwg), c4 = u % NCH, ch0 = c4 * 64 + pc * 8;
             const int soff = __builtin_amdgcn_readfirstlane(b0 * (KA_BOARD * ROWB) + c4 * 128);
             char* img = smem + (u & 1) * (2 * kP2Img);
             float sc[8], sh[8], k3[8], pb[2][8];
             {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f}, o = {1.f, 1.f, 1.f, 1.f};
+                // (GATED: the three coefficient vectors are one array k[3][C] and gate / add one array [2][B][C] -- two base pointers in
+                //  scalar registers instead of five: with five the weight descriptor no longer fits the scalar file, moves to vector
+                //  registers and every weight load of the MFMA loop becomes a readfirstlane loop)
+                const float* shp = GATED ? a.in_scale + C : a.in_shift;
+                const float* k3p = GATED ? a.in_scale + 2 * C : a.in_k3;
                 const f32x4 s0 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + ch0) : o, s1 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_scale + ch0 + 4) : o;
-                const f32x4 t0 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0) : z, t1 = has_aff ? *reinterpret_cast<const f32x4*>(a.in_shift + ch0 + 4) : z;
-                const f32x4 u0 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0) : z, u1 = TWO ? *reinterpret_cast<const f32x4*>(a.in_k3 + ch0 + 4) : z;
+                const f32x4 t0 = has_aff ? *reinterpret_cast<const f32x4*>(shp + ch0) : z, t1 = has_aff ? *reinterpret_cast<const f32x4*>(shp + ch0 + 4) : z;
+                const f32x4 u0 = TWO ? *reinterpret_cast<const f32x4*>(k3p + ch0) : z, u1 = TWO ? *reinterpret_cast<const f32x4*>(k3p + ch0 + 4) : z;
                 const bool bias = !TWO && a.in_bias;
                 const f32x4 p00 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * C + ch0) : z;
                 const f32x4 p01 = bias ? *reinterpret_cast<const f32x4*>(a.in_bias + (size_t)b0 * C + ch0 + 4) : z;
@@ -1332,6 +1342,25 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                     pb[0][e] = p00[e]; pb[0][4 + e] = p01[e]; pb[1][e] = p10[e]; pb[1][4 + e] = p11[e];
                 }
             }
+            // gated two-tensor form: per board j, (in*gate_j + add_j)*sc + sh = in*(gate_j*sc) + (add_j*sc + sh)
+            float gsc0[8], gsh0[8], gsc1[8], gsh1[8];
+            if constexpr (GATED) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const float* gp = a.in_bias + (size_t)b0 * C + ch0;
+                const float* ap = gp + (size_t)a.B * C;
+                const bool b1 = b0 + 1 < a.B;
+                const f32x4 g00 = *reinterpret_cast<const f32x4*>(gp), g01 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const f32x4 a00 = *reinterpret_cast<const f32x4*>(ap), a01 = *reinterpret_cast<const f32x4*>(ap + 4);
+                const f32x4 g10 = b1 ? *reinterpret_cast<const f32x4*>(gp + C) : z, g11 = b1 ? *reinterpret_cast<const f32x4*>(gp + C + 4) : z;
+                const f32x4 a10 = b1 ? *reinterpret_cast<const f32x4*>(ap + C) : z, a11 = b1 ? *reinterpret_cast<const f32x4*>(ap + C + 4) : z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gsc0[e] = g00[e] * sc[e]; gsc0[4 + e] = g01[e] * sc[4 + e];
+                    gsh0[e] = fmaf(a00[e], sc[e], sh[e]); gsh0[4 + e] = fmaf(a01[e], sc[4 + e], sh[4 + e]);
+                    gsc1[e] = g10[e] * sc[e]; gsc1[4 + e] = g11[e] * sc[4 + e];
+                    gsh1[e] = fmaf(a10[e], sc[e], sh[e]); gsh1[4 + e] = fmaf(a11[e], sc[4 + e], sh[4 + e]);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 if (!live(k)) continue;
@@ -1340,8 +1369,18 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 const int j = i >= kHalf ? 1 : 0;
                 bf16x8 v = pv[k];
                 if (TWO) {
+                    // (the board of a piece is a compile-time fact in every round but the one the pair's middle falls in)
+                    const bool jlo = NP * (k + 1) <= kHalf, jhi = NP * k >= kHalf;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
+                    for (int e = 0; e < 8; ++e) {
+                        float se_ = sc[e], he_ = sh[e];
+                        if constexpr (GATED) {
+                            const float c0 = gsc0[e], c1 = gsc1[e], h0 = gsh0[e], h1 = gsh1[e];
+                            se_ = jlo ? c0 : jhi ? c1 : (j ? c1 : c0);
+                            he_ = jlo ? h0 : jhi ? h1 : (j ? h1 : h0);
+                        }
+                        v[e] = (__bf16)fmaf((float)pw[TWO ? k : 0][e], k3[e], fmaf((float)v[e], se_, he_));
+                    }
                     if (b0 + j >= a.B) v = bf16x8{};          // (a missing board stays all zeros: the transform of zeros is the shift)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r_out,
                                                            voff0 + k * (NP / 8) * ROWB, soff, 0);
@@ -1380,7 +1419,7 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
                 }
             }
         };
-        auto stage = [&](int u) { stage_load(u); stage_write(u); side_write(u); };
+        auto stage = [&](int u) __attribute__((always_inline)) { stage_load(u); stage_write(u); side_write(u); };   // (inlined by force: as a call its closure -- and the kernel arguments -- live in scratch)
         stage(0);
         KA_LDS_BARRIER();
         if constexpr (STAG) {
@@ -1551,16 +1590,21 @@ __global__ __launch_bounds__((C / 32 + NPW) * 64) void conv3x3_pc2_kernel(ConvAr
     }
 }
 
-template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false>
+template <int C, int MT, bool TWO, bool MASKED, int NPW, bool SKIP = false, bool STAG = false, bool GATED = false>
 static int launch_conv_pc2_form(const ConvArgs& a, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};          // per instantiation: devices already configured
-    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), done, what)) return rc;
+    if (int rc = ka_big_lds_once(reinterpret_cast<const void*>(&conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG, GATED>), done, what)) return rc;
     const int pairs = (a.B + 1) / 2, grid = pairs < 256 ? pairs : 256;
-    hipLaunchKernelGGL((conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG>), dim3(grid), dim3((C / 32 + NPW) * 64),
+    hipLaunchKernelGGL((conv3x3_pc2_kernel<C, MT, TWO, MASKED, NPW, SKIP, STAG, GATED>), dim3(grid), dim3((C / 32 + NPW) * 64),
                        C == 256 ? kP2LdsCorner : kP2Lds, st, a);       // (the 256-channel forms always carry the side buffer: their staging stores are unconditional)
     return ka_check_launch(what);
 }
 static int launch_conv_pc2(const ConvArgs& a, hipStream_t st) {
+    if (a.in2 && a.in_bias) {                                  // conv2's data gradient taking (du, gate, add) for dz: ka_conv3x3_dgrad_fused_gated
+        KA_REQUIRE(a.in2 && a.ep_y, "conv3x3: the gated input comes with the two-tensor transform and the masked epilogue");
+        if (a.Cin == 128) return launch_conv_pc2_form<128, 6, true, true, 4, false, false, true>(a, st, "conv3x3 (two boards per unit, 128 channels, gated two-tensor, masked)");
+        return launch_conv_pc2_form<256, 5, true, true, 4, false, false, true>(a, st, "conv3x3 (two boards per unit, gated two-tensor, masked)");
+    }
     if (a.Cin == 128) {                                        // the 128-channel tower (BASELINE configs[1], keisei-ddp.toml): all 81 squares, no corner launch
         if (a.in2 && a.ep_y) return launch_conv_pc2_form<128, 6, true, true, 4>(a, st, "conv3x3 (two boards per unit, 128 channels, two-tensor, masked)");
         if (a.in2) return launch_conv_pc2_form<128, 6, true, false, 4>(a, st, "conv3x3 (two boards per unit, 128 channels, two-tensor)");
@@ -1645,7 +1689,18 @@ __global__ __launch_bounds__(512) void conv3x3_corner_kernel(ConvArgs a) {
         for (int k = 0; k < 8; ++k) {
             const int i = tid + 512 * k, bl = i >> 7, ps = (i >> 5) & 3;
             bf16x8 v = pv[k];
-            if (a.in2) {
+            if (a.in2 && a.in_bias) {
+                // (the tower kernel's gated transform, term for term)
+                const size_t go = (size_t)min(b0 + bl, a.B - 1) * 256 + ch0;
+                const float* addp = a.in_bias + (size_t)a.B * 256;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.in_bias + go), g1 = *reinterpret_cast<const f32x4*>(a.in_bias + go + 4);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(addp + go), a1 = *reinterpret_cast<const f32x4*>(addp + go + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ge = e < 4 ? g0[e & 3] : g1[e & 3], ae = e < 4 ? a0[e & 3] : a1[e & 3];
+                    v[e] = (__bf16)fmaf((float)pw[k][e], k3[e], fmaf((float)v[e], ge * sc[e], fmaf(ae, sc[e], sh[e])));
+                }
+            } else if (a.in2) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaf((float)pw[k][e], k3[e], fmaf((float)v[e], sc[e], sh[e]));
             } else if (has_aff || a.relu || a.in_bias) {
@@ -1767,6 +1822,7 @@ int conv_dispatch(ConvArgs a, hipStream_t st) {
         }
         if (p2 != 0 && pv != 0 && a.Cin == 128 && a.Cout == 128 && a.B >= 512 && (!a.in2 || (p2 >= 2 && !a.ep_y) || p2 >= 3))
             return launch_conv_pc2(a, st);
+        KA_REQUIRE(!(a.in2 && a.in_bias), "conv3x3: the gated two-tensor input exists in the two-board kernel only (ka_conv3x3_dgrad_gated_supported)");
         if (pv != 0 && a.Cin == 256 && a.Cout == 256 && a.B >= 512 &&
             (!a.in2 || (pv >= 2 && !a.ep_y) || pv >= 3)) {
             a.mt5 = want5;
@@ -1877,6 +1933,34 @@ extern "C" int ka_conv3x3_dgrad_fused(const void* in, const void* in2, const flo
     KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused: bf16 only");
     KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused: epilogue tensors");
     ConvArgs a{in, wpack, out, k, k + Cin, nullptr, bsum, nullptr, B, Cin, Cout, 0, 0,
+               in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps.load()};
+    return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
+}
+
+// does conv_dispatch take a two-tensor launch of this shape to the two-board kernel (the only form with the gated input)?
+extern "C" int ka_conv3x3_dgrad_gated_supported(int B, int Cin, int Cout, int dtype, int masked) {
+    if (dtype != KA_DTYPE_BF16 || B < 512 || Cin != Cout || (Cin != 256 && Cin != 128)) return 0;
+    const int pv = ka_opt(KA_OPT_CONV_P, 1), p2 = ka_opt(KA_OPT_CONV_PC2, 3);
+    if (pv == 0 || p2 < 3 || !masked) return 0;
+    if (Cin == 256 && ka_opt(KA_OPT_CONV_MT, 5) == 6) return 0;
+    return 1;
+}
+
+// ka_conv3x3_dgrad_fused whose gradient input is given as du and gate_add = [gate | add] ([2][B][Cin] fp32) with
+// dz = du * gate[b, c] + add[b, c] (ka_block_dx_tail_bwd_du_gate writes the three): dy = dz*k[0] + k[1] + in2*k[2] is formed from the unrounded dz, written
+// to dy_out and convolved.  Everything else as ka_conv3x3_dgrad_fused.
+extern "C" int ka_conv3x3_dgrad_fused_gated(const void* du, const float* gate_add, const void* in2, const float* k,
+                                            void* dy_out, const void* wpack, void* out, float* bsum, const void* ep_y,
+                                            const float* ep_scale, const float* ep_shift, const float* ep_mean,
+                                            const float* ep_invstd, float* ep_s1, float* ep_s2, int B, int Cin, int Cout,
+                                            int dtype, void* stream) {
+    KA_REQUIRE(du && gate_add && in2 && k && wpack && out, "conv3x3_dgrad_fused_gated: null tensor");
+    KA_REQUIRE(dtype == KA_DTYPE_BF16, "conv3x3_dgrad_fused_gated: bf16 only");
+    KA_REQUIRE(!ep_y || (ep_scale && ep_shift && ep_mean && ep_invstd && ep_s1 && ep_s2), "conv3x3_dgrad_fused_gated: epilogue tensors");
+    KA_REQUIRE(ka_conv3x3_dgrad_gated_supported(B, Cin, Cout, dtype, ep_y != nullptr),
+               "conv3x3_dgrad_fused_gated: shape B=%d C=%d/%d %s is not taken by the two-board kernel's masked form", B, Cin, Cout,
+               ep_y ? "masked" : "plain");
+    ConvArgs a{du, wpack, out, k, k + Cin, gate_add, bsum, nullptr, B, Cin, Cout, 0, 0,
                in2, k + 2 * Cin, dy_out, ep_y, ep_scale, ep_shift, ep_mean, ep_invstd, ep_s1, ep_s2, 0, 0, g_stamps.load()};
     return conv_dispatch<bf16_t>(a, static_cast<hipStream_t>(stream));
 }

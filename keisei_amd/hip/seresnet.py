@@ -808,6 +808,11 @@ class SEResNetEngine:
         Hse = m.blocks[0].se_fc1.weight.shape[0] if len(m.blocks) > 0 else 0
         fuse_dx = (len(m.blocks) > 0 and os.environ.get("KA_DX_TAIL", "1") != "0"
                    and bool(_lib.query("ka_block_dx_tail_bwd_supported", C, Hse, code)))
+        # ... and without dz (ka_block_dx_tail_bwd_du_gate): dz = du * gate[b, c] + add[b, c] is formed inside the conv2 data
+        # gradient's input transform (ka_conv3x3_dgrad_fused_gated) from the du the launch writes anyway -- 5 passes, and dz is
+        # no longer rounded to bf16 on its way into BatchNorm's backward.  KA_TAIL_GATE=0: the dz form.
+        gate_dz = (fuse_dx and T == torch.bfloat16 and os.environ.get("KA_TAIL_GATE", "1") != "0"
+                   and bool(_lib.query("ka_conv3x3_dgrad_gated_supported", B, C, C, code, 1)))
         pend = (dxc, None, None, x, pool, dpool, new_act())
         dout = pend[6]
         if not fuse_dx:
@@ -878,12 +883,21 @@ class SEResNetEngine:
             if not train:
                 mu1, is1 = eval_stats(blk.bn1); mu2, is2 = eval_stats(blk.bn2)
             dse = torch.empty(B, 2 * C, device=dev)
-            dz = new_act()
             H = blk.se_fc1.weight.shape[0]
             gpool_join()
-            if pend is not None:
+            gate_add = None
+            if pend is not None and gate_dz:
+                dse1 = torch.empty(B, H, device=dev)
+                gate_add = torch.empty(2, B, C, device=dev)
+                dz = pend[6]                                          # the du this launch writes; dz = du * gate + add
+                _call("ka_block_dx_tail_bwd_du_gate", pend[0], pend[1], *pend[3:], y2, sc2, sh2, se, se1, blk.se_fc2.weight,
+                      blk.se_fc1.weight, mu2, is2, gate_add[0], gate_add[1], dse, dse1, s1p, s2p, B, C, H, code, st)
+                self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
+                self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st, need_dx=False)
+            elif pend is not None:
                 # (pend[3], the input of the block above, IS this block's output `out`)
                 dse1 = torch.empty(B, H, device=dev)
+                dz = new_act()
                 _call("ka_block_dx_tail_bwd_du", pend[0], pend[1], *pend[3:], y2, sc2, sh2, se, se1, blk.se_fc2.weight,
                       blk.se_fc1.weight, mu2, is2, dz, dse, dse1, s1p, s2p, B, C, H, code, st)
                 self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
@@ -891,11 +905,13 @@ class SEResNetEngine:
             elif _lib.query("ka_tail_bwd_fused_supported", C, H, code):
                 # one read of dout / out / y2: SE-gate reductions, the per-board FC chain backward and dz in one kernel
                 dse1 = torch.empty(B, H, device=dev)
+                dz = new_act()
                 _call("ka_tail_bwd_fused", dout, out, y2, sc2, sh2, se, se1, blk.se_fc2.weight, blk.se_fc1.weight, mu2, is2,
                       dz, dse, dse1, s1p, s2p, B, C, H, code, st)
                 self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st, need_dx=False)
                 self._linear_bwd(dse1, sqz, blk.se_fc1, grads, pre + "se_fc1.weight", pre + "se_fc1.bias", st, need_dx=False)
             else:
+                dz = new_act()
                 _call("ka_tail_bwd_reduce", dout, out, y2, sc2, sh2, se, dse, B, C, code, st)
                 dse1 = self._linear_bwd(dse, se1, blk.se_fc2, grads, pre + "se_fc2.weight", pre + "se_fc2.bias", st)
                 _call("ka_relu_mask", dse1, se1, dse1.numel(), st)
@@ -909,8 +925,12 @@ class SEResNetEngine:
                 rows = _lib.query("ka_conv3x3_sqpart_rows", B)
                 dy2, dh = new_act(), new_act()
                 ep1 = torch.empty(rows, C, device=dev); ep2 = torch.empty(rows, C, device=dev)
-                self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dz, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
-                            y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
+                if gate_add is not None:
+                    self._timed("conv3x3", "ka_conv3x3_dgrad_fused_gated", dz, gate_add, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
+                                y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
+                else:
+                    self._timed("conv3x3", "ka_conv3x3_dgrad_fused", dz, y2, k2, dy2, packs[pre + "conv2"][1], dh, dg,
+                                y1, sc1, sh1, mu1, is1, ep1, ep2, B, C, C, code, st)
                 dW2 = conv_grad(blk.conv2.weight, i, False)
                 if x2 is not None:       # the forward kept conv2's input: a plain operand
                     self._wgrad_launch(side, main, (dy2, dW2), dy2, x2, None, None, None, 0, slab, dW2, B, C, C, C, 0, twg, code)

@@ -170,7 +170,7 @@ def test_wgrad_fused_input_transform(dtn):
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("C", [32, 128, 256])
-def test_bn_stats_and_tail_forward(dtn, C):
+def test_bn_stats_and_tail_forward(ka_env, dtn, C):
     dt = DT[dtn]
     B = 5
     g = torch.Generator().manual_seed(23 + C)
@@ -212,6 +212,15 @@ def test_bn_stats_and_tail_forward(dtn, C):
     pool2 = torch.empty(B, 4 * C, device=DEV)
     _lib.call("ka_pool_fwd", out, pool2, B, C, _lib.dtype_code(dt), st())
     assert torch.equal(pool2, pool)
+    # the forms that request the loads of 2 / 3 / all 6 of a thread's squares together (KA_TAIL_FWD_KB): the same bits
+    for kb in ("0", "2", "3", "6"):
+        ka_env.set("KA_TAIL_FWD_KB", kb)
+        out_k = torch.full_like(out, float("nan")); pool_k = torch.full_like(pool, float("nan"))
+        _lib.call("ka_block_tail_fwd", to_nhwc(y, dt), scale, shift, se.to(DEV), to_nhwc(x, dt), out_k, pool_k, B, C,
+                  _lib.dtype_code(dt), st())
+        torch.cuda.synchronize()
+        assert torch.equal(out_k, out) and torch.equal(pool_k, pool), kb
+    ka_env.unset("KA_TAIL_FWD_KB")
     # eval coefficients
     es, eh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     _lib.call("ka_bn_eval_coeffs", gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, es, eh, C, st())
@@ -609,12 +618,76 @@ def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
     du_r = torch.where(x > 0, dx_r, torch.zeros_like(dx_r))
     for name, a, b in (("du", du, du_r), ("dz", dz, dz_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
         assert torch.equal(a, b), name
+    # the chain form without dz: same du / dse / dh / s1 / s2, and bf16(fmaf(du, gate, add)) IS the dz of the other forms
+    du_g, _, dse, dh, s1, s2 = outs()
+    gate_add = torch.full((2, B, C), float("nan"), device=DEV)
+    _lib.call("ka_block_dx_tail_bwd_du_gate", dxc, du_up, x, pool, dpool, du_g, y, sc, sh, se, se1, W2, W1, mu, istd,
+              gate_add[0], gate_add[1], dse, dh, s1, s2, B, C, H, code, st())
+    torch.cuda.synchronize()
+    for name, a, b in (("du", du_g, du_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
+        assert torch.equal(a, b), "gate form: " + name
+    assert float((gate_add[0] - torch.sigmoid(se[:, :C])).abs().max()) < 1e-6
+    dz_g = torch.addcmul(gate_add[1].double()[:, None, :], du_g.double(), gate_add[0].double()[:, None, :])   # one rounding, like fmaf
+    assert torch.equal(dz_g.float().to(dt), dz_r), "gate form: dz"
     # ... and ka_block_dx takes a du as its dout: same result as from the unmasked gradient
     if not heads:
         dx2 = torch.empty_like(x)
         _lib.call("ka_block_dx", dxc, du_up, out_up, x, pool, dpool, dx2, B, C, code, st())
         torch.cuda.synchronize()
         assert torch.equal(dx2, dx_r)
+
+
+@pytest.mark.parametrize("B,C", [(515, 256), (1024, 256), (4096, 256), (515, 128), (2048, 128)])
+def test_gated_data_gradient_equals_the_plain_one_on_its_own_dy(B, C):
+    """ka_conv3x3_dgrad_fused_gated(du, [gate | add], y, k): the input transform forms dz = du * gate[b, c] + add[b, c] in fp32 and
+    dy = dz * k0 + k1 + y * k2 from it.  (1) Its written-back dy is the fp32 formula rounded once to bf16 (the dz form rounds
+    twice); (2) everything downstream of the transform is the same kernel: ka_conv3x3_dgrad_fused fed that dy with the identity
+    transform (k = 1, 0, 0) gives the same out / bsum / ep_s1 / ep_s2 bit for bit -- squares 0..79 and the corner launch;
+    (3) against the dz form (dz rounded to bf16 first) the outputs differ by that rounding only."""
+    assert _lib.query("ka_conv3x3_dgrad_gated_supported", B, C, C, 1, 1)
+    g = torch.Generator(device=DEV).manual_seed(B + C)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    du = torch.relu(rnd(B, 81, C)).to(torch.bfloat16)         # a masked gradient: exact zeros
+    y, yprev = rnd(B, 81, C).to(torch.bfloat16), rnd(B, 81, C).to(torch.bfloat16)
+    gate_add = torch.stack([torch.sigmoid(rnd(B, C)), 0.05 * rnd(B, C)]).contiguous()
+    w = rnd(C, C, 3, 3) / 48
+    wp = torch.empty(9 * (C // 32) * (C // 16) * 1024, dtype=torch.uint8, device=DEV)
+    _lib.call("ka_pack_conv3x3", w, wp, C, C, C, C, 1, 1, _lib.stream_ptr())
+    k = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, 0.1 * rnd(C), 0.2 * rnd(C)])
+    sc, sh = torch.rand(C, device=DEV, generator=g) + 0.5, rnd(C) * 0.1
+    mu, istd = 0.1 * rnd(C), torch.rand(C, device=DEV, generator=g) + 0.5
+
+    def outs():
+        nan = lambda *s, dt=torch.float32: torch.full(s, float("nan"), device=DEV).to(dt)
+        return nan(B, 81, C, dt=torch.bfloat16), nan(B, 81, C, dt=torch.bfloat16), nan(B, C), nan(B, C), nan(B, C)
+    st = _lib.stream_ptr()
+    out, dy, bsum, e1, e2 = outs()
+    _lib.call("ka_conv3x3_dgrad_fused_gated", du, gate_add, y, k, dy, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st)
+    torch.cuda.synchronize()
+    for t in (out, dy, bsum, e1, e2):
+        assert not bool(t.float().isnan().any())
+    # (1) dy against the formula in float64, rounded once
+    dz64 = du.double() * gate_add[0].double()[:, None, :] + gate_add[1].double()[:, None, :]
+    dy64 = dz64 * k[:C].double() + k[C:2 * C].double() + y.double() * k[2 * C:].double()
+    err = (dy.double() - dy64).abs()
+    assert bool((err <= 2.0 ** -8 * dy64.abs() + 1e-5).all())          # half a bf16 ulp + the fp32 arithmetic of three fused steps
+    assert float((dy.double() != dy64.float().to(torch.bfloat16).double()).double().mean()) < 2e-3   # (fp32 vs float64 before the one rounding)
+    # (2) the plain kernel on that dy, identity transform
+    ident = torch.cat([torch.ones(C, device=DEV), torch.zeros(2 * C, device=DEV)])
+    out2, dy2, bsum2, e12, e22 = outs()
+    _lib.call("ka_conv3x3_dgrad_fused", dy, y, ident, dy2, wp, out2, bsum2, yprev, sc, sh, mu, istd, e12, e22, B, C, C, 1, st)
+    torch.cuda.synchronize()
+    for name, a, b in (("dy", dy2, dy), ("out", out2, out), ("bsum", bsum2, bsum), ("ep_s1", e12, e1), ("ep_s2", e22, e2)):
+        assert torch.equal(a, b), name
+    # (3) the dz form: dz rounded to bf16 before the transform
+    dz = dz64.float().to(torch.bfloat16)
+    out3, dy3, bsum3, e13, e23 = outs()
+    _lib.call("ka_conv3x3_dgrad_fused", dz, y, k, dy3, wp, out3, bsum3, yprev, sc, sh, mu, istd, e13, e23, B, C, C, 1, st)
+    torch.cuda.synchronize()
+    d = (dy3.float() - dy.float()).abs()
+    assert bool((d <= 2.0 ** -6 * dy.float().abs() + 2.0 ** -7 * dz.float().abs() * k[:C].abs() + 1e-5).all())
+    rel = float((out3.float() - out.float()).norm() / out.float().norm())
+    assert rel < 4e-3, rel                                            # two roundings against one, through a 2304-term sum
 
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])

@@ -40,6 +40,17 @@ cases += [
     ("block_dx_tail_bwd_du, chain form (4R+2W)", 6, lambda: _lib.call("ka_block_dx_tail_bwd_du", dxc, dout, x, pool, dpool, dx2, y, sc, sh, se, se1, W2, W1, mu, istd,
                                                                       dz, dse, dh, s1, s2, B, C, H, code, st())),
 ]
+gate_add = torch.empty(2, B, C, device=dev)
+def gate_form(wpe):
+    def fn():
+        _lib.call("ka_block_dx_tail_bwd_du_gate", dxc, dout, x, pool, dpool, dx2, y, sc, sh, se, se1, W2, W1, mu, istd,
+                  gate_add[0], gate_add[1], dse, dh, s1, s2, B, C, H, code, st())
+    return fn
+cases += [("block_dx_tail_bwd_du_gate, no dz (4R+1W)", 5, gate_form(4))]
 for name, passes, fn in cases:
     ms = timeit(fn)
     print(f"{name:44s} {ms * 1e3:8.1f} us  {passes * abytes / ms / 1e9:6.2f} TB/s", flush=True)
+for kb in (0, 2, 3, 6, 0, 6):
+    os.environ["KA_TAIL_FWD_KB"] = str(kb); _lib.reload_options()
+    ms = timeit(lambda: _lib.call("ka_block_tail_fwd", y, sc, sh, se, x, out, pool, B, C, code, st()))
+    print(f"{'block_tail_fwd (2R+1W), KA_TAIL_FWD_KB=' + str(kb):44s} {ms * 1e3:8.1f} us  {3 * abytes / ms / 1e9:6.2f} TB/s", flush=True)

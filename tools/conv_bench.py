@@ -37,12 +37,14 @@ elif which == "conv":
     x2 = torch.randn(B, 81, C, device=dev).to(dt); yprev = torch.randn(B, 81, C, device=dev).to(dt)
     dyo = torch.empty_like(x); e1 = torch.empty(rows, C, device=dev); e2 = torch.empty(rows, C, device=dev)
     mu = 0.1 * torch.randn(C, device=dev); istd = torch.rand(C, device=dev) + 0.5
+    gate_add = torch.stack([torch.sigmoid(torch.randn(B, C, device=dev)), 0.05 * torch.randn(B, C, device=dev)]).contiguous()
     for kc, wm in ([(128, 1)] if os.environ.get("CB_QUICK") else [(128, 1), (64, 1), (128, 2)]):
         os.environ["KA_CONV_KC"] = str(kc); os.environ["KA_CONV_WM"] = str(wm); _lib.reload_options()
         for name, fn in (
             ("plain (conv1 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, code, _lib.stream_ptr())),
             ("bn+relu+bias input (conv2 fwd)", lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, code, _lib.stream_ptr())),
             ("dgrad fused, masked epilogue (conv2 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, code, _lib.stream_ptr())),
+            ("dgrad fused GATED, masked epilogue (conv2 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused_gated", x, gate_add, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, code, _lib.stream_ptr())),
             ("dgrad fused, plain epilogue (conv1 bwd)", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, code, _lib.stream_ptr())),
             ("dgrad fused, plain epilogue, no dy write-back", lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, None, wp, out, None, None, None, None, None, None, None, None, B, C, C, code, _lib.stream_ptr())),
         ):

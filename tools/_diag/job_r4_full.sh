@@ -1,6 +1,10 @@
 #!/bin/bash
-# round 4: the whole GPU suite on the current tree + default bench
-root=$(pwd); out=$root/gpurun_out; mkdir -p $out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $out/r4full_tests.log 2>&1 || { tail -30 $out/r4full_tests.log; exit 1; }
-tail -2 $out/r4full_tests.log
-for r in 1 2; do timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fp32 --no-secondary 2>/dev/null | tail -1 | cut -c1-130; done
+# full GPU suite + smoke + default bench line on the final sources
+set -e
+mkdir -p gpurun_out
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/full_gpu_tests.txt 2>&1 || { tail -40 gpurun_out/full_gpu_tests.txt; exit 1; }
+tail -3 gpurun_out/full_gpu_tests.txt
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/full_smoke.txt 2>&1 || { tail -20 gpurun_out/full_smoke.txt; exit 1; }
+tail -3 gpurun_out/full_smoke.txt
+timeout -k 10 600 python bench.py > gpurun_out/full_bench_default.json 2> gpurun_out/full_bench_default.err || { tail -20 gpurun_out/full_bench_default.err; exit 1; }
+tail -1 gpurun_out/full_bench_default.json | cut -c1-400

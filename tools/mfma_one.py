@@ -1,6 +1,6 @@
 """Runs every MFMA kernel form of the 40x256 step a few times at the headline shape (for rocprofv3 --pmc runs):
 forward conv (plain / BatchNorm+ReLU+bias input), data gradient (two-tensor input; plain / masked epilogue), weight gradient
-(plain / fused input).  MFMA_ONE=<comma list of fwd,fwd2,dgrad,dgradm,wgrad,wgradf> selects forms (default: all)."""
+(plain / fused input).  MFMA_ONE=<comma list of fwd,fwd2,dgrad,dgradm,dgradmg,wgrad,wgradf> selects forms (default: all)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,11 +23,13 @@ twg = int(os.environ.get("MFMA_ONE_WGS", 0))
 ns = _lib.query("ka_wgrad_splits", B, C, C, twg)
 slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
 st = _lib.stream_ptr
+gate_add = torch.stack([torch.sigmoid(torch.randn(B, C, device=dev)), 0.05 * torch.randn(B, C, device=dev)]).contiguous()
 forms = {
     "fwd": lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st()),
     "fwd2": lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, 1, st()),
     "dgrad": lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st()),
     "dgradm": lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st()),
+    "dgradmg": lambda: _lib.call("ka_conv3x3_dgrad_fused_gated", x, gate_add, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st()),
     "wgrad": lambda: _lib.call("ka_conv3x3_wgrad", dy, x, None, None, None, 0, slab, dw, B, C, C, C, 0, twg, 1, st()),
     "wgradf": lambda: _lib.call("ka_conv3x3_wgrad", dy, x, sc, sh, g, 1, slab, dw, B, C, C, C, 0, twg, 1, st()),
 }

@@ -561,14 +561,18 @@ __global__ void pack_conv3x3_multi_kernel(const long long* __restrict__ table) {
         const int nt = u % NT;
         const int ks = u / NT;
         const int n = chan_of(nt, lane & 15, NT);
+        // (all 9 * P16 reads requested together from an address that is always valid -- a channel past the tensor reads element 0
+        //  and is zeroed afterwards: behind `ok ? src[..] : 0` each read sat behind a branch, one round trip after the other)
         float f[9][P16];
 #pragma unroll
         for (int e = 0; e < P16; ++e) {
             const int c = ks * CPK + (lane >> 4) * P16 + e;
             const bool ok = mode == 0 ? (n < Co && c < Ci) : (c < Co && n < Ci);
-            const float* src = mode == 0 ? w + ((size_t)n * Ci + c) * 9 : w + ((size_t)c * Ci + n) * 9;
+            const float* src = !ok ? w : (mode == 0 ? w + ((size_t)n * Ci + c) * 9 : w + ((size_t)c * Ci + n) * 9);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) f[tap][e] = ok ? src[mode == 0 ? tap : 8 - tap] : 0.f;
+            for (int tap = 0; tap < 9; ++tap) f[tap][e] = src[mode == 0 ? tap : 8 - tap];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) f[tap][e] = ok ? f[tap][e] : 0.f;
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)

@@ -155,6 +155,14 @@ int ka_affine_rows(const float* in, const float* a, const float* s, float mul, f
  * se == NULL and res == NULL give relu(bn(y)) (stem, se_resnet.py:140). */
 int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se, const void* res, void* out,
                       float* pool, int B, int C, int dtype, void* stream);
+/* ka_block_tail_fwd with the squeeze-excite FC chain of the block inside (se_resnet.py:83-86: se = se_fc2(relu(se_fc1(mean over the
+ * squares of bn2(y))))): z = scale * (bsum / 81) + shift from the conv's per-board sums, h = relu(W1 z + b1), se = W2 h + b2, then the
+ * tail as above with that se.  sqz_out (B,C) / se1_out (B,H) / se_out (B,2C) receive z, h and se for the backward -- the tensors
+ * ka_fc_chain leaves when the chain is a launch of its own in front of ka_block_tail_fwd.  Shapes: ka_block_tail_fwd_se_supported. */
+int ka_block_tail_fwd_se_supported(int C, int H, int dtype);
+int ka_block_tail_fwd_se(const void* y, const float* scale, const float* shift, const float* bsum, const float* W1, const float* b1,
+                         const float* W2, const float* b2, const void* res, void* out, float* pool, float* sqz_out, float* se1_out,
+                         float* se_out, int B, int C, int H, int dtype, void* stream);
 int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, void* stream);
 /* backward of the tail: dse = [sigmoid'(a)*sum_p du*z | sum_p du] with du = dout*[out>0]; then
  * dz = du*sigmoid(a) + dsq/81 plus the per-board BatchNorm partial sums s1p = sum dz, s2p = sum dz*yhat. */

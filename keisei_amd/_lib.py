@@ -45,6 +45,8 @@ _SIGS = {
     "ka_affine_rows": "ppp f p ii p",
     "ka_bn_bwd_apply": "pppp ii i p",
     "ka_block_tail_fwd": "ppppp pp ii i p",
+    "ka_block_tail_fwd_se_supported": "iii",
+    "ka_block_tail_fwd_se": "pppppppp ppp ppp iii i p",
     "ka_pool_fwd": "pp ii i p",
     "ka_tail_bwd_reduce": "pppppp p ii i p",
     "ka_tail_bwd_dz": "ppppppp ppp ii i p",

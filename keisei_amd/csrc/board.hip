@@ -922,10 +922,21 @@ __global__ __launch_bounds__(kThreads) void block_dx_kernel(
 // KB > 0: the loads of KB squares are requested together (addresses clamped to the board, a square past it adds nothing).  The
 // per-square loop (KB = 0) branches on p < 81 and on the optional operands, so every square of a thread is an HBM round trip
 // of its own: six in a row.  KB = 6 takes all of a thread's squares in one round trip at four waves per SIMD.
-template <typename T, int MAXSQ, int NTHR, int KB = 0>
+// SeArgs (sea.W1 != NULL): the squeeze-excite FC chain of the board runs HERE instead of as a launch of its own in front of this
+// one (ka_block_tail_fwd_se): z = scale * (bsum[b] / 81) + shift (the BatchNorm'd channel means of y: se_resnet.py:83),
+// h = relu(W1 z + b1), se = W2 h + b2 -- 2 C + H dot products per board, their weights (48 KB at C = 256, H = 16) requested at
+// the kernel's first instruction; z / h / se are written out for the backward exactly as ka_fc_chain leaves them.
+struct SeArgs {
+    const float* bsum;                       // (B, C) per-board sums of y (the conv's epilogue output)
+    const float* W1; const float* b1;        // (H, C), (H)
+    const float* W2; const float* b2;        // (2C, H), (2C)
+    float* sqz_out; float* se1_out; float* se_out;   // (B, C), (B, H), (B, 2C)
+    int H;
+};
+template <typename T, int MAXSQ, int NTHR, int KB = 0, bool SEIN = false>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(((MAXSQ <= 6 || sizeof(T) == 4) && KB < 6) ? 6 : 4))) void block_tail_fwd16_kernel(
     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C) {
+    const float* __restrict__ se, const T* __restrict__ res, T* __restrict__ out, float* __restrict__ pool, int C, SeArgs sea) {
     typedef Elem<T> E;
     typedef typename E::vec16 vec16;
     constexpr int P16 = E::kPer16;
@@ -944,7 +955,55 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(((MAXSQ <=
     const bool raw = scale == nullptr;       // pooled statistics of y as it is (ka_pool_fwd): no transform, no store
     // v = (y*scale + shift)*gate + bias = y*ca + cb: the two per-channel coefficients (one sigmoid per channel) are
     // computed once per workgroup and shared through LDS (redA/redB are free until the first combine)
-    if (!raw) {
+    if (SEIN && !raw) {
+        // ---- the board's squeeze-excite chain (shapes: H <= 16 divides NTHR, C / (NTHR / H) <= 8, 2 C <= NTHR: the launcher checks)
+        const int H = sea.H, parts = NTHR / H, j = tid % H, part = tid / H, kper = C / parts;
+        float* zz = redC;                    // [C]            (redC is free until the second combine)
+        float* sev = redC + C;               // [2C]
+        float* hp = redC + 3 * C;            // [parts][H]
+        float* hh = hp + NTHR;               // [H]
+        constexpr int kW1 = 8, kW2 = 16;     // weights of a thread, requested before anything else is waited for
+        float w1r[kW1], w2a[kW2];
+#pragma unroll
+        for (int u = 0; u < kW1; ++u) w1r[u] = u < kper ? sea.W1[(size_t)j * C + part * kper + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < kW2; ++u) w2a[u] = (u < H && tid < 2 * C) ? sea.W2[(size_t)tid * H + u] : 0.f;
+        for (int c = tid; c < C; c += NTHR) {
+            const float z = scale[c] * (sea.bsum[(size_t)b * C + c] * (1.f / KA_BOARD)) + shift[c];
+            zz[c] = z;
+            if (sea.sqz_out) sea.sqz_out[(size_t)b * C + c] = z;
+        }
+        __syncthreads();
+        {
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < kW1; ++u) if (u < kper) a = fmaf(zz[part * kper + u], w1r[u], a);
+            hp[part * H + j] = a;
+        }
+        __syncthreads();
+        if (tid < H) {
+            float a = sea.b1 ? sea.b1[tid] : 0.f;
+            for (int q2 = 0; q2 < parts; ++q2) a += hp[q2 * H + tid];
+            a = fmaxf(a, 0.f);
+            hh[tid] = a;
+            if (sea.se1_out) sea.se1_out[(size_t)b * H + tid] = a;
+        }
+        __syncthreads();
+        if (tid < 2 * C) {
+            float a = sea.b2 ? sea.b2[tid] : 0.f;
+#pragma unroll
+            for (int u = 0; u < kW2; ++u) if (u < H) a = fmaf(hh[u], w2a[u], a);
+            sev[tid] = a;
+            sea.se_out[(size_t)b * 2 * C + tid] = a;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += NTHR) {
+            const float gt = sigmoidf_(sev[c]);
+            redA[c] = scale[c] * gt;
+            redB[c] = shift[c] * gt + sev[C + c];
+        }
+        __syncthreads();
+    } else if (!raw) {
         for (int c = tid; c < C; c += NTHR) {
             const float gt = se ? sigmoidf_(se[(size_t)b * 2 * C + c]) : 1.f;
             redA[c] = scale[c] * gt;
@@ -1323,10 +1382,8 @@ extern "C" int ka_bn_bwd_apply(const void* dz, const void* y, const float* k, vo
     return ka_check_launch("bn_bwd_apply");
 }
 
-extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se,
-                                 const void* res, void* out, float* pool, int B, int C, int dtype, void* stream) {
-    KA_REQUIRE(y && scale && shift && out, "block_tail_fwd: null tensor");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+static int tail_fwd_launch(const void* y, const float* scale, const float* shift, const float* se, const void* res, void* out,
+                           float* pool, int B, int C, int dtype, const SeArgs& sea, hipStream_t st) {
     int nt = 0;
     const int nsq = ka_opt_set(KA_OPT_BOARD_PAIRS) ? 0 : board16_plan(C, dtype, &nt);
     if (nsq > 0 && nsq <= 11 && B > 0) {
@@ -1335,9 +1392,20 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
         const size_t lds = (size_t)4 * nrow * C * sizeof(float);
 #define KA_TAILF_LAUNCH_KB(MAXSQ, NTHR, KB_) \
         KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR, KB_>), dim3(B), dim3(NTHR), lds, st, \
-                                                (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C))
+                                                (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C, sea))
 #define KA_TAILF_LAUNCH(MAXSQ, NTHR) KA_TAILF_LAUNCH_KB(MAXSQ, NTHR, 0)
+#define KA_TAILF_LAUNCH_SE(MAXSQ, NTHR) \
+        KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR, 0, true>), dim3(B), dim3(NTHR), lds, st, \
+                                                (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C, sea))
         if (lds <= 64 * 1024) {
+            if (sea.W1) {
+                const int H = sea.H, parts = H > 0 && nt % H == 0 ? nt / H : 0;
+                KA_REQUIRE(parts > 0 && C % parts == 0 && C / parts <= 8 && H <= 16 && 2 * C <= nt &&
+                           3 * C + nt + H <= 2 * nrow * C, "block_tail_fwd_se: unsupported shape C=%d H=%d", C, H);
+                if (nt == 512) { if (nsq <= 6) KA_TAILF_LAUNCH_SE(6, 512); else KA_TAILF_LAUNCH_SE(11, 512); }
+                else           { if (nsq <= 6) KA_TAILF_LAUNCH_SE(6, 256); else KA_TAILF_LAUNCH_SE(11, 256); }
+                return ka_check_launch("block_tail_fwd_se");
+            }
             // KA_TAIL_FWD_KB: squares whose loads a thread requests together (512-thread, six-square shapes): 0 one at a time
             const int kb = ka_opt(KA_OPT_TAIL_FWD_KB, 0);
             if (nt == 512 && nsq <= 6 && kb > 0) {
@@ -1350,11 +1418,42 @@ extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float*
         }
 #undef KA_TAILF_LAUNCH
 #undef KA_TAILF_LAUNCH_KB
+#undef KA_TAILF_LAUNCH_SE
     }
+    KA_REQUIRE(!sea.W1, "block_tail_fwd_se: unsupported shape C=%d (ka_block_tail_fwd_se_supported)", C);
     KA_BOARD_CHECK("block_tail_fwd");
     KA_DISPATCH_T(dtype, hipLaunchKernelGGL(block_tail_fwd_kernel<T>, dim3(B), dim3(kThreads), red_bytes<T>(C), st,
                                             (const T*)y, scale, shift, se, (const T*)res, (T*)out, pool, C));
     return ka_check_launch("block_tail_fwd");
+}
+
+extern "C" int ka_block_tail_fwd(const void* y, const float* scale, const float* shift, const float* se,
+                                 const void* res, void* out, float* pool, int B, int C, int dtype, void* stream) {
+    KA_REQUIRE(y && scale && shift && out, "block_tail_fwd: null tensor");
+    return tail_fwd_launch(y, scale, shift, se, res, out, pool, B, C, dtype, SeArgs{}, static_cast<hipStream_t>(stream));
+}
+
+// 1 when ka_block_tail_fwd_se covers (C, H, dtype): the 16-byte single-pass tail with the board's SE chain inside
+extern "C" int ka_block_tail_fwd_se_supported(int C, int H, int dtype) {
+    int nt = 0;
+    if (ka_opt_set(KA_OPT_BOARD_PAIRS)) return 0;
+    const int nsq = board16_plan(C, dtype, &nt);
+    if (nsq <= 0 || nsq > 11 || H <= 0 || H > 16 || nt % H != 0) return 0;
+    const int p16 = dtype == KA_DTYPE_BF16 ? 8 : 4, groups = C / p16, nrow = nt / (groups > 64 ? groups : 64), parts = nt / H;
+    return C % parts == 0 && C / parts <= 8 && 2 * C <= nt && 3 * C + nt + H <= 2 * nrow * C &&
+           (size_t)4 * nrow * C * sizeof(float) <= 64 * 1024;
+}
+
+// ka_block_tail_fwd with the squeeze-excite FC chain of se_resnet.py:83-86 inside: se = W2 relu(W1 z + b1) + b2 with
+// z = scale * (bsum / 81) + shift (what ka_fc_chain computes from the same operands in a launch of its own); sqz_out (B, C),
+// se1_out (B, H) and se_out (B, 2C) receive z, the hidden row and se for the backward.  Shapes: ka_block_tail_fwd_se_supported.
+extern "C" int ka_block_tail_fwd_se(const void* y, const float* scale, const float* shift, const float* bsum, const float* W1,
+                                    const float* b1, const float* W2, const float* b2, const void* res, void* out, float* pool,
+                                    float* sqz_out, float* se1_out, float* se_out, int B, int C, int H, int dtype, void* stream) {
+    KA_REQUIRE(y && scale && shift && out && bsum && W1 && W2 && se_out, "block_tail_fwd_se: null tensor");
+    KA_REQUIRE(ka_block_tail_fwd_se_supported(C, H, dtype), "block_tail_fwd_se: unsupported shape C=%d H=%d", C, H);
+    const SeArgs sea{bsum, W1, b1, W2, b2, sqz_out, se1_out, se_out, H};
+    return tail_fwd_launch(y, scale, shift, nullptr, res, out, pool, B, C, dtype, sea, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, void* stream) {
@@ -1368,7 +1467,7 @@ extern "C" int ka_pool_fwd(const void* x, float* pool, int B, int C, int dtype, 
         const size_t lds = (size_t)4 * nrow * C * sizeof(float);
 #define KA_POOL_LAUNCH(MAXSQ, NTHR) \
         KA_DISPATCH_T(dtype, hipLaunchKernelGGL((block_tail_fwd16_kernel<T, MAXSQ, NTHR>), dim3(B), dim3(NTHR), lds, st, \
-                                                (const T*)x, nullptr, nullptr, nullptr, nullptr, (T*)nullptr, pool, C))
+                                                (const T*)x, nullptr, nullptr, nullptr, nullptr, (T*)nullptr, pool, C, SeArgs{}))
         if (lds <= 64 * 1024) {
             if (nt == 512) { if (nsq <= 6) KA_POOL_LAUNCH(6, 512); else KA_POOL_LAUNCH(11, 512); }
             else           { if (nsq <= 6) KA_POOL_LAUNCH(6, 256); else KA_POOL_LAUNCH(11, 256); }

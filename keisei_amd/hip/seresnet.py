@@ -617,6 +617,8 @@ class SEResNetEngine:
         main_f = torch.cuda.current_stream(dev)
         keep_x2 = (T == torch.bfloat16 and os.environ.get("KA_KEEP_X2", "0") == "1"
                    and bool(_lib.query("ka_conv3x3_fwd_keep_supported", B, C, C, code)))
+        # the squeeze-excite FC chain of a block inside its tail launch (ka_block_tail_fwd_se): KA_SE_IN_TAIL=1
+        se_in_tail = os.environ.get("KA_SE_IN_TAIL", "0") == "1"
         for i, blk in enumerate(m.blocks if tower_tab is None else ()):
             # g = global_fc(pool(x)) is only needed by conv2
             if fside is not None:
@@ -665,10 +667,21 @@ class SEResNetEngine:
                 self._timed("conv3x3", "ka_conv3x3_fwd", y1, packs[f"blocks.{i}.conv2"][0], y2, sc1, sh1, g, 1,
                             bsum2, sq2 if train else None, B, C, C, code, st)
             sc2, sh2, mu2, is2 = self._bn_forward(blk.bn2, bsum2, B, sq2, rows, C, count, train, dev, st)
-            sqz, se1, se = self._fc_chain(bsum2, blk.se_fc1, blk.se_fc2, st, keep, affine=(sc2, sh2, 1.0 / 81.0))
             out = new_act(C)
             pool_out = torch.empty(B, 4 * C, device=dev)
-            _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
+            Hse = blk.se_fc1.weight.shape[0]
+            if (se_in_tail and blk.se_fc1.weight.is_contiguous() and blk.se_fc2.weight.is_contiguous()
+                    and blk.se_fc1.bias is not None and blk.se_fc2.bias is not None
+                    and _lib.query("ka_block_tail_fwd_se_supported", C, Hse, code)):
+                # the board's squeeze-excite chain inside the tail launch (one launch less per block)
+                sqz = torch.empty(B, C, device=dev) if keep else None
+                se1 = torch.empty(B, Hse, device=dev) if keep else None
+                se = torch.empty(B, 2 * C, device=dev)
+                _call("ka_block_tail_fwd_se", y2, sc2, sh2, bsum2, blk.se_fc1.weight, blk.se_fc1.bias, blk.se_fc2.weight,
+                      blk.se_fc2.bias, x, out, pool_out, sqz, se1, se, B, C, Hse, code, st)
+            else:
+                sqz, se1, se = self._fc_chain(bsum2, blk.se_fc1, blk.se_fc2, st, keep, affine=(sc2, sh2, 1.0 / 81.0))
+                _call("ka_block_tail_fwd", y2, sc2, sh2, se, x, out, pool_out, B, C, code, st)
             if keep:
                 sv.blocks.append((x, pool, y1, sc1, sh1, mu1, is1, g1, g, y2, sc2, sh2, mu2, is2, sqz, se1, se, out, x2))
             x, pool = out, pool_out

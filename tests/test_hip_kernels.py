@@ -221,6 +221,33 @@ def test_bn_stats_and_tail_forward(ka_env, dtn, C):
         torch.cuda.synchronize()
         assert torch.equal(out_k, out) and torch.equal(pool_k, pool), kb
     ka_env.unset("KA_TAIL_FWD_KB")
+    # the squeeze-excite chain inside the launch (ka_block_tail_fwd_se): se from the per-board sums through the two FC layers,
+    # then the same tail -- against the chain in float64 torch + ka_block_tail_fwd on the same operands
+    H = max(C // 16, 4)
+    code = _lib.dtype_code(dt)
+    if _lib.query("ka_block_tail_fwd_se_supported", C, H, code):
+        W1, b1 = (torch.randn(H, C, generator=g) / C ** 0.5).to(DEV), torch.randn(H, generator=g).to(DEV)
+        W2, b2 = (torch.randn(2 * C, H, generator=g) / H ** 0.5).to(DEV), torch.randn(2 * C, generator=g).to(DEV)
+        sqz_r = scale * (bsum * (1.0 / 81.0)) + shift
+        se1_r = torch.relu(sqz_r.double() @ W1.double().t() + b1.double()).float()
+        se_r = (se1_r.double() @ W2.double().t() + b2.double()).float().contiguous()
+        out_r = torch.empty_like(out); pool_r = torch.empty_like(pool)
+        _lib.call("ka_block_tail_fwd", to_nhwc(y, dt), scale, shift, se_r, to_nhwc(x, dt), out_r, pool_r, B, C, code, st())
+        sqz, se1, se2 = torch.empty(B, C, device=DEV), torch.empty(B, H, device=DEV), torch.empty(B, 2 * C, device=DEV)
+        out_s = torch.full_like(out, float("nan")); pool_s = torch.full_like(pool, float("nan"))
+        _lib.call("ka_block_tail_fwd_se", to_nhwc(y, dt), scale, shift, bsum, W1, b1, W2, b2, to_nhwc(x, dt), out_s, pool_s,
+                  sqz, se1, se2, B, C, H, code, st())
+        torch.cuda.synchronize()
+        assert torch.allclose(sqz, sqz_r, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(se1, se1_r, rtol=1e-5, atol=2e-6) and torch.allclose(se2, se_r, rtol=1e-5, atol=5e-6)
+        # the tail itself on the launch's OWN se is the plain launch bit for bit
+        out_t = torch.empty_like(out); pool_t = torch.empty_like(pool)
+        _lib.call("ka_block_tail_fwd", to_nhwc(y, dt), scale, shift, se2, to_nhwc(x, dt), out_t, pool_t, B, C, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(out_s, out_t) and torch.equal(pool_s, pool_t)
+        close(from_nhwc(out_s), from_nhwc(out_r), dt, k=2)
+    else:
+        assert C == 32                                            # (2 C <= threads of the workgroup fails only there)
     # eval coefficients
     es, eh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     _lib.call("ka_bn_eval_coeffs", gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, es, eh, C, st())

@@ -359,6 +359,40 @@ def test_backward_schedules_give_identical_gradients(monkeypatch, amp):
             assert torch.equal(grads[name][n], ref), (name, n)
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_se_chain_inside_the_tail_launch(monkeypatch, amp):
+    """KA_SE_IN_TAIL=1: the squeeze-excite FC chain of a block runs inside its forward-tail launch (ka_block_tail_fwd_se) instead of
+    as a ka_fc_chain launch in front of it.  Same operands, plain fp32 FMAs in another order than the chain kernel's MFMAs:
+    outputs and every parameter gradient agree to fp32 rounding (fp32 mode) / to the bf16 mode's own noise floor."""
+    shape = orc.NetShape(3, 64, 8, 32, 16, 64, 32)
+    sd = orc.init_like_state_dict(shape)
+    g = torch.Generator().manual_seed(12)
+    B = 37
+    obs = torch.randn(B, 50, 9, 9, generator=g).to(DEV)
+    cp, cv, cs = torch.randn(B, 9, 9, 139, generator=g).to(DEV), torch.randn(B, 3, generator=g).to(DEV), torch.randn(B, 1, generator=g).to(DEV)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("KA_SE_IN_TAIL", flag)
+        m = SEResNetModel(SEResNetParams(**shape.__dict__))
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        if amp:
+            m.configure_amp(True, torch.bfloat16, "cuda")
+        o = m(obs)
+        ((o.policy_logits * cp).sum() / B + (o.value_logits * cv).sum() + (o.score_lead * cs).sum()).backward()
+        torch.cuda.synchronize()
+        runs[flag] = (o.policy_logits.detach().clone(), o.value_logits.detach().clone(), {n: prm.grad.clone() for n, prm in m.named_parameters()})
+    monkeypatch.delenv("KA_SE_IN_TAIL")
+    tol = 2e-2 if amp else 1e-4
+    for a, b in ((runs["0"][0], runs["1"][0]), (runs["0"][1], runs["1"][1])):
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-6
+    for n, ref in runs["0"][2].items():
+        got = runs["1"][2][n]
+        den = float(ref.norm())
+        if den > 0:
+            assert float((got - ref).norm()) / den <= (5e-2 if amp else 1e-4), n
+
+
 @pytest.mark.parametrize("nb,B", [(3, 5), (40, 130)])
 def test_eval_tower_kernel_matches_the_per_layer_path(monkeypatch, nb, B):
     """bf16 eval forward of a 256-channel model: the one-launch tower (csrc/tower.hip, the default in eval mode) against the

@@ -22,11 +22,13 @@ k3 = torch.cat([torch.rand(C, device=dev) + 0.5, 0.1 * torch.randn(C, device=dev
 ns = _lib.query("ka_wgrad_splits", B, C, C, 0)
 slab = torch.empty(ns * 9 * C * C, device=dev); dw = torch.empty(C, C, 3, 3, device=dev)
 st = _lib.stream_ptr
+gate_add = torch.stack([torch.sigmoid(torch.randn(B, C, device=dev)), 0.05 * torch.randn(B, C, device=dev)]).contiguous()
 forms = {
     "conv3x3_pc2_kernel, plain input (conv1 forward)": lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, None, None, None, 0, bsum, sq, B, C, C, 1, st()),
     "conv3x3_pc2_kernel, transform input (conv2 forward)": lambda: _lib.call("ka_conv3x3_fwd", x, wp, out, sc, sh, g, 1, bsum, sq, B, C, C, 1, st()),
     "conv3x3_pc2_kernel, two-tensor input (conv1 data gradient)": lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, None, None, None, None, None, None, None, None, B, C, C, 1, st()),
     "conv3x3_pc2_kernel, two-tensor input + masked epilogue (conv2 data gradient)": lambda: _lib.call("ka_conv3x3_dgrad_fused", x, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st()),
+    "conv3x3_pc2_kernel, GATED two-tensor input + masked epilogue (conv2 data gradient as shipped)": lambda: _lib.call("ka_conv3x3_dgrad_fused_gated", x, gate_add, x2, k3, dyo, wp, out, bsum, yprev, sc, sh, mu, istd, e1, e2, B, C, C, 1, st()),
     "wgrad_flat_kernel, plain input (conv1 weight gradient)": lambda: _lib.call("ka_conv3x3_wgrad", dy, x, None, None, None, 0, slab, dw, B, C, C, C, 0, 0, 1, st()),
     "wgrad_flat_kernel, fused input (conv2 weight gradient)": lambda: _lib.call("ka_conv3x3_wgrad", dy, x, sc, sh, g, 1, slab, dw, B, C, C, C, 0, 0, 1, st()),
 }
@@ -50,7 +52,7 @@ for name, fn in forms.items():
     ok = (s[:, 4] - s[:, 3]) > 0
     ghz = ((s[:, 7] - s[:, 0])[ok] / (s[:, 4] - s[:, 3])[ok] * 0.1)
     cyc = (s[:, 7] - s[:, 0])[ok]
-    lines.append(f"{name:80s} {us:7.1f} us/launch (incl. corner)  clock {float(ghz.median()):.3f} GHz (p10 {float(ghz.quantile(0.1)):.3f}, p90 {float(ghz.quantile(0.9)):.3f})  "
+    lines.append(f"{name:96s} {us:7.1f} us/launch (incl. corner)  clock {float(ghz.median()):.3f} GHz (p10 {float(ghz.quantile(0.1)):.3f}, p90 {float(ghz.quantile(0.9)):.3f})  "
                  f"main loop {float(cyc.median()) / 1e3:.0f} k cycles, {int(ok.sum())} workgroups")
     print(lines[-1], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)

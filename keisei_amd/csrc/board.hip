@@ -572,14 +572,31 @@ struct DxArgs {
 // pass, and nothing of a board streams after its FC chain.  s1 / s2 were never sums over the rounded dz (see above), so they
 // are unchanged.  (Form 3 at six waves per SIMD -- three boards per CU -- spills at 80 registers: 285 us against 227, and 496
 // against 175 once the loads are batched; not kept.)
-template <typename T, int MAXSQ, int NTHR, int DX>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 6 && !DX) ? 6 : 4))) void tail_bwd_fused_kernel(
+// Half-width pieces (KA_TAIL_GATE_P4=1, gate form, bf16): a thread owns FOUR channels (8-byte pieces) and every eighth square, so
+// its per-channel state -- three sums, the coefficient registers, the unpacked values -- is half as wide: 80 registers, three
+// boards per CU, four squares per round trip.
+struct ElemBf4 {
+    static constexpr int kPer16 = 4;
+    typedef bf16x4 vec16;
+    static __device__ __forceinline__ void unpack(const vec16& v, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+    }
+    static __device__ __forceinline__ vec16 pack(const float* f) {
+        vec16 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (__bf16)f[i];
+        return v;
+    }
+};
+template <typename T, int MAXSQ, int NTHR, int DX, typename EE = Elem<T>>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(((MAXSQ <= 6 && !DX) || EE::kPer16 * (int)sizeof(T) < 16) ? 6 : 4))) void tail_bwd_fused_kernel(
     const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ se, const float* __restrict__ se1,
     const float* __restrict__ W2, const float* __restrict__ W1, const float* __restrict__ mean,
     const float* __restrict__ invstd, T* __restrict__ dz, float* __restrict__ dse_out, float* __restrict__ dh_out,
     float* __restrict__ s1p, float* __restrict__ s2p, int C, int H, DxArgs dxa) {
-    typedef Elem<T> E;
+    typedef EE E;
     typedef typename E::vec16 vec16;
     constexpr int P16 = E::kPer16;
     extern __shared__ float lds[];
@@ -635,7 +652,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu((MAXSQ <= 
         const T* dup = static_cast<const T*>(dxa.dout_up);
         batched = dxc != nullptr && dup != nullptr && H % 4 == 0;     // (H % 4: the LDS vectors below stay 16-byte aligned)
         if (batched) {
-            constexpr int KB = 2;
+            constexpr int KB = P16 * (int)sizeof(T) < 16 ? 3 : 2;
 #pragma unroll 1
             for (int i0 = 0; i0 < MAXSQ; i0 += KB) {
                 vec16 ro[KB], ry[KB], r1[KB], r2[KB];
@@ -1551,7 +1568,13 @@ static int tail_bwd_launch(const void* dout, const void* out, const void* y, con
 #define KA_TAIL_PICK(DX_) \
     if (nt == 512) { if (nsq <= 6) KA_TAIL_LAUNCH(6, 512, DX_); else KA_TAIL_LAUNCH(11, 512, DX_); } \
     else           { if (nsq <= 6) KA_TAIL_LAUNCH(6, 256, DX_); else KA_TAIL_LAUNCH(11, 256, DX_); }
-    if (dxp && dxp->du_io == 2) { KA_TAIL_PICK(3) } else if (dxp && dxp->du_io) { KA_TAIL_PICK(2) } else if (dxp) { KA_TAIL_PICK(1) } else { KA_TAIL_PICK(0) }
+    if (dxp && dxp->du_io == 2 && ka_opt(KA_OPT_TAIL_GATE_P4, 1) != 0 && dtype == KA_DTYPE_BF16 && nt == 512 && C % 4 == 0 && C / 4 <= 512 && 512 % (C / 4) == 0 &&
+        (KA_BOARD + 512 / (C / 4) - 1) / (512 / (C / 4)) <= 11 && 512 % H == 0) {
+        // (same LDS footprint: nrow is 8 for 64 channel groups as for 32)
+        hipLaunchKernelGGL((tail_bwd_fused_kernel<bf16_t, 11, 512, 3, ElemBf4>), dim3(B), dim3(512), lds, st,
+                           (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, scale, shift, se, se1, W2, W1, mean,
+                           invstd, (bf16_t*)dz, dse, dh, s1p, s2p, C, H, dxa);
+    } else if (dxp && dxp->du_io == 2) { KA_TAIL_PICK(3) } else if (dxp && dxp->du_io) { KA_TAIL_PICK(2) } else if (dxp) { KA_TAIL_PICK(1) } else { KA_TAIL_PICK(0) }
 #undef KA_TAIL_PICK
 #undef KA_TAIL_LAUNCH
     return ka_check_launch(dxp ? "block_dx_tail_bwd" : "tail_bwd_fused");

@@ -64,7 +64,7 @@ inline const char* ka_diag_env(const char* name) {
 #define KA_OPTIONS(X)                                                                                                      \
     X(CONV_P) X(CONV_MT) X(CONV_PC2) X(CONV_PC2_SKIP) X(CONV_PC2_STAG) X(CONV_CORNER_IN) X(CONV_P_STAG) X(CONV_P_PRIO) X(CONV_P_WGS) X(CONV_P_NPW) X(CONV_WM) X(CONV_KC)       \
     X(CONV_NTW) X(CONV_STAGGER) X(CONV_PRIO) X(WGRAD_TN) X(WGRAD_WGS) X(WGRAD_STAG) X(WGRAD_LEAN) X(BOARD_PAIRS) X(TF_LDS_EPI) X(TF_K256) X(TF_BIG)    \
-    X(TF_MAP2D) X(TF_ATTN_LDS) X(TF_ATTN_ONE) X(TAIL_FWD_KB)
+    X(TF_MAP2D) X(TF_ATTN_LDS) X(TF_ATTN_ONE) X(TAIL_FWD_KB) X(TAIL_GATE_P4)
 enum KaOpt {
 #define KA_OPT_ENUM(n) KA_OPT_##n,
     KA_OPTIONS(KA_OPT_ENUM)

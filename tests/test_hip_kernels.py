@@ -603,7 +603,7 @@ def test_tail_bwd_fused_matches_unfused_sequence(dtn, B, C, H):
 
 @pytest.mark.parametrize("dtn", ["f32", "bf16"])
 @pytest.mark.parametrize("B,C,H,heads", [(3, 32, 4, False), (5, 128, 8, True), (4, 256, 16, False), (515, 256, 16, False)])
-def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
+def test_block_dx_tail_bwd_equals_the_two_launches(ka_env, dtn, B, C, H, heads):
     """ka_block_dx_tail_bwd == ka_block_dx followed by ka_tail_bwd_fused (dout = its dx, out = its x), every output bit for bit;
     `heads`: the form that enters the tower (no residual branch above)."""
     dt = DT[dtn]
@@ -646,6 +646,7 @@ def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
     for name, a, b in (("du", du, du_r), ("dz", dz, dz_r), ("dse", dse, dse_r), ("dh", dh, dh_r), ("s1", s1, s1_r), ("s2", s2, s2_r)):
         assert torch.equal(a, b), name
     # the chain form without dz: same du / dse / dh / s1 / s2, and bf16(fmaf(du, gate, add)) IS the dz of the other forms
+    ka_env.set("KA_TAIL_GATE_P4", "0")
     du_g, _, dse, dh, s1, s2 = outs()
     gate_add = torch.full((2, B, C), float("nan"), device=DEV)
     _lib.call("ka_block_dx_tail_bwd_du_gate", dxc, du_up, x, pool, dpool, du_g, y, sc, sh, se, se1, W2, W1, mu, istd,
@@ -656,6 +657,20 @@ def test_block_dx_tail_bwd_equals_the_two_launches(dtn, B, C, H, heads):
     assert float((gate_add[0] - torch.sigmoid(se[:, :C])).abs().max()) < 1e-6
     dz_g = torch.addcmul(gate_add[1].double()[:, None, :], du_g.double(), gate_add[0].double()[:, None, :])   # one rounding, like fmaf
     assert torch.equal(dz_g.float().to(dt), dz_r), "gate form: dz"
+    # the half-width form of that launch (a thread owns four channels and every eighth square; the default for 512-thread bf16
+    # shapes, KA_TAIL_GATE_P4=0 selects the other): the same du, sums in another order
+    for p4 in ("0", "1"):
+        ka_env.set("KA_TAIL_GATE_P4", p4)
+        du_h, _, dse_h, dh_h, s1_h, s2_h = outs()
+        ga_h = torch.full((2, B, C), float("nan"), device=DEV)
+        _lib.call("ka_block_dx_tail_bwd_du_gate", dxc, du_up, x, pool, dpool, du_h, y, sc, sh, se, se1, W2, W1, mu, istd,
+                  ga_h[0], ga_h[1], dse_h, dh_h, s1_h, s2_h, B, C, H, code, st())
+        torch.cuda.synchronize()
+        assert torch.equal(du_h, du_r), p4
+        for name, a, b in (("dse", dse_h, dse_r), ("dh", dh_h, dh_r), ("s1", s1_h, s1_r), ("s2", s2_h, s2_r), ("gate_add", ga_h, gate_add)):
+            assert not bool(a.isnan().any()), (p4, name)
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, (p4, name)
+    ka_env.unset("KA_TAIL_GATE_P4")
     # ... and ka_block_dx takes a du as its dout: same result as from the unmasked gradient
     if not heads:
         dx2 = torch.empty_like(x)

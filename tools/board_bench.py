@@ -50,7 +50,12 @@ cases += [("block_dx_tail_bwd_du_gate, no dz (4R+1W)", 5, gate_form(4))]
 for name, passes, fn in cases:
     ms = timeit(fn)
     print(f"{name:44s} {ms * 1e3:8.1f} us  {passes * abytes / ms / 1e9:6.2f} TB/s", flush=True)
-for kb in (0, 2, 3, 6, 0, 6):
+for p4 in (1, 0, 1):
+    os.environ["KA_TAIL_GATE_P4"] = str(p4); _lib.reload_options()
+    ms = timeit(gate_form(4))
+    print(f"{'block_dx_tail_bwd_du_gate, KA_TAIL_GATE_P4=' + str(p4):44s} {ms * 1e3:8.1f} us  {5 * abytes / ms / 1e9:6.2f} TB/s", flush=True)
+os.environ.pop("KA_TAIL_GATE_P4"); _lib.reload_options()
+for kb in (0, 6):
     os.environ["KA_TAIL_FWD_KB"] = str(kb); _lib.reload_options()
     ms = timeit(lambda: _lib.call("ka_block_tail_fwd", y, sc, sh, se, x, out, pool, B, C, code, st()))
     print(f"{'block_tail_fwd (2R+1W), KA_TAIL_FWD_KB=' + str(kb):44s} {ms * 1e3:8.1f} us  {3 * abytes / ms / 1e9:6.2f} TB/s", flush=True)
